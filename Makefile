@@ -1,0 +1,21 @@
+# Builds the HIP extension in-tree (the .so travels to the GPU box with the repo snapshot).
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := montgomery_amd/csrc
+LIB := montgomery_amd/libmsm_hip.so
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function -Wno-unused-variable \
+            -Iinclude -I$(CSRC)
+
+all: $(LIB)
+
+$(CSRC)/constants_gen.h: $(CSRC)/gen_constants.py
+	python3 $(CSRC)/gen_constants.py
+
+$(LIB): $(CSRC)/msm_api.hip $(CSRC)/msm_kernels.h $(CSRC)/msm_gen.h $(CSRC)/field.h $(CSRC)/curve.h $(CSRC)/glv.h \
+        $(CSRC)/host_field.h $(CSRC)/constants_gen.h include/msm_hip.h
+	$(HIPCC) $(HIPFLAGS) $(CSRC)/msm_api.hip -o $(LIB)
+
+clean:
+	rm -f $(LIB)
+
+.PHONY: all clean

@@ -1,0 +1,134 @@
+/* C ABI of the MI355X MSM engine (libmsm_hip.so).
+ *
+ * This is the drop-in boundary for the reference's MSM path: the coarse `Curve.Parallel.*` surface
+ * that callers use (reference src/parallel.ts:135-145, 251-259) expressed over plain pointers and
+ * sizes, plus a few fine-grained operators of the wasm export table (src/field-msm.ts:86-123,
+ * src/scalar-glv.ts:41-51) exposed as GPU test kernels.  INTEGRATION.md shows the N-API / ctypes
+ * stubs that bind it.
+ *
+ * Wire formats are the reference's (`pointsFromBytes` / `scalarsFromBytes`, src/parallel.ts:97-133):
+ *   BLS12-377 G1 point : 96 bytes  = x || y, each 48-byte little-endian canonical integer (non-Montgomery)
+ *   Ed-on-BLS12-377    : 64 bytes  = x || y, each 32-byte little-endian
+ *   scalar             : 32 bytes little-endian
+ * The all-zero point encoding denotes the identity (the reference's byte format cannot express it;
+ * its object form has `isZero`, scripts/zprize23/submission-bls377.ts:83).
+ *
+ * Ownership: the caller owns every buffer it passes; the library owns all device memory.  Calls on
+ * one context are serialised by the caller; distinct contexts are independent.  Every function
+ * returns MSM_OK or an error code; msm_last_error() gives the message of the last failure.
+ */
+#ifndef MSM_HIP_H
+#define MSM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  MSM_OK = 0,
+  MSM_ERR_ARG = 1,         /* null pointer, bad length, bad window size, unknown curve */
+  MSM_ERR_HIP = 2,         /* HIP runtime failure (message has the HIP error string) */
+  MSM_ERR_POINT = 3,       /* coordinate >= p, or point not on the curve (when validation is requested) */
+  MSM_ERR_NO_POINTS = 4,   /* msm called before msm_set_points, or with n > resident points */
+  MSM_ERR_NO_DEVICE = 5    /* no usable GPU: there is no CPU fallback */
+};
+
+enum {
+  MSM_CURVE_BLS12_377_G1 = 0,     /* Weierstrass + GLV, batched-affine path: src/msm-batched-affine.ts */
+  MSM_CURVE_ED_ON_BLS12_377 = 1   /* twisted Edwards, generic path: src/msm-basic.ts */
+};
+
+typedef struct msm_ctx msm_ctx;
+
+/* Options of one msm call; mirrors `{c, useSafeAdditions}` of src/msm-batched-affine.ts:74-77.
+ * Zero-initialise for defaults. */
+typedef struct msm_opts {
+  int32_t c;            /* window size in bits, 0 = pick from N (windowSize, src/msm-common.ts:8-41, retuned) */
+  int32_t unsafe;       /* accepted for API parity with msmUnsafe; the GPU path always handles edge cases */
+  int32_t k_lo, k_hi;   /* window shard [k_lo, k_hi) for msm_window_sums; 0,0 = all windows */
+  int32_t reserved[4];
+} msm_opts;
+
+#define MSM_N_PHASES 8
+/* phase_ms indices (HIP-event timings on the context's stream; the reference returns a tic/toc log,
+ * src/msm-common.ts:176-214) */
+enum {
+  MSM_T_TOTAL = 0, MSM_T_UPLOAD = 1, MSM_T_DIGITS = 2, MSM_T_SORT = 3,
+  MSM_T_ACCUMULATE = 4, MSM_T_REDUCE = 5, MSM_T_FINAL = 6, MSM_T_ACC_ROUND1 = 7
+};
+
+typedef struct msm_result {
+  uint8_t x[48];        /* canonical affine result, little-endian (first 32 bytes used for Ed-on-BLS12-377) */
+  uint8_t y[48];
+  int32_t is_infinity;  /* Weierstrass only; twisted Edwards returns (0, 1) for the identity */
+  int32_t c;            /* window size used */
+  int32_t K;            /* number of windows */
+  int32_t rounds;       /* accumulation tree rounds of the last window group */
+  float phase_ms[MSM_N_PHASES];
+  uint64_t n_pairs;     /* affine pair additions issued (all rounds, all windows) */
+  uint64_t max_bucket;  /* largest bucket population seen */
+} msm_result;
+
+/* Context: binds one curve to one GPU (device index as seen by HIP). Replaces
+ * `Weierstraß.create(params)` / `TwistedEdwards.create(params)` (src/parallel.ts:40-66, 179-200). */
+int msm_ctx_create(msm_ctx** out, int curve, int device);
+void msm_ctx_destroy(msm_ctx* ctx);
+const char* msm_last_error(const msm_ctx* ctx);
+
+/* Upload + convert the base points and keep them resident (pointsFromBytes, src/parallel.ts:97-116:
+ * fromPackedBytes + toMontgomery; the endomorphism image beta*x is precomputed here once instead of
+ * per call as in preparePointsAndScalars, src/msm-batched-affine.ts:350-421).
+ * on_device != 0: `points` is a device pointer.  check_curve != 0: verify the curve equation. */
+int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, int check_curve);
+
+/* sum_i scalars[i] * points[i] over the first n resident points
+ * (msm / msmUnsafe, src/msm-batched-affine.ts:69-340, 587-598; for the Edwards curve msmBasic,
+ * src/msm-basic.ts:45-164).  on_device != 0: `scalars` already sits in HBM. */
+int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, msm_result* out);
+
+/* Window-sharded form for multi-GPU runs: computes the partition sums P_k for k in [k_lo, k_hi)
+ * only (src/msm-batched-affine.ts:42 "P_k = sum_l l * B_(k,l)") and writes them as
+ * (k_hi - k_lo) x 144 bytes: X || Y || Z homogeneous projective, 48-byte little-endian canonical
+ * integers.  Ranks exchange these with one all-gather; msm_combine finishes. */
+int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts,
+                    uint8_t* partials_out, msm_result* stats);
+
+/* S = sum_k 2^(c k) P_k over all K windows, then to affine (src/msm-batched-affine.ts:322-333,
+ * src/curve-projective.ts:335-349). */
+int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm_result* out);
+
+/* Window plan for n points: the c the library would pick and the resulting K. */
+int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_out, int32_t* K_out);
+
+/* Synthetic inputs generated on the GPU (randomPointsFast / randomScalars, src/curve-random.ts):
+ * n resident points P_i = a_i * G and, if `a_out` is non-null, the n scalars a_i (32-byte LE) so a
+ * caller can verify sum s_i P_i = (sum s_i a_i) G in O(n). */
+int msm_generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out);
+/* n uniformly random scalars < q, written to a device buffer owned by the context; returns its
+ * device pointer (valid until the next call) and optionally copies them to the host. */
+int msm_generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void** dev_ptr_out, uint8_t* host_out);
+
+/* Read resident point i back in wire format (debug / tests). */
+int msm_get_point(msm_ctx* ctx, uint64_t i, uint8_t* out_xy);
+
+/* ---- fine-grained GPU operators for parity tests (debug surface) ---- */
+enum { MSM_OP_MUL = 0, MSM_OP_SQR = 1, MSM_OP_ADD = 2, MSM_OP_SUB = 3, MSM_OP_INV = 4,
+       MSM_OP_TO_MONT = 5, MSM_OP_FROM_MONT = 6 };
+/* element-wise base-field op on n operands, each a 48-byte (32 for Ed) little-endian word string;
+ * MUL/SQR/ADD/SUB/INV act on Montgomery-form operands (radix 2^390 / 2^270) and return canonical
+ * Montgomery-form values, i.e. `multiply`, `square`, `add`, `subtract`, `inverse` of
+ * src/field-msm.ts:86-123. */
+int msm_test_fp(msm_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, uint64_t n);
+/* GLV `decompose` (src/wasm/glv.ts:68-169) of n 32-byte scalars: out = n x 40 bytes
+ * |s0| (16 B LE) || |s1| (16 B LE) || neg0 (u32) || neg1 (u32). */
+int msm_test_glv(msm_ctx* ctx, const uint8_t* scalars, uint8_t* out, uint64_t n);
+/* affine pair additions G_i + H_i through the batched-affine kernel (batchAddNew,
+ * src/curve-affine.ts:376-458): inputs n x 96-byte wire points, output n x 96 bytes. */
+int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t* out, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSM_HIP_H */

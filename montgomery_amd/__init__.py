@@ -1,0 +1,13 @@
+"""montgomery_amd: MI355X-native MSM engine behind the reference's msm() API shape.
+
+Host-side mirror of the reference's curve modules (src/parallel.ts, src/concrete/*) over the C ABI
+of libmsm_hip.so.  See DESIGN.md and INTEGRATION.md.
+"""
+from .api import (  # noqa: F401
+    BLS12377,
+    Weierstrass,
+    MsmContext,
+    compute_msm,
+    create_weierstrass,
+)
+from ._lib import MsmError  # noqa: F401

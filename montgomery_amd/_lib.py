@@ -1,0 +1,87 @@
+"""ctypes binding of libmsm_hip.so (the C ABI in include/msm_hip.h).
+
+There is no CPU fallback: if the HIP extension is missing or no GPU is usable, loading / creating
+a context raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
+
+MSM_OK, MSM_ERR_ARG, MSM_ERR_HIP, MSM_ERR_POINT, MSM_ERR_NO_POINTS, MSM_ERR_NO_DEVICE = range(6)
+CURVE_BLS12_377_G1 = 0
+CURVE_ED_ON_BLS12_377 = 1
+N_PHASES = 8
+PHASE_NAMES = ("total", "upload", "digits", "sort", "accumulate", "reduce", "final", "accumulate_round1")
+
+OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_INV, OP_TO_MONT, OP_FROM_MONT = range(7)
+
+# every symbol include/msm_hip.h declares
+EXPORTS = (
+    "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_set_points", "msm_run", "msm_window_sums",
+    "msm_combine", "msm_plan", "msm_generate_points", "msm_generate_scalars", "msm_get_point", "msm_test_fp",
+    "msm_test_glv", "msm_test_batch_add",
+)
+
+
+class MsmOpts(C.Structure):
+    _fields_ = [("c", C.c_int32), ("unsafe", C.c_int32), ("k_lo", C.c_int32), ("k_hi", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class MsmResult(C.Structure):
+    _fields_ = [
+        ("x", C.c_uint8 * 48),
+        ("y", C.c_uint8 * 48),
+        ("is_infinity", C.c_int32),
+        ("c", C.c_int32),
+        ("K", C.c_int32),
+        ("rounds", C.c_int32),
+        ("phase_ms", C.c_float * N_PHASES),
+        ("n_pairs", C.c_uint64),
+        ("max_bucket", C.c_uint64),
+    ]
+
+
+class MsmError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"msm error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP extension; raises if it has not been built (python __graft_entry__.py / make)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
+    lib.msm_ctx_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    lib.msm_ctx_create.restype = C.c_int
+    lib.msm_ctx_destroy.argtypes = [vp]
+    lib.msm_ctx_destroy.restype = None
+    lib.msm_last_error.argtypes = [vp]
+    lib.msm_last_error.restype = C.c_char_p
+    lib.msm_set_points.argtypes = [vp, vp, u64, C.c_int, C.c_int]
+    lib.msm_run.argtypes = [vp, vp, u64, C.c_int, C.POINTER(MsmOpts), C.POINTER(MsmResult)]
+    lib.msm_window_sums.argtypes = [vp, vp, u64, C.c_int, C.POINTER(MsmOpts), vp, C.POINTER(MsmResult)]
+    lib.msm_combine.argtypes = [vp, vp, i32, i32, C.POINTER(MsmResult)]
+    lib.msm_plan.argtypes = [vp, u64, C.POINTER(MsmOpts), C.POINTER(i32), C.POINTER(i32)]
+    lib.msm_generate_points.argtypes = [vp, u64, u64, vp]
+    lib.msm_generate_scalars.argtypes = [vp, u64, u64, C.POINTER(vp), vp]
+    lib.msm_get_point.argtypes = [vp, u64, vp]
+    lib.msm_test_fp.argtypes = [vp, C.c_int, vp, vp, vp, u64]
+    lib.msm_test_glv.argtypes = [vp, vp, vp, u64]
+    lib.msm_test_batch_add.argtypes = [vp, vp, vp, vp, u64]
+    for name in EXPORTS:
+        if name not in ("msm_ctx_destroy", "msm_last_error"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib

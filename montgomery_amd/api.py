@@ -1,0 +1,389 @@
+"""Host-side mirror of the reference's curve-module API for the MSM path.
+
+Reference surface being mirrored (names, argument meaning, error behaviour):
+  * ``Weierstraß.create(params)``                      src/parallel.ts:40-177
+  * ``Curve.Parallel.{msm, msmUnsafe, pointsFromBytes, scalarsFromBytes, getPointer,
+    getScalarPointer, randomPointsFast, randomScalars}``   src/parallel.ts:135-145
+  * ``msm(scalarPtr, pointPtr, N, verbose, {c, useSafeAdditions}) -> {result, log}``
+                                                        src/msm-batched-affine.ts:69-78, :339
+  * ``compute_msm(points, scalars) -> {x, y}``          scripts/zprize23/submission-bls377.ts:20-65
+
+In the reference "pointers" are byte offsets into the shared wasm memory; here they are small handle
+objects for buffers owned by the HIP library (points live in HBM in the library's row format, scalars
+either on the host or in HBM).  All arithmetic happens in libmsm_hip.so; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+from . import _lib
+from ._lib import MsmError, MsmOpts, MsmResult
+
+BytesLike = Union[bytes, bytearray, memoryview]
+
+
+# ---------------------------------------------------------------------------------------------
+# curve parameters (src/concrete/bls12-377.params.ts:11-45)
+# ---------------------------------------------------------------------------------------------
+
+
+@dataclass(frozen=True)
+class WeierstrassParams:
+    label: str
+    modulus: int
+    order: int
+    cofactor: int
+    a: int
+    b: int
+    generator: Tuple[int, int]
+    endomorphism: Tuple[int, int]  # (lambda, beta)
+
+
+BLS12_377_PARAMS = WeierstrassParams(
+    label="bls12-377",
+    modulus=0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001,
+    order=0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001,
+    cofactor=0x170B5D44300000000000000000000000,
+    a=0,
+    b=1,
+    generator=(
+        0x008848DEFE740A67C8FC6225BF87FF5485951E2CAA9D41BB188282C8BD37CB5CD5481512FFCD394EEAB9B16EB21BE9EF,
+        0x01914A69C5102EFF1F674F5D30AFEEC4BD7FB348CA3E52D96D182AD44FB82305C2FE3D3634A9591AFD82DE55559C8EA6,
+    ),
+    endomorphism=(
+        0x12AB655E9A2CA55660B44D1E5C37B00114885F32400000000000000000000000,
+        0x1AE3A4617C510EABC8756BA8F8C524EB8882A75CC9BC8E359064EE822FB5BFFD1E945779FFFFFFFFFFFFFFFFFFFFFFF,
+    ),
+)
+
+
+# ---------------------------------------------------------------------------------------------
+# low-level context
+# ---------------------------------------------------------------------------------------------
+
+
+@dataclass
+class AffineResult:
+    """Canonical affine result, as `Affine.toBigint` returns it (src/curve-affine.ts:220-233)."""
+
+    x: int
+    y: int
+    isZero: bool
+
+    def as_tuple(self) -> Optional[Tuple[int, int]]:
+        return None if self.isZero else (self.x, self.y)
+
+
+def _result_to_dict(res: MsmResult) -> Dict:
+    return {
+        "c": res.c,
+        "K": res.K,
+        "rounds": res.rounds,
+        "n_pairs": int(res.n_pairs),
+        "max_bucket": int(res.max_bucket),
+        "phase_ms": {name: float(res.phase_ms[i]) for i, name in enumerate(_lib.PHASE_NAMES)},
+    }
+
+
+class MsmContext:
+    """One curve bound to one GPU: thin object wrapper over the msm_* C functions."""
+
+    def __init__(self, curve: int = _lib.CURVE_BLS12_377_G1, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.msm_ctx_create(C.byref(h), curve, device)
+        if rc != _lib.MSM_OK:
+            raise MsmError(rc, "msm_ctx_create failed (no usable GPU?) -- there is no CPU fallback")
+        self._h = h
+        self.curve = curve
+        self.device = device
+        self.n_points = 0
+        self.coord_bytes = 48 if curve == _lib.CURVE_BLS12_377_G1 else 32
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.msm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc != _lib.MSM_OK:
+            raise MsmError(rc, self._lib.msm_last_error(self._h).decode())
+
+    # -- points ---------------------------------------------------------------------------
+    def set_points(self, points: BytesLike, check_curve: bool = False) -> int:
+        step = 2 * self.coord_bytes
+        if len(points) % step:
+            raise MsmError(_lib.MSM_ERR_ARG, f"point buffer length {len(points)} is not a multiple of {step}")
+        n = len(points) // step
+        buf = (C.c_uint8 * max(len(points), 1)).from_buffer_copy(bytes(points) or b"\0")
+        self._check(self._lib.msm_set_points(self._h, buf, n, 0, int(check_curve)))
+        self.n_points = n
+        return n
+
+    def set_points_device(self, dev_ptr: int, n: int, check_curve: bool = False) -> int:
+        self._check(self._lib.msm_set_points(self._h, C.c_void_p(dev_ptr), n, 1, int(check_curve)))
+        self.n_points = n
+        return n
+
+    def generate_points(self, n: int, seed: int = 1, want_scalars: bool = False) -> Optional[bytes]:
+        out = (C.c_uint8 * (32 * n))() if want_scalars and n else None
+        self._check(self._lib.msm_generate_points(self._h, n, seed, out))
+        self.n_points = n
+        return bytes(out) if out is not None else (b"" if want_scalars else None)
+
+    def generate_scalars(self, n: int, seed: int = 1, to_host: bool = False) -> Tuple[int, Optional[bytes]]:
+        dev = C.c_void_p()
+        out = (C.c_uint8 * (32 * n))() if to_host and n else None
+        self._check(self._lib.msm_generate_scalars(self._h, n, seed, C.byref(dev), out))
+        return int(dev.value or 0), (bytes(out) if out is not None else None)
+
+    def get_point(self, i: int) -> Optional[Tuple[int, int]]:
+        out = (C.c_uint8 * 96)()
+        self._check(self._lib.msm_get_point(self._h, i, out))
+        b = bytes(out)
+        x, y = int.from_bytes(b[:48], "little"), int.from_bytes(b[48:], "little")
+        return None if (x == 0 and y == 0) else (x, y)
+
+    # -- msm ------------------------------------------------------------------------------
+    def plan(self, n: int, c: Optional[int] = None) -> Tuple[int, int]:
+        opts = MsmOpts(c=c or 0)
+        cc, kk = C.c_int32(), C.c_int32()
+        self._check(self._lib.msm_plan(self._h, n, C.byref(opts), C.byref(cc), C.byref(kk)))
+        return cc.value, kk.value
+
+    def run(self, scalars: BytesLike, c: Optional[int] = None, unsafe: bool = False) -> Tuple[AffineResult, Dict]:
+        if len(scalars) % 32:
+            raise MsmError(_lib.MSM_ERR_ARG, f"scalar buffer length {len(scalars)} is not a multiple of 32")
+        n = len(scalars) // 32
+        buf = (C.c_uint8 * max(len(scalars), 1)).from_buffer_copy(bytes(scalars) or b"\0")
+        return self._run(buf, n, 0, c, unsafe)
+
+    def run_device(self, dev_ptr: int, n: int, c: Optional[int] = None, unsafe: bool = False) -> Tuple[AffineResult, Dict]:
+        return self._run(C.c_void_p(dev_ptr), n, 1, c, unsafe)
+
+    def _run(self, ptr, n: int, on_device: int, c: Optional[int], unsafe: bool) -> Tuple[AffineResult, Dict]:
+        opts = MsmOpts(c=c or 0, unsafe=int(unsafe))
+        res = MsmResult()
+        self._check(self._lib.msm_run(self._h, ptr, n, on_device, C.byref(opts), C.byref(res)))
+        nb = self.coord_bytes
+        out = AffineResult(
+            x=int.from_bytes(bytes(res.x)[:nb], "little"),
+            y=int.from_bytes(bytes(res.y)[:nb], "little"),
+            isZero=bool(res.is_infinity),
+        )
+        return out, _result_to_dict(res)
+
+    def window_sums(self, scalars: Union[BytesLike, int], n: int, k_lo: int, k_hi: int, c: Optional[int] = None,
+                    on_device: bool = False) -> Tuple[bytes, Dict]:
+        """Partition sums P_k, k in [k_lo, k_hi): (k_hi - k_lo) x 144 bytes (X, Y, Z)."""
+        opts = MsmOpts(c=c or 0, k_lo=k_lo, k_hi=k_hi)
+        res = MsmResult()
+        out = (C.c_uint8 * (144 * max(k_hi - k_lo, 1)))()
+        if on_device:
+            ptr = C.c_void_p(int(scalars))
+        else:
+            ptr = (C.c_uint8 * max(32 * n, 1)).from_buffer_copy(bytes(scalars) or b"\0")
+        self._check(self._lib.msm_window_sums(self._h, ptr, n, int(on_device), C.byref(opts), out, C.byref(res)))
+        return bytes(out)[: 144 * (k_hi - k_lo)], _result_to_dict(res)
+
+    def combine(self, partials: BytesLike, K: int, c: int) -> AffineResult:
+        buf = (C.c_uint8 * len(partials)).from_buffer_copy(bytes(partials))
+        res = MsmResult()
+        self._check(self._lib.msm_combine(self._h, buf, K, c, C.byref(res)))
+        nb = self.coord_bytes
+        return AffineResult(int.from_bytes(bytes(res.x)[:nb], "little"), int.from_bytes(bytes(res.y)[:nb], "little"), bool(res.is_infinity))
+
+    # -- fine-grained operators (GPU test kernels) -------------------------------------------
+    def test_fp(self, op: int, a: BytesLike, b: Optional[BytesLike] = None) -> bytes:
+        nb = self.coord_bytes
+        n = len(a) // nb
+        b = a if b is None else b
+        ba = (C.c_uint8 * len(a)).from_buffer_copy(bytes(a))
+        bb = (C.c_uint8 * len(b)).from_buffer_copy(bytes(b))
+        out = (C.c_uint8 * len(a))()
+        self._check(self._lib.msm_test_fp(self._h, op, ba, bb, out, n))
+        return bytes(out)
+
+    def test_glv(self, scalars: BytesLike) -> List[Tuple[int, int, bool, bool]]:
+        n = len(scalars) // 32
+        bs = (C.c_uint8 * len(scalars)).from_buffer_copy(bytes(scalars))
+        out = (C.c_uint8 * (40 * n))()
+        self._check(self._lib.msm_test_glv(self._h, bs, out, n))
+        raw = bytes(out)
+        res = []
+        for i in range(n):
+            r = raw[40 * i : 40 * i + 40]
+            res.append((int.from_bytes(r[:16], "little"), int.from_bytes(r[16:32], "little"),
+                        bool(int.from_bytes(r[32:36], "little")), bool(int.from_bytes(r[36:40], "little"))))
+        return res
+
+    def test_batch_add(self, g: BytesLike, h: BytesLike) -> bytes:
+        n = len(g) // (2 * self.coord_bytes)
+        bg = (C.c_uint8 * len(g)).from_buffer_copy(bytes(g))
+        bh = (C.c_uint8 * len(h)).from_buffer_copy(bytes(h))
+        out = (C.c_uint8 * len(g))()
+        self._check(self._lib.msm_test_batch_add(self._h, bg, bh, out, n))
+        return bytes(out)
+
+
+# ---------------------------------------------------------------------------------------------
+# reference-shaped facade
+# ---------------------------------------------------------------------------------------------
+
+
+@dataclass
+class PointPtr:
+    """Handle standing in for the reference's `pointPtr` (byte offset of an affine point array)."""
+
+    size: int = 0
+    n: int = 0
+
+
+@dataclass
+class ScalarPtr:
+    """Handle standing in for `scalarPtr`: host bytes or a device pointer with a count."""
+
+    size: int = 0
+    data: bytes = b""
+    dev_ptr: int = 0
+    n: int = 0
+
+
+class _Parallel:
+    """`Curve.Parallel` (src/parallel.ts:135-145)."""
+
+    def __init__(self, ctx: MsmContext, params: WeierstrassParams):
+        self._ctx = ctx
+        self._params = params
+
+    def getPointer(self, size: int) -> PointPtr:
+        return PointPtr(size=size)
+
+    def getScalarPointer(self, size: int) -> ScalarPtr:
+        return ScalarPtr(size=size)
+
+    def pointsFromBytes(self, pointPtr: PointPtr, pointInput: BytesLike, n: int) -> None:
+        """src/parallel.ts:97-116: n points of 96 bytes (x || y little-endian) -> resident device points."""
+        self._ctx.set_points(bytes(pointInput)[: 96 * n])
+        pointPtr.n = n
+
+    def scalarsFromBytes(self, scalarPtr: ScalarPtr, scalarInput: BytesLike, n: int) -> None:
+        """src/parallel.ts:119-133: n scalars of 32 bytes little-endian."""
+        scalarPtr.data = bytes(scalarInput)[: 32 * n]
+        scalarPtr.dev_ptr = 0
+        scalarPtr.n = n
+
+    def randomPointsFast(self, n: int, seed: int = 1) -> PointPtr:
+        """src/curve-random.ts:14-92 (generated on the GPU; the seed is explicit, the reference is unseeded)."""
+        self._ctx.generate_points(n, seed)
+        return PointPtr(size=96 * n, n=n)
+
+    def randomScalars(self, n: int, seed: int = 1) -> ScalarPtr:
+        """src/curve-random.ts:151-194."""
+        dev, _ = self._ctx.generate_scalars(n, seed)
+        return ScalarPtr(size=32 * n, dev_ptr=dev, n=n)
+
+    def msm(self, scalarPtr: ScalarPtr, pointPtr: PointPtr, N: int, verboseTiming: bool = False,
+            options: Optional[Dict] = None) -> Dict:
+        """`msm` (src/msm-batched-affine.ts:69-340): returns {"result": AffineResult, "log": [...]}.
+        options: {"c": window bits, "useSafeAdditions": bool}."""
+        options = options or {}
+        if N > self._ctx.n_points:
+            raise MsmError(_lib.MSM_ERR_NO_POINTS, f"{N} scalars but {self._ctx.n_points} resident points")
+        unsafe = not options.get("useSafeAdditions", True)
+        if scalarPtr.dev_ptr:
+            res, info = self._ctx.run_device(scalarPtr.dev_ptr, N, options.get("c"), unsafe)
+        else:
+            res, info = self._ctx.run(scalarPtr.data[: 32 * N], options.get("c"), unsafe)
+        log: List = []
+        if verboseTiming:
+            log.append([{"n": (N - 1).bit_length() if N > 1 else 0, "K": info["K"], "c": info["c"]}])
+            for name, ms in info["phase_ms"].items():
+                log.append([f"{name}... {ms:.3f}ms"])
+        return {"result": res, "log": log, "info": info}
+
+    def msmUnsafe(self, scalarPtr: ScalarPtr, pointPtr: PointPtr, N: int, verboseTiming: bool = False,
+                  options: Optional[Dict] = None) -> Dict:
+        """`msmUnsafe` (src/msm-batched-affine.ts:587-598). The GPU kernels always handle the edge cases."""
+        options = dict(options or {})
+        options["useSafeAdditions"] = False
+        return self.msm(scalarPtr, pointPtr, N, verboseTiming, options)
+
+
+class Weierstrass:
+    """Curve module as `Weierstraß.create(params)` returns it (src/parallel.ts:147-160), MSM path only."""
+
+    def __init__(self, params: WeierstrassParams, device: int = 0):
+        if params.label != "bls12-377":
+            raise MsmError(_lib.MSM_ERR_ARG, f"curve {params.label!r} has no device constants (only bls12-377 G1)")
+        self.params = params
+        self.context = MsmContext(_lib.CURVE_BLS12_377_G1, device)
+        self.Parallel = _Parallel(self.context, params)
+
+    @classmethod
+    def create(cls, params: WeierstrassParams, device: int = 0) -> "Weierstrass":
+        return cls(params, device)
+
+
+def create_weierstrass(params: WeierstrassParams = BLS12_377_PARAMS, device: int = 0) -> Weierstrass:
+    return Weierstrass.create(params, device)
+
+
+class _LazyCurve:
+    """`BLS12377` of src/concrete/bls12-377.ts: created on first use (needs a GPU)."""
+
+    def __init__(self, params: WeierstrassParams):
+        self._params = params
+        self._curve: Optional[Weierstrass] = None
+
+    def _get(self) -> Weierstrass:
+        if self._curve is None:
+            self._curve = Weierstrass.create(self._params)
+        return self._curve
+
+    def __getattr__(self, name):
+        return getattr(self._get(), name)
+
+
+BLS12377 = _LazyCurve(BLS12_377_PARAMS)
+
+
+def compute_msm(inputPoints, inputScalars, curve: Optional[Weierstrass] = None) -> Dict[str, int]:
+    """ZPrize entry point, scripts/zprize23/submission-bls377.ts:20-65.
+
+    inputPoints: bytes (n x 96, x || y little-endian) or a list of {"x", "y", "isZero"} dicts;
+    inputScalars: bytes (n x 32 little-endian) or a list of ints.  Returns {"x": int, "y": int}.
+    """
+    cv = curve or BLS12377._get()
+    if isinstance(inputScalars, (bytes, bytearray, memoryview)):
+        sbytes = bytes(inputScalars)
+    else:
+        sbytes = b"".join(int(s).to_bytes(32, "little") for s in inputScalars)
+    n = len(sbytes) // 32
+    if isinstance(inputPoints, (bytes, bytearray, memoryview)):
+        pbytes = bytes(inputPoints)
+    else:
+        chunks = []
+        for P in inputPoints:
+            if P.get("isZero"):
+                chunks.append(b"\0" * 96)
+            else:
+                chunks.append(int(P["x"]).to_bytes(48, "little") + int(P["y"]).to_bytes(48, "little"))
+        pbytes = b"".join(chunks)
+    par = cv.Parallel
+    pp = par.getPointer(len(pbytes))
+    sp = par.getScalarPointer(len(sbytes))
+    par.pointsFromBytes(pp, pbytes, n)
+    par.scalarsFromBytes(sp, sbytes, n)
+    same = n > 1 and pbytes[:96] == pbytes[96:192]
+    out = par.msm(sp, pp, n) if same else par.msmUnsafe(sp, pp, n)
+    res = out["result"]
+    return {"x": res.x, "y": res.y}

@@ -1,0 +1,314 @@
+// Montgomery field arithmetic for gfx950, one field element per lane.
+//
+// Replaces the reference's generated-WebAssembly field backend:
+//   multiply / square      src/wasm/multiply-montgomery.ts:58-215
+//   add / sub / reduce     src/wasm/field-arithmetic.ts:32-166
+//   inverse                src/wasm/inverse.ts:191-218 (here: Fermat chain, see fe_inv)
+//   packed-bytes codecs    src/wasm/field-helpers.ts:211-301
+//
+// Register form ("Fe"): NL limbs of 30 bits, radix R = 2^(30*NL) (2^390 for the 377-bit prime,
+// 2^270 for the 253-bit prime).  30-bit limbs let a whole 13-term column of 60-bit products sit in
+// a 64-bit v_mad_u64_u32 accumulator without carry handling -- gfx950 issues v_mad_u64_u32 at
+// nearly the plain-VALU rate (measured: tools/ubench_int.hip), so instruction count is what
+// matters and carry-flag chains for 32-bit limbs would double it.
+// Memory form: NW packed 32-bit little-endian words, Montgomery representation, CANONICAL
+// (value in [0, p)) so equality is a plain word compare.
+//
+// Value-range discipline (the reference keeps values < 2p with R = 2^406; we have R >= 2^13 p):
+//   fe_mul/fe_sqr accept any operands with a*b < 2^12 * p * p and return a value < p + p/2,
+//   so sums/differences of a few elements may be multiplied without reduction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "constants_gen.h"
+
+namespace msm {
+
+constexpr int LB = 30;
+constexpr uint32_t LMASK = (1u << LB) - 1;
+
+#define MSM_DEV __device__ __forceinline__
+
+template <class C>
+struct Fe {
+  uint32_t l[C::NL];
+};
+
+// ---------------------------------------------------------------- pack / unpack
+
+// words (32-bit packed, little endian) -> 30-bit limbs
+template <class C>
+MSM_DEV void fe_unpack(Fe<C>& r, const uint32_t (&w)[C::NW]) {
+#pragma unroll
+  for (int i = 0; i < C::NL; i++) {
+    const int bit = LB * i;
+    const int wi = bit / 32, sh = bit % 32;
+    uint32_t lo = wi < C::NW ? w[wi] : 0u;
+    uint32_t hi = (wi + 1) < C::NW ? w[wi + 1] : 0u;
+    uint32_t v = sh == 0 ? lo : __funnelshift_r(lo, hi, sh);
+    r.l[i] = v & LMASK;
+  }
+}
+
+// 30-bit limbs (normalized, value < 2^(32*NW)) -> packed words
+template <class C>
+MSM_DEV void fe_pack(uint32_t (&w)[C::NW], const Fe<C>& a) {
+#pragma unroll
+  for (int j = 0; j < C::NW; j++) {
+    const int bit = 32 * j;
+    const int li = bit / LB, sh = bit % LB;  // word j starts inside limb li at bit sh
+    uint32_t v = a.l[li] >> sh;
+    int have = LB - sh;
+    if (li + 1 < C::NL) {
+      v |= a.l[li + 1] << have;
+      have += LB;
+      if (have < 32 && li + 2 < C::NL) v |= a.l[li + 2] << have;
+    }
+    w[j] = v;
+  }
+}
+
+// ---------------------------------------------------------------- linear ops on limbs
+
+// carry-normalize limbs that may have grown to < 2^32 (unsigned)
+template <class C>
+MSM_DEV void fe_norm(Fe<C>& a) {
+#pragma unroll
+  for (int i = 0; i + 1 < C::NL; i++) {
+    a.l[i + 1] += a.l[i] >> LB;
+    a.l[i] &= LMASK;
+  }
+}
+
+// r = a + b (no modular reduction; value bound adds)
+template <class C>
+MSM_DEV void fe_add(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < C::NL; i++) {
+    uint32_t t = a.l[i] + b.l[i] + c;
+    if (i + 1 < C::NL) {
+      c = t >> LB;
+      r.l[i] = t & LMASK;
+    } else {
+      r.l[i] = t;
+    }
+  }
+}
+
+// limb i of K*p for K in {1, 2, 4} (compile-time table pick; tables are only ever value-used
+// so they stay compile-time constants in device code)
+template <class C, int K>
+MSM_DEV constexpr uint32_t fe_kp_limb(int i) {
+  static_assert(K == 1 || K == 2 || K == 4, "multiples available: p, 2p, 4p");
+  return K == 1 ? C::P[i] : (K == 2 ? C::P2[i] : C::P4[i]);
+}
+
+// r = a - b + K*p, requires b < K*p so the result is >= 0.
+template <class C, int K>
+MSM_DEV void fe_sub_k(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) {
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < C::NL; i++) {
+    int32_t t = (int32_t)(a.l[i] + fe_kp_limb<C, K>(i)) - (int32_t)b.l[i] + c;
+    if (i + 1 < C::NL) {
+      c = t >> LB;  // arithmetic
+      r.l[i] = (uint32_t)t & LMASK;
+    } else {
+      r.l[i] = (uint32_t)t;
+    }
+  }
+}
+template <class C>
+MSM_DEV void fe_sub_p(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) { fe_sub_k<C, 1>(r, a, b); }   // b < p
+template <class C>
+MSM_DEV void fe_sub_2p(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) { fe_sub_k<C, 2>(r, a, b); }  // b < 2p
+template <class C>
+MSM_DEV void fe_sub_4p(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) { fe_sub_k<C, 4>(r, a, b); }  // b < 4p
+
+// a -= K*p if a >= K*p
+template <class C, int K>
+MSM_DEV void fe_cond_sub(Fe<C>& a) {
+  uint32_t t[C::NL];
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < C::NL; i++) {
+    int32_t v = (int32_t)a.l[i] - (int32_t)fe_kp_limb<C, K>(i) + c;
+    if (i + 1 < C::NL) {
+      c = v >> LB;
+      t[i] = (uint32_t)v & LMASK;
+    } else {
+      c = v >> 31;  // sign of the top limb = sign of the whole difference
+      t[i] = (uint32_t)v;
+    }
+  }
+  bool neg = c != 0;
+#pragma unroll
+  for (int i = 0; i < C::NL; i++) a.l[i] = neg ? a.l[i] : t[i];
+}
+
+// canonical form for a value < 2p / < 4p
+template <class C>
+MSM_DEV void fe_reduce_2p(Fe<C>& a) { fe_cond_sub<C, 1>(a); }
+template <class C>
+MSM_DEV void fe_reduce_4p(Fe<C>& a) {
+  fe_cond_sub<C, 2>(a);
+  fe_cond_sub<C, 1>(a);
+}
+
+template <class C>
+MSM_DEV bool fe_is_zero_canonical(const Fe<C>& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < C::NL; i++) o |= a.l[i];
+  return o == 0;
+}
+
+template <class C>
+MSM_DEV void fe_set_one(Fe<C>& r) {  // Montgomery form of 1
+#pragma unroll
+  for (int i = 0; i < C::NL; i++) r.l[i] = C::ONE[i];
+}
+template <class C>
+MSM_DEV void fe_set_zero(Fe<C>& r) {
+#pragma unroll
+  for (int i = 0; i < C::NL; i++) r.l[i] = 0;
+}
+
+template <class C>
+MSM_DEV void fe_select(Fe<C>& r, bool c, const Fe<C>& a, const Fe<C>& b) {  // r = c ? a : b
+#pragma unroll
+  for (int i = 0; i < C::NL; i++) r.l[i] = c ? a.l[i] : b.l[i];
+}
+
+// ---------------------------------------------------------------- Montgomery product
+
+// Interleaved (CIOS-style) Montgomery multiplication on 30-bit limbs with 64-bit column
+// accumulators.  Row i adds a_i*b and m_i*p, then shifts one limb.  p == 1 mod 2^30 for both
+// primes, so m_i = -t_0 mod 2^30 needs no multiply and the j = 0 product is known.
+// One carry sweep after row CARRY_ROW keeps every accumulator < 2^64
+// (at most 14 products of < 2^60 before it, 12 + a small carry after it).
+template <class C>
+MSM_DEV void fe_mul(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) {
+  constexpr int N = C::NL;
+  static_assert(C::MU == LMASK, "modulus must be 1 mod 2^30");
+  static_assert(C::P[0] == 1, "modulus must be 1 mod 2^30");
+  uint64_t t[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) t[j] = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+#pragma unroll
+    for (int j = 0; j < N; j++) t[j] += (uint64_t)a.l[i] * b.l[j];
+    uint32_t lo = (uint32_t)t[0] & LMASK;
+    uint32_t m = (0u - lo) & LMASK;
+    // t[0] + m*P[0] = t[0] + m is a multiple of 2^30
+    uint64_t carry = (t[0] + m) >> LB;
+#pragma unroll
+    for (int j = 1; j < N; j++) t[j] += (uint64_t)m * C::P[j];
+    t[1] += carry;
+#pragma unroll
+    for (int j = 0; j + 1 < N; j++) t[j] = t[j + 1];
+    t[N - 1] = 0;
+    if (N > 7 && i == N / 2) {
+#pragma unroll
+      for (int j = 0; j + 1 < N; j++) {
+        t[j + 1] += t[j] >> LB;
+        t[j] &= LMASK;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j + 1 < N; j++) {
+    t[j + 1] += t[j] >> LB;
+    r.l[j] = (uint32_t)t[j] & LMASK;
+  }
+  r.l[N - 1] = (uint32_t)t[N - 1];
+}
+
+template <class C>
+MSM_DEV void fe_sqr(Fe<C>& r, const Fe<C>& a) {
+  constexpr int N = C::NL;
+  // column-wise square with doubled cross terms folded into the same interleaved reduction:
+  // row i contributes a_i^2 at column 2i and 2*a_i*a_j (j > i) at column i+j.  We run it as
+  // rows over a "doubled" operand so the reduction interleave stays identical to fe_mul.
+  uint32_t a2[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) a2[j] = a.l[j] << 1;  // < 2^31
+  uint64_t t[2 * N];
+#pragma unroll
+  for (int j = 0; j < 2 * N; j++) t[j] = 0;
+  // full product first (no overflow: column sums < 7 * 2^61 + 2^60 < 2^64)
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    t[2 * i] += (uint64_t)a.l[i] * a.l[i];
+#pragma unroll
+    for (int j = i + 1; j < N; j++) t[i + j] += (uint64_t)a.l[i] * a2[j];
+  }
+  // normalize the low half so the reduction rows cannot overflow the accumulators
+#pragma unroll
+  for (int j = 0; j + 1 < 2 * N; j++) {
+    t[j + 1] += t[j] >> LB;
+    t[j] &= LMASK;
+  }
+  // reduction: N rows of m_i * p
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    uint32_t lo = (uint32_t)t[i] & LMASK;
+    uint32_t m = (0u - lo) & LMASK;
+    uint64_t carry = (t[i] + m) >> LB;
+#pragma unroll
+    for (int j = 1; j < N; j++) t[i + j] += (uint64_t)m * C::P[j];
+    t[i + 1] += carry;
+  }
+#pragma unroll
+  for (int j = N; j + 1 < 2 * N; j++) {
+    t[j + 1] += t[j] >> LB;
+    r.l[j - N] = (uint32_t)t[j] & LMASK;
+  }
+  r.l[N - 1] = (uint32_t)t[2 * N - 1];
+}
+
+// ---------------------------------------------------------------- inversion
+
+// a^(p-2) by plain MSB-first square-and-multiply (uniform control flow: the exponent is a
+// compile-time constant, so no lane diverges).  Input any value < 2p, Montgomery form; output
+// Montgomery form of the inverse, < p + p/2.  a == 0 gives 0 (callers exclude it; the reference
+// traps: src/wasm/inverse.ts:198-199).
+template <class C>
+MSM_DEV void fe_inv(Fe<C>& r, const Fe<C>& a) {
+  Fe<C> acc;
+  fe_set_one<C>(acc);
+#pragma unroll 1
+  for (int bit = C::BITS - 1; bit >= 0; bit--) {
+    fe_sqr<C>(acc, acc);
+    if ((C::PM2W[bit / 32] >> (bit % 32)) & 1u) fe_mul<C>(acc, acc, a);
+  }
+  r = acc;
+}
+
+// ---------------------------------------------------------------- memory helpers
+
+// canonical packed element <-> registers, AoS (contiguous NW words, 16-byte aligned)
+template <class C>
+MSM_DEV void fe_load(Fe<C>& r, const uint32_t* p) {
+  uint32_t w[C::NW];
+  const uint4* p4 = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int j = 0; j < C::NW / 4; j++) {
+    uint4 v = p4[j];
+    w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+  }
+  fe_unpack<C>(r, w);
+}
+
+template <class C>
+MSM_DEV void fe_store(uint32_t* p, const Fe<C>& a) {
+  uint32_t w[C::NW];
+  fe_pack<C>(w, a);
+  uint4* p4 = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int j = 0; j < C::NW / 4; j++) p4[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+}
+
+}  // namespace msm

@@ -1,0 +1,224 @@
+// Host-side 384-bit prime-field and projective-curve arithmetic for the O(K*c) tail of the MSM:
+// the Horner combination of the K window sums and the final projective -> affine conversion.
+// The reference runs exactly this step on its main thread as well
+// (src/msm-batched-affine.ts:306-333 "this whole stage takes < 0.2ms and is done on the main thread",
+//  toAffine: src/curve-projective.ts:335-349).  It is independent of N: K*c doublings + K additions.
+//
+// 6 x 64-bit limbs, Montgomery radix 2^384, values kept canonical in [0, p).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+namespace msm_host {
+
+typedef unsigned __int128 u128;
+
+struct Fe6 {
+  uint64_t v[6];
+};
+
+struct Field6 {
+  Fe6 p;
+  uint64_t pinv;  // -p^-1 mod 2^64
+  Fe6 one;        // 2^384 mod p
+  Fe6 r2;         // 2^768 mod p
+
+  static bool ge(const Fe6& a, const Fe6& b) {
+    for (int i = 5; i >= 0; i--) {
+      if (a.v[i] > b.v[i]) return true;
+      if (a.v[i] < b.v[i]) return false;
+    }
+    return true;
+  }
+  static bool is_zero(const Fe6& a) {
+    uint64_t o = 0;
+    for (int i = 0; i < 6; i++) o |= a.v[i];
+    return o == 0;
+  }
+  static bool eq(const Fe6& a, const Fe6& b) { return memcmp(a.v, b.v, sizeof(a.v)) == 0; }
+
+  void sub_raw(Fe6& r, const Fe6& a, const Fe6& b) const {
+    u128 br = 0;
+    for (int i = 0; i < 6; i++) {
+      u128 d = (u128)a.v[i] - b.v[i] - (uint64_t)br;
+      r.v[i] = (uint64_t)d;
+      br = (d >> 64) & 1;
+    }
+  }
+  void add(Fe6& r, const Fe6& a, const Fe6& b) const {
+    u128 c = 0;
+    Fe6 t;
+    for (int i = 0; i < 6; i++) {
+      c += (u128)a.v[i] + b.v[i];
+      t.v[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    if (c || ge(t, p)) sub_raw(t, t, p);
+    r = t;
+  }
+  void sub(Fe6& r, const Fe6& a, const Fe6& b) const {
+    Fe6 t;
+    if (ge(a, b)) {
+      sub_raw(t, a, b);
+    } else {
+      Fe6 u;
+      sub_raw(u, b, a);
+      sub_raw(t, p, u);
+    }
+    r = t;
+  }
+  void dbl(Fe6& r, const Fe6& a) const { add(r, a, a); }
+
+  // Montgomery product a*b*2^-384 mod p (CIOS), inputs canonical
+  void mul(Fe6& r, const Fe6& a, const Fe6& b) const {
+    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 6; i++) {
+      u128 c = 0;
+      for (int j = 0; j < 6; j++) {
+        c += (u128)a.v[i] * b.v[j] + t[j];
+        t[j] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[6];
+      t[6] = (uint64_t)c;
+      t[7] = (uint64_t)(c >> 64);
+      uint64_t m = t[0] * pinv;
+      c = (u128)m * p.v[0] + t[0];
+      c >>= 64;
+      for (int j = 1; j < 6; j++) {
+        c += (u128)m * p.v[j] + t[j];
+        t[j - 1] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[6];
+      t[5] = (uint64_t)c;
+      t[6] = t[7] + (uint64_t)(c >> 64);
+      t[7] = 0;
+    }
+    Fe6 o;
+    for (int i = 0; i < 6; i++) o.v[i] = t[i];
+    if (t[6] || ge(o, p)) sub_raw(o, o, p);
+    r = o;
+  }
+  void sqr(Fe6& r, const Fe6& a) const { mul(r, a, a); }
+
+  // a^(p-2), Montgomery in / out
+  void inv(Fe6& r, const Fe6& a) const {
+    Fe6 e = p;
+    // e = p - 2
+    Fe6 two = {{2, 0, 0, 0, 0, 0}};
+    sub_raw(e, p, two);
+    Fe6 acc = one;
+    for (int bit = 383; bit >= 0; bit--) {
+      sqr(acc, acc);
+      if ((e.v[bit / 64] >> (bit % 64)) & 1) mul(acc, acc, a);
+    }
+    r = acc;
+  }
+
+  void init(const uint32_t* p_words12) {
+    for (int i = 0; i < 6; i++) p.v[i] = (uint64_t)p_words12[2 * i] | ((uint64_t)p_words12[2 * i + 1] << 32);
+    // Newton iteration for p^-1 mod 2^64
+    uint64_t x = p.v[0];
+    for (int i = 0; i < 6; i++) x *= 2 - p.v[0] * x;
+    pinv = (uint64_t)0 - x;
+    // one = 2^384 mod p by repeated doubling of 1
+    Fe6 t = {{1, 0, 0, 0, 0, 0}};
+    for (int i = 0; i < 384; i++) add(t, t, t);
+    one = t;
+    for (int i = 0; i < 384; i++) add(t, t, t);
+    r2 = t;
+  }
+  // 2^k mod p as a plain (non-Montgomery) integer
+  Fe6 pow2(int k) const {
+    Fe6 t = {{1, 0, 0, 0, 0, 0}};
+    for (int i = 0; i < k; i++) add(t, t, t);
+    return t;
+  }
+};
+
+struct Proj6 {
+  Fe6 X, Y, Z;
+};
+
+struct Curve6 {
+  Field6 F;
+
+  bool is_zero(const Proj6& P) const { return Field6::is_zero(P.Z); }
+  Proj6 zero() const {
+    Proj6 P;
+    memset(&P, 0, sizeof(P));
+    P.Y = F.one;
+    return P;
+  }
+  // dbl-1998-cmo-2, a = 0 (src/curve-projective.ts:202-253)
+  Proj6 dbl(const Proj6& P) const {
+    if (is_zero(P)) return zero();
+    Fe6 w, s, ss, sss, R, B, h, t, u;
+    F.sqr(t, P.X);
+    F.add(w, t, t);
+    F.add(w, w, t);
+    F.mul(s, P.Y, P.Z);
+    F.sqr(ss, s);
+    F.mul(sss, s, ss);
+    F.mul(R, P.Y, s);
+    F.mul(B, P.X, R);
+    Fe6 B2, B4, B8;
+    F.dbl(B2, B);
+    F.dbl(B4, B2);
+    F.dbl(B8, B4);
+    F.sqr(h, w);
+    F.sub(h, h, B8);
+    Proj6 Q;
+    F.mul(t, h, s);
+    F.dbl(Q.X, t);
+    F.sub(u, B4, h);
+    F.mul(u, w, u);
+    F.sqr(t, R);
+    F.dbl(t, t);
+    F.dbl(t, t);
+    F.dbl(t, t);
+    F.sub(Q.Y, u, t);
+    F.dbl(t, sss);
+    F.dbl(t, t);
+    F.dbl(Q.Z, t);
+    return Q;
+  }
+  // add-1998-cmo-2 with edge cases (src/curve-projective.ts:51-160)
+  Proj6 add(const Proj6& P, const Proj6& Q) const {
+    if (is_zero(P)) return Q;
+    if (is_zero(Q)) return P;
+    Fe6 Y1Z2, X1Z2, Z1Z2, u, v, t;
+    F.mul(Y1Z2, P.Y, Q.Z);
+    F.mul(X1Z2, P.X, Q.Z);
+    F.mul(Z1Z2, P.Z, Q.Z);
+    F.mul(t, Q.Y, P.Z);
+    F.sub(u, t, Y1Z2);
+    F.mul(t, Q.X, P.Z);
+    F.sub(v, t, X1Z2);
+    if (Field6::is_zero(v)) {
+      if (Field6::is_zero(u)) return dbl(P);
+      return zero();
+    }
+    Fe6 uu, vv, vvv, R, A;
+    F.sqr(uu, u);
+    F.sqr(vv, v);
+    F.mul(vvv, v, vv);
+    F.mul(R, vv, X1Z2);
+    F.mul(A, uu, Z1Z2);
+    F.sub(A, A, vvv);
+    F.dbl(t, R);
+    F.sub(A, A, t);
+    Proj6 S;
+    F.mul(S.X, v, A);
+    F.sub(t, R, A);
+    F.mul(t, u, t);
+    Fe6 t2;
+    F.mul(t2, vvv, Y1Z2);
+    F.sub(S.Y, t, t2);
+    F.mul(S.Z, vvv, Z1Z2);
+    return S;
+  }
+};
+
+}  // namespace msm_host

@@ -1,0 +1,751 @@
+// Host side of libmsm_hip.so: context, workspace, the kernel pipeline of one MSM and the C ABI
+// declared in include/msm_hip.h.  Orchestration follows `createMsm().msm`
+// (reference src/msm-batched-affine.ts:69-340); the per-thread SPMD phases separated by
+// `barrier()` there become kernel launches on one HIP stream here.
+#include "msm_kernels.h"
+#include "host_field.h"
+#include "../../include/msm_hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace msm;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct HipFail {
+  hipError_t e;
+  const char* what;
+  int line;
+};
+
+#define HIPCHK(x)                                   \
+  do {                                              \
+    hipError_t _e = (x);                            \
+    if (_e != hipSuccess) throw HipFail{_e, #x, __LINE__}; \
+  } while (0)
+
+inline uint32_t ceil_log2_u64(uint64_t n) {
+  uint32_t r = 0;
+  while ((1ull << r) < n) r++;
+  return r;
+}
+
+}  // namespace
+
+struct msm_ctx {
+  int curve = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[12];
+  std::string err;
+  int n_cu = 256;
+
+  // resident points
+  DevBuf rows;
+  uint64_t n_points = 0;
+
+  // workspace
+  DevBuf scal, dig, counts, cursor, tail_off, info, slots, bufA, bufB, scratch, columns, partials, errflag, misc;
+  uint32_t* h_info = nullptr;      // pinned
+  uint32_t* h_partials = nullptr;  // pinned, up to 64 windows x 36 words
+  uint64_t ws_budget = 0;          // bytes the tree buffers of one window group may take
+
+  msm_host::Curve6 hc;
+  msm_host::Fe6 k_dev_to_host;  // 2^378: device Montgomery (2^390) -> host Montgomery (2^384)
+
+  void ensure(DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return;
+    if (b.p) HIPCHK(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 16 + 256;
+    HIPCHK(hipMalloc(&b.p, want));
+    b.cap = want;
+  }
+  void release(DevBuf& b) {
+    if (b.p) hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+  }
+};
+
+#include "msm_gen.h"
+
+namespace {
+
+int fail(msm_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+int fail_hip(msm_ctx* ctx, const HipFail& f) {
+  return fail(ctx, MSM_ERR_HIP, "HIP error %d (%s) at msm_api.hip:%d: %s", (int)f.e, hipGetErrorString(f.e), f.line, f.what);
+}
+
+// GPU-tuned window size (the reference's table, src/msm-common.ts:25-41, was tuned for 16 CPU
+// threads and copies points; here the trade is 2N*K pair additions against K*2^(c-1) buckets to
+// reduce, with histogram/scatter counters that must stay cache friendly).
+int pick_window(uint64_t n) {
+  uint32_t lg = ceil_log2_u64(std::max<uint64_t>(n, 1));
+  int c = (int)lg - 6;
+  if (lg >= 22) c = 16;
+  c = std::max(4, std::min(16, c));
+  return c;
+}
+
+struct Plan {
+  int c, K, L_log;
+  uint32_t L;
+};
+
+int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
+  int c = (opts && opts->c > 0) ? opts->c : pick_window(n);
+  if (c < 2 || c > 24) return MSM_ERR_ARG;
+  const int b = GlvBls377::MAX_BITS;
+  pl.c = c;
+  pl.K = (b + 1 + c - 1) / c;  // K = ceil((b + 1) / c), src/msm-batched-affine.ts:90
+  pl.L_log = c - 1;
+  pl.L = 1u << (c - 1);
+  (void)ctx;
+  return MSM_OK;
+}
+
+struct GroupStats {
+  uint64_t n_pairs = 0;
+  uint64_t max_bucket = 0;
+  int rounds = 0;
+  float ms_digits = 0, ms_sort = 0, ms_acc = 0, ms_red = 0, ms_r1 = 0;
+};
+
+// launch geometry of one tree round
+struct RoundGeom {
+  uint32_t steps, grid;
+  uint64_t T;
+};
+
+RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out) {
+  const uint64_t target = (uint64_t)ctx->n_cu * 4 * 2 * 64;  // two waves per SIMD
+  const uint32_t max_steps = 512;
+  uint64_t steps = (n_out + target - 1) / target;
+  steps = std::max<uint64_t>(1, std::min<uint64_t>(steps, max_steps));
+  uint64_t threads = (n_out + steps - 1) / steps;
+  uint64_t grid = std::max<uint64_t>(1, (threads + 255) / 256);
+  return RoundGeom{(uint32_t)steps, (uint32_t)grid, grid * 256};
+}
+
+// Partition sums P_k for windows [k_lo, k_hi) -> ctx->h_partials[(k - k_lo) * 36 ...]
+// scalars: device pointer, n x 8 words.
+void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const Plan& pl, int k_lo, int k_hi,
+                      uint32_t* h_partials_out, GroupStats& st) {
+  hipStream_t s = ctx->stream;
+  const int kc = k_hi - k_lo;
+  const uint32_t L = pl.L;
+  const uint64_t nb = (uint64_t)kc * L;
+  const uint64_t two_n = 2 * n;
+  const uint64_t n_entries = (uint64_t)kc * two_n;
+
+  // padding granule G = 2^g: about 1/16 of the mean bucket population
+  uint64_t mean = std::max<uint64_t>(1, two_n / L);
+  uint32_t logG = 1;
+  while (logG < 10 && (1ull << (logG + 1)) * 16 <= mean) logG++;
+
+  ctx->ensure(ctx->dig, n_entries * 4);
+  ctx->ensure(ctx->counts, nb * 4);
+  ctx->ensure(ctx->cursor, nb * 4);
+  ctx->ensure(ctx->tail_off, (size_t)34 * (nb + 1) * 4);
+  ctx->ensure(ctx->info, 64 * 4);
+
+  HIPCHK(hipEventRecord(ctx->ev[0], s));
+  HIPCHK(hipMemsetAsync(ctx->counts.p, 0, nb * 4, s));
+  {
+    uint32_t grid = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)ctx->dig.p, (uint32_t*)ctx->counts.p, d_scalars,
+                       (uint32_t)n, pl.c, pl.K, k_lo, kc);
+  }
+  HIPCHK(hipEventRecord(ctx->ev[1], s));
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, (const uint32_t*)ctx->counts.p, (uint32_t)nb, logG,
+                     (uint32_t*)ctx->cursor.p, (uint32_t*)ctx->tail_off.p, (uint32_t*)ctx->info.p);
+  HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->info.p, 64 * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const uint64_t total_slots = ctx->h_info[0];
+  const uint32_t max_bucket = ctx->h_info[1];
+  const int RT = (int)ctx->h_info[2];
+  st.max_bucket = std::max<uint64_t>(st.max_bucket, max_bucket);
+
+  // scatter
+  ctx->ensure(ctx->slots, std::max<uint64_t>(total_slots, 2) * 4);
+  HIPCHK(hipMemsetAsync(ctx->slots.p, 0xFF, std::max<uint64_t>(total_slots, 2) * 4, s));
+  {
+    uint64_t grid = (n_entries + 255) / 256;
+    hipLaunchKernelGGL(k_scatter, dim3((uint32_t)grid), dim3(256), 0, s, (uint32_t*)ctx->slots.p, (uint32_t*)ctx->cursor.p,
+                       (const uint32_t*)ctx->dig.p, two_n, n_entries, L);
+  }
+  HIPCHK(hipEventRecord(ctx->ev[2], s));
+
+  // accumulation tree
+  // outputs alternate between two buffers: size each for the largest round it receives
+  uint64_t capA = 1, capB = 1;
+  {
+    int which = 0;
+    uint64_t cnt = total_slots;
+    for (uint32_t r = 1; r <= logG; r++) {
+      cnt /= 2;
+      (which ? capB : capA) = std::max<uint64_t>(which ? capB : capA, cnt);
+      which ^= 1;
+    }
+    for (int r = 1; r <= RT; r++) {
+      cnt = ctx->h_info[3 + r];
+      (which ? capB : capA) = std::max<uint64_t>(which ? capB : capA, cnt);
+      which ^= 1;
+    }
+  }
+  ctx->ensure(ctx->bufA, capA * 96);
+  ctx->ensure(ctx->bufB, capB * 96);
+  uint4* buf[2] = {(uint4*)ctx->bufA.p, (uint4*)ctx->bufB.p};
+  uint64_t cap[2] = {capA, capB};
+  int cur = 0;  // buffer that receives the next round's output
+  uint64_t n_in = total_slots;
+  int round = 0;
+  const uint4* fin = buf[0];
+  uint64_t fin_cap = cap[0];
+  const uint32_t* off_fin = (const uint32_t*)ctx->tail_off.p;
+  if (total_slots > 0) {
+    for (uint32_t r = 1; r <= logG; r++) {
+      uint64_t n_out = n_in / 2;
+      RoundGeom g = round_geom(ctx, n_out);
+      ctx->ensure(ctx->scratch, (size_t)g.steps * NL * g.T * 4);
+      BatchArgs a{};
+      a.points = (const uint32_t*)ctx->rows.p;
+      a.slots = (const uint32_t*)ctx->slots.p;
+      a.in = buf[cur ^ 1];
+      a.in_cap = cap[cur ^ 1];
+      a.out = buf[cur];
+      a.out_cap = cap[cur];
+      a.scratch = (uint32_t*)ctx->scratch.p;
+      a.n_out = n_out;
+      a.steps = g.steps;
+      if (r == 1) {
+        hipLaunchKernelGGL(k_batch_add<MODE_GATHER>, dim3(g.grid), dim3(256), 0, s, a);
+        HIPCHK(hipEventRecord(ctx->ev[6], s));
+      } else {
+        hipLaunchKernelGGL(k_batch_add<MODE_REGULAR>, dim3(g.grid), dim3(256), 0, s, a);
+      }
+      st.n_pairs += n_out;
+      fin = buf[cur];
+      fin_cap = cap[cur];
+      cur ^= 1;
+      n_in = n_out;
+      round++;
+    }
+    for (int r = 1; r <= RT; r++) {
+      uint64_t n_out = ctx->h_info[3 + r];
+      RoundGeom g = round_geom(ctx, n_out);
+      ctx->ensure(ctx->scratch, (size_t)g.steps * NL * g.T * 4);
+      BatchArgs a{};
+      a.in = buf[cur ^ 1];
+      a.in_cap = cap[cur ^ 1];
+      a.out = buf[cur];
+      a.out_cap = cap[cur];
+      a.scratch = (uint32_t*)ctx->scratch.p;
+      a.n_out = n_out;
+      a.steps = g.steps;
+      a.off_in = (const uint32_t*)ctx->tail_off.p + (uint64_t)(r - 1) * (nb + 1);
+      a.off_out = (const uint32_t*)ctx->tail_off.p + (uint64_t)r * (nb + 1);
+      a.nb = (uint32_t)nb;
+      hipLaunchKernelGGL(k_batch_add<MODE_SEARCH>, dim3(g.grid), dim3(256), 0, s, a);
+      st.n_pairs += n_out;
+      fin = buf[cur];
+      fin_cap = cap[cur];
+      cur ^= 1;
+      round++;
+    }
+    off_fin = (const uint32_t*)ctx->tail_off.p + (uint64_t)RT * (nb + 1);
+  }
+  st.rounds = round;
+  if (total_slots == 0) HIPCHK(hipEventRecord(ctx->ev[6], s));
+  HIPCHK(hipEventRecord(ctx->ev[3], s));
+
+  // bucket reduction
+  uint32_t TC = (uint32_t)std::max<uint64_t>(2, (nb + 65535) / 65536);
+  TC = std::min<uint32_t>(TC, L);
+  uint32_t nchunks = (L + TC - 1) / TC;
+  ctx->ensure(ctx->columns, (size_t)kc * nchunks * 3 * NL * 4);
+  ctx->ensure(ctx->partials, (size_t)kc * 36 * 4);
+  {
+    uint32_t threads = nchunks * (uint32_t)kc;
+    hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)ctx->columns.p, fin, fin_cap,
+                       off_fin, L, TC, nchunks, (uint32_t)kc);
+    hipLaunchKernelGGL(k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
+                       (const uint32_t*)ctx->columns.p, nchunks);
+  }
+  HIPCHK(hipMemcpyAsync(h_partials_out, ctx->partials.p, (size_t)kc * 36 * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(ctx->ev[4], s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  float ms;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); st.ms_digits += ms;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2])); st.ms_sort += ms;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); st.ms_acc += ms;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[6])); st.ms_r1 += ms;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); st.ms_red += ms;
+}
+
+// how many windows fit one group under the workspace budget
+int windows_per_group(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
+  // per window: digits 8n, slots ~8n(+pad), bufA ~ n*96, bufB ~ n*48, scratch ~ n*52
+  long double per = (long double)n * (8 + 9 + 96 + 48 + 56) + (long double)pl.L * 4 * 40;
+  int w = (int)std::max<long double>(1, (long double)ctx->ws_budget / per);
+  return std::min(w, pl.K);
+}
+
+void words_to_fe6(msm_host::Fe6& r, const uint32_t* w) {
+  for (int i = 0; i < 6; i++) r.v[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+}
+
+void fe6_to_bytes(uint8_t* out, const msm_host::Fe6& a) {
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(a.v[i] >> (8 * j));
+}
+
+// device-Montgomery packed partial (36 words) -> host projective point (host Montgomery form)
+msm_host::Proj6 partial_to_host(const msm_ctx* ctx, const uint32_t* w) {
+  msm_host::Proj6 P;
+  msm_host::Fe6 t;
+  words_to_fe6(t, w);      ctx->hc.F.mul(P.X, t, ctx->k_dev_to_host);
+  words_to_fe6(t, w + 12); ctx->hc.F.mul(P.Y, t, ctx->k_dev_to_host);
+  words_to_fe6(t, w + 24); ctx->hc.F.mul(P.Z, t, ctx->k_dev_to_host);
+  return P;
+}
+
+// S = sum_k 2^(ck) P_k, then affine (src/msm-batched-affine.ts:322-333, src/curve-projective.ts:335-349)
+void horner_to_affine(const msm_ctx* ctx, const std::vector<msm_host::Proj6>& P, int c, msm_result* out) {
+  const auto& C = ctx->hc;
+  int K = (int)P.size();
+  msm_host::Proj6 acc = P[K - 1];
+  for (int k = K - 2; k >= 0; k--) {
+    for (int j = 0; j < c; j++) acc = C.dbl(acc);
+    acc = C.add(acc, P[k]);
+  }
+  memset(out->x, 0, 48);
+  memset(out->y, 0, 48);
+  if (C.is_zero(acc)) {
+    out->is_infinity = 1;
+    return;
+  }
+  out->is_infinity = 0;
+  msm_host::Fe6 zi, x, y, one = {{1, 0, 0, 0, 0, 0}};
+  C.F.inv(zi, acc.Z);
+  C.F.mul(x, acc.X, zi);
+  C.F.mul(y, acc.Y, zi);
+  C.F.mul(x, x, one);  // leave Montgomery form
+  C.F.mul(y, y, one);
+  fe6_to_bytes(out->x, x);
+  fe6_to_bytes(out->y, y);
+}
+
+int stage_scalars(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const uint32_t** d_out) {
+  if (on_device) {
+    *d_out = (const uint32_t*)scalars;
+    return MSM_OK;
+  }
+  ctx->ensure(ctx->scal, n * 32);
+  HIPCHK(hipMemcpyAsync(ctx->scal.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  *d_out = (const uint32_t*)ctx->scal.p;
+  return MSM_OK;
+}
+
+int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, int k_lo, int k_hi,
+                     const Plan& pl, std::vector<uint32_t>& words, msm_result* stats) {
+  const uint32_t* d_scal = nullptr;
+  HIPCHK(hipEventRecord(ctx->ev[8], ctx->stream));
+  stage_scalars(ctx, scalars, n, on_device, &d_scal);
+  HIPCHK(hipEventRecord(ctx->ev[9], ctx->stream));
+  GroupStats st;
+  words.assign((size_t)(k_hi - k_lo) * 36, 0);
+  int wpg = windows_per_group(ctx, n, pl);
+  for (int k = k_lo; k < k_hi; k += wpg) {
+    int ke = std::min(k_hi, k + wpg);
+    run_window_group(ctx, d_scal, n, pl, k, ke, ctx->h_partials, st);
+    memcpy(&words[(size_t)(k - k_lo) * 36], ctx->h_partials, (size_t)(ke - k) * 36 * 4);
+  }
+  HIPCHK(hipEventRecord(ctx->ev[10], ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (stats) {
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[9]));
+    stats->phase_ms[MSM_T_UPLOAD] = ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[10]));
+    stats->phase_ms[MSM_T_TOTAL] = ms;
+    stats->phase_ms[MSM_T_DIGITS] = st.ms_digits;
+    stats->phase_ms[MSM_T_SORT] = st.ms_sort;
+    stats->phase_ms[MSM_T_ACCUMULATE] = st.ms_acc;
+    stats->phase_ms[MSM_T_ACC_ROUND1] = st.ms_r1;
+    stats->phase_ms[MSM_T_REDUCE] = st.ms_red;
+    stats->n_pairs = st.n_pairs;
+    stats->max_bucket = st.max_bucket;
+    stats->rounds = st.rounds;
+    stats->c = pl.c;
+    stats->K = pl.K;
+  }
+  (void)opts;
+  return MSM_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+
+extern "C" {
+
+int msm_ctx_create(msm_ctx** out, int curve, int device) {
+  if (!out) return MSM_ERR_ARG;
+  *out = nullptr;
+  if (curve != MSM_CURVE_BLS12_377_G1 && curve != MSM_CURVE_ED_ON_BLS12_377) return MSM_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MSM_ERR_NO_DEVICE;
+  msm_ctx* ctx = new msm_ctx();
+  ctx->curve = curve;
+  ctx->device = device;
+  try {
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_info, 64 * 4, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_partials, 128 * 36 * 4, hipHostMallocDefault));
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    // leave room for the resident points (144 B/point at 2^26 = 9.7 GB) and fragmentation
+    ctx->ws_budget = (uint64_t)(free_b * 0.55);
+    ctx->ensure(ctx->errflag, 16);
+  } catch (const HipFail& f) {
+    fprintf(stderr, "msm_ctx_create: HIP error %s at line %d\n", hipGetErrorString(f.e), f.line);
+    delete ctx;
+    return MSM_ERR_HIP;
+  }
+  ctx->hc.F.init(Fp377::PW);
+  ctx->k_dev_to_host = ctx->hc.F.pow2(378);
+  *out = ctx;
+  return MSM_OK;
+}
+
+void msm_ctx_destroy(msm_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->dig, &ctx->counts, &ctx->cursor, &ctx->tail_off, &ctx->info, &ctx->slots,
+                    &ctx->bufA, &ctx->bufB, &ctx->scratch, &ctx->columns, &ctx->partials, &ctx->errflag, &ctx->misc})
+    ctx->release(*b);
+  if (ctx->h_info) hipHostFree(ctx->h_info);
+  if (ctx->h_partials) hipHostFree(ctx->h_partials);
+  for (auto& e : ctx->ev) hipEventDestroy(e);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* msm_last_error(const msm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, int check_curve) {
+  if (!ctx || (!points && n)) return fail(ctx, MSM_ERR_ARG, "msm_set_points: null argument");
+  if (ctx->curve != MSM_CURVE_BLS12_377_G1) return fail(ctx, MSM_ERR_ARG, "msm_set_points: curve not supported yet");
+  if (n >= (1ull << 30)) return fail(ctx, MSM_ERR_ARG, "msm_set_points: n must be < 2^30");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->n_points = 0;
+    ctx->ensure(ctx->rows, std::max<uint64_t>(n, 1) * ROW_WORDS * 4);
+    const uint32_t* d_wire = (const uint32_t*)points;
+    if (!on_device && n) {
+      ctx->ensure(ctx->misc, n * 96);
+      HIPCHK(hipMemcpyAsync(ctx->misc.p, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
+      d_wire = (const uint32_t*)ctx->misc.p;
+    }
+    HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
+    if (n) {
+      uint64_t grid = (n + 255) / 256;
+      hipLaunchKernelGGL(k_points_from_wire, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p, d_wire, n,
+                         check_curve, (uint32_t*)ctx->errflag.p);
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->errflag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    if (!on_device) ctx->release(ctx->misc);
+    if (ctx->h_info[0] & 1) return fail(ctx, MSM_ERR_POINT, "msm_set_points: coordinate >= p");
+    if (ctx->h_info[0] & 2) return fail(ctx, MSM_ERR_POINT, "msm_set_points: point not on curve");
+    ctx->n_points = n;
+  } catch (const HipFail& f) {
+    return fail_hip(ctx, f);
+  }
+  return MSM_OK;
+}
+
+int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_out, int32_t* K_out) {
+  Plan pl;
+  int rc = make_plan(ctx, n, opts, pl);
+  if (rc) return rc;
+  if (c_out) *c_out = pl.c;
+  if (K_out) *K_out = pl.K;
+  return MSM_OK;
+}
+
+int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, uint8_t* partials_out,
+                    msm_result* stats) {
+  if (!ctx || !partials_out || (!scalars && n)) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: null argument");
+  if (ctx->curve != MSM_CURVE_BLS12_377_G1) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: curve not supported yet");
+  if (n > ctx->n_points) return fail(ctx, MSM_ERR_NO_POINTS, "msm_window_sums: %llu scalars but %llu resident points",
+                                     (unsigned long long)n, (unsigned long long)ctx->n_points);
+  Plan pl;
+  if (make_plan(ctx, n, opts, pl)) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: bad window size");
+  int k_lo = opts ? opts->k_lo : 0, k_hi = opts ? opts->k_hi : 0;
+  if (k_lo == 0 && k_hi == 0) k_hi = pl.K;
+  if (k_lo < 0 || k_hi > pl.K || k_lo >= k_hi) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: bad window shard [%d, %d) of %d", k_lo, k_hi, pl.K);
+  if (stats) memset(stats, 0, sizeof(*stats));
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<uint32_t> words;
+    if (n == 0) {
+      words.assign((size_t)(k_hi - k_lo) * 36, 0);
+    } else {
+      window_sums_impl(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
+    }
+    // to 48-byte canonical integers (leave device Montgomery form on the host)
+    for (int k = 0; k < k_hi - k_lo; k++) {
+      const uint32_t* w = &words[(size_t)k * 36];
+      bool zero_z = true;
+      for (int j = 0; j < 12; j++) zero_z &= w[24 + j] == 0;
+      msm_host::Proj6 P;
+      if (n == 0 || zero_z) P = ctx->hc.zero();
+      else P = partial_to_host(ctx, w);
+      msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}}, t;
+      ctx->hc.F.mul(t, P.X, one); fe6_to_bytes(partials_out + (size_t)k * 144, t);
+      ctx->hc.F.mul(t, P.Y, one); fe6_to_bytes(partials_out + (size_t)k * 144 + 48, t);
+      ctx->hc.F.mul(t, P.Z, one); fe6_to_bytes(partials_out + (size_t)k * 144 + 96, t);
+    }
+    if (stats) { stats->c = pl.c; stats->K = pl.K; }
+  } catch (const HipFail& f) {
+    return fail_hip(ctx, f);
+  }
+  return MSM_OK;
+}
+
+int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
+  if (!ctx || !partials || !out || K <= 0 || c <= 0) return fail(ctx, MSM_ERR_ARG, "msm_combine: bad argument");
+  std::vector<msm_host::Proj6> P(K);
+  for (int k = 0; k < K; k++) {
+    msm_host::Fe6 t[3];
+    for (int j = 0; j < 3; j++) {
+      const uint8_t* b = partials + (size_t)k * 144 + 48 * j;
+      for (int i = 0; i < 6; i++) {
+        uint64_t v = 0;
+        for (int q = 0; q < 8; q++) v |= (uint64_t)b[8 * i + q] << (8 * q);
+        t[j].v[i] = v;
+      }
+      if (msm_host::Field6::ge(t[j], ctx->hc.F.p)) return fail(ctx, MSM_ERR_ARG, "msm_combine: coordinate >= p");
+      ctx->hc.F.mul(t[j], t[j], ctx->hc.F.r2);  // to host Montgomery form
+    }
+    P[k].X = t[0]; P[k].Y = t[1]; P[k].Z = t[2];
+  }
+  horner_to_affine(ctx, P, c, out);
+  out->c = c;
+  out->K = K;
+  return MSM_OK;
+}
+
+int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, msm_result* out) {
+  if (!ctx || !out || (!scalars && n)) return fail(ctx, MSM_ERR_ARG, "msm_run: null argument");
+  if (ctx->curve != MSM_CURVE_BLS12_377_G1) return fail(ctx, MSM_ERR_ARG, "msm_run: curve not supported yet");
+  if (n > ctx->n_points) return fail(ctx, MSM_ERR_NO_POINTS, "msm_run: %llu scalars but %llu resident points",
+                                     (unsigned long long)n, (unsigned long long)ctx->n_points);
+  Plan pl;
+  if (make_plan(ctx, n, opts, pl)) return fail(ctx, MSM_ERR_ARG, "msm_run: bad window size");
+  memset(out, 0, sizeof(*out));
+  out->c = pl.c;
+  out->K = pl.K;
+  if (n == 0) {
+    out->is_infinity = 1;
+    return MSM_OK;
+  }
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<uint32_t> words;
+    window_sums_impl(ctx, scalars, n, on_device, opts, 0, pl.K, pl, words, out);
+    HIPCHK(hipEventRecord(ctx->ev[10], ctx->stream));
+    std::vector<msm_host::Proj6> P(pl.K);
+    for (int k = 0; k < pl.K; k++) P[k] = partial_to_host(ctx, &words[(size_t)k * 36]);
+    horner_to_affine(ctx, P, pl.c, out);
+    HIPCHK(hipEventRecord(ctx->ev[11], ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[10], ctx->ev[11]));
+    out->phase_ms[MSM_T_FINAL] = ms;
+    out->phase_ms[MSM_T_TOTAL] += ms;
+  } catch (const HipFail& f) {
+    return fail_hip(ctx, f);
+  }
+  return MSM_OK;
+}
+
+int msm_get_point(msm_ctx* ctx, uint64_t i, uint8_t* out_xy) {
+  if (!ctx || !out_xy || i >= ctx->n_points) return fail(ctx, MSM_ERR_ARG, "msm_get_point: bad argument");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    uint32_t row[ROW_WORDS];
+    HIPCHK(hipMemcpy(row, (const uint32_t*)ctx->rows.p + i * ROW_WORDS, sizeof row, hipMemcpyDeviceToHost));
+    memset(out_xy, 0, 96);
+    if (row[11] == INF_WORD) return MSM_OK;
+    msm_host::Fe6 t, one = {{1, 0, 0, 0, 0, 0}};
+    for (int j = 0; j < 2; j++) {
+      words_to_fe6(t, row + 12 * j);
+      ctx->hc.F.mul(t, t, ctx->k_dev_to_host);  // host Montgomery
+      ctx->hc.F.mul(t, t, one);                 // plain
+      fe6_to_bytes(out_xy + 48 * j, t);
+    }
+  } catch (const HipFail& f) {
+    return fail_hip(ctx, f);
+  }
+  return MSM_OK;
+}
+
+int msm_test_fp(msm_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, uint64_t n) {
+  if (!ctx || !a || !b || !out) return fail(ctx, MSM_ERR_ARG, "msm_test_fp: null argument");
+  if (ctx->curve != MSM_CURVE_BLS12_377_G1) return fail(ctx, MSM_ERR_ARG, "msm_test_fp: curve not supported yet");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->ensure(ctx->misc, n * 48 * 3 + 64);
+    uint8_t* d = (uint8_t*)ctx->misc.p;
+    HIPCHK(hipMemcpyAsync(d, a, n * 48, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d + n * 48, b, n * 48, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_test_fp, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)(d + 2 * n * 48),
+                       (const uint32_t*)d, (const uint32_t*)(d + n * 48), (uint32_t)n, op);
+    HIPCHK(hipMemcpyAsync(out, d + 2 * n * 48, n * 48, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+  } catch (const HipFail& f) {
+    return fail_hip(ctx, f);
+  }
+  return MSM_OK;
+}
+
+int msm_test_glv(msm_ctx* ctx, const uint8_t* scalars, uint8_t* out, uint64_t n) {
+  if (!ctx || !scalars || !out) return fail(ctx, MSM_ERR_ARG, "msm_test_glv: null argument");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->ensure(ctx->misc, n * 72 + 64);
+    uint8_t* d = (uint8_t*)ctx->misc.p;
+    HIPCHK(hipMemcpyAsync(d, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_test_glv, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)(d + n * 32),
+                       (const uint32_t*)d, (uint32_t)n);
+    HIPCHK(hipMemcpyAsync(out, d + n * 32, n * 40, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+  } catch (const HipFail& f) {
+    return fail_hip(ctx, f);
+  }
+  return MSM_OK;
+}
+
+int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t* out, uint64_t n) {
+  if (!ctx || !g || !h || !out || n == 0) return fail(ctx, MSM_ERR_ARG, "msm_test_batch_add: bad argument");
+  if (ctx->curve != MSM_CURVE_BLS12_377_G1) return fail(ctx, MSM_ERR_ARG, "msm_test_batch_add: curve not supported yet");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    // rows for 2n points: pair e = (row 2e, row 2e + 1), gathered through identity payload slots
+    DevBuf rows, wire, slots, outb, scr;
+    ctx->ensure(wire, 2 * n * 96);
+    ctx->ensure(rows, 2 * n * ROW_WORDS * 4);
+    ctx->ensure(slots, 2 * n * 4);
+    ctx->ensure(outb, n * 96);
+    std::vector<uint8_t> inter(2 * n * 96);
+    std::vector<uint32_t> sl(2 * n);
+    for (uint64_t i = 0; i < n; i++) {
+      memcpy(&inter[(2 * i) * 96], g + i * 96, 96);
+      memcpy(&inter[(2 * i + 1) * 96], h + i * 96, 96);
+      sl[2 * i] = (uint32_t)((2 * i) << 2);
+      sl[2 * i + 1] = (uint32_t)((2 * i + 1) << 2);
+    }
+    HIPCHK(hipMemcpyAsync(wire.p, inter.data(), 2 * n * 96, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(slots.p, sl.data(), 2 * n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_points_from_wire, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)rows.p,
+                       (const uint32_t*)wire.p, 2 * n, 0, (uint32_t*)ctx->errflag.p);
+    RoundGeom gm = round_geom(ctx, n);
+    gm.steps = (uint32_t)std::min<uint64_t>(n, 3);  // exercise the shared inversion with a few pairs per lane
+    uint64_t threads = (n + gm.steps - 1) / gm.steps;
+    gm.grid = (uint32_t)((threads + 255) / 256);
+    gm.T = (uint64_t)gm.grid * 256;
+    ctx->ensure(scr, (size_t)gm.steps * NL * gm.T * 4);
+    BatchArgs a{};
+    a.points = (const uint32_t*)rows.p;
+    a.slots = (const uint32_t*)slots.p;
+    a.out = (uint4*)outb.p;
+    a.out_cap = n;
+    a.scratch = (uint32_t*)scr.p;
+    a.n_out = n;
+    a.steps = gm.steps;
+    hipLaunchKernelGGL(k_batch_add<MODE_GATHER>, dim3(gm.grid), dim3(256), 0, ctx->stream, a);
+    std::vector<uint32_t> planes(n * 24);
+    HIPCHK(hipMemcpyAsync(planes.data(), outb.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
+    for (uint64_t e = 0; e < n; e++) {
+      uint32_t w[24];
+      for (int cpl = 0; cpl < 6; cpl++)
+        for (int q = 0; q < 4; q++) w[4 * cpl + q] = planes[((uint64_t)cpl * n + e) * 4 + q];
+      memset(out + e * 96, 0, 96);
+      if (w[11] == INF_WORD) continue;
+      for (int j = 0; j < 2; j++) {
+        msm_host::Fe6 t;
+        words_to_fe6(t, w + 12 * j);
+        ctx->hc.F.mul(t, t, ctx->k_dev_to_host);
+        ctx->hc.F.mul(t, t, one);
+        fe6_to_bytes(out + e * 96 + 48 * j, t);
+      }
+    }
+    for (DevBuf* b : {&rows, &wire, &slots, &outb, &scr}) ctx->release(*b);
+  } catch (const HipFail& f) {
+    return fail_hip(ctx, f);
+  }
+  return MSM_OK;
+}
+
+int msm_generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
+  if (!ctx) return MSM_ERR_ARG;
+  if (ctx->curve != MSM_CURVE_BLS12_377_G1) return fail(ctx, MSM_ERR_ARG, "msm_generate_points: curve not supported yet");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    return msm_gen::generate_points(ctx, n, seed, a_out);
+  } catch (const HipFail& f) {
+    return fail_hip(ctx, f);
+  }
+}
+
+int msm_generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void** dev_ptr_out, uint8_t* host_out) {
+  if (!ctx || !dev_ptr_out) return MSM_ERR_ARG;
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    return msm_gen::generate_scalars(ctx, n, seed, dev_ptr_out, host_out);
+  } catch (const HipFail& f) {
+    return fail_hip(ctx, f);
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+// Synthetic input generation on the GPU (bench / large-N tests only):
+//   generate_points  : P_i = sum_j T_j[idx_ij] with T_j[t] = (t + 1) * B_j, B_j = b_j * G  -- the scheme of
+//                      `randomPointsFast` (reference src/curve-random.ts:14-92: 5 basis points, small tables,
+//                      batch-normalised), with KNOWN discrete logs a_i = sum_j (idx_ij + 1) * b_j mod q so a
+//                      2^26-point MSM can be checked in O(N): sum s_i P_i = (sum s_i a_i) * G
+//   generate_scalars : uniform scalars < q by masked rejection sampling (src/curve-random.ts:151-194)
+// Randomness is a counter-based splitmix64 stream, identical on host and device, keyed by (seed, index).
+//
+// Included by msm_api.hip after msm_ctx / HIPCHK are defined.
+#pragma once
+
+namespace msm_gen {
+
+constexpr int N_BASIS = 5;
+constexpr int TBL_BITS = 10;
+constexpr int TBL = 1 << TBL_BITS;
+
+__host__ __device__ inline uint64_t mix64(uint64_t seed, uint64_t ctr) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// ---- scalars ---------------------------------------------------------------------------------
+
+__host__ __device__ inline bool ge_q(const uint64_t* s, const uint64_t* q) {
+  for (int i = 3; i >= 0; i--) {
+    if (s[i] > q[i]) return true;
+    if (s[i] < q[i]) return false;
+  }
+  return true;
+}
+
+__host__ __device__ inline void draw_scalar(uint64_t* s, uint64_t seed, uint64_t i, const uint64_t* q) {
+  for (uint64_t attempt = 0; attempt < 256; attempt++) {
+    for (int j = 0; j < 4; j++) s[j] = mix64(seed ^ 0x5ca1ab1e00000000ull, (i * 256 + attempt) * 4 + j);
+    s[3] &= (1ull << 61) - 1;  // 253 bits
+    if (!ge_q(s, q)) return;
+  }
+  s[0] = 1; s[1] = s[2] = s[3] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_gen_scalars(uint64_t* out, uint64_t n, uint64_t seed) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t q[4], s[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) q[j] = (uint64_t)msm::GlvBls377::Q[2 * j] | ((uint64_t)msm::GlvBls377::Q[2 * j + 1] << 32);
+  draw_scalar(s, seed, i, q);
+#pragma unroll
+  for (int j = 0; j < 4; j++) out[i * 4 + j] = s[j];
+}
+
+inline int generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void** dev_ptr_out, uint8_t* host_out) {
+  ctx->ensure(ctx->scal, std::max<uint64_t>(n, 1) * 32);
+  if (n) {
+    hipLaunchKernelGGL(k_gen_scalars, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint64_t*)ctx->scal.p, n, seed);
+    if (host_out) HIPCHK(hipMemcpyAsync(host_out, ctx->scal.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  *dev_ptr_out = ctx->scal.p;
+  return MSM_OK;
+}
+
+// ---- points ----------------------------------------------------------------------------------
+
+__host__ __device__ inline uint32_t table_index(uint64_t seed, uint64_t i, int j) {
+  return (uint32_t)(mix64(seed ^ 0x90117500000000ull, i) >> (TBL_BITS * j)) & (TBL - 1);
+}
+
+// tables: N_BASIS * TBL point rows (x, y used); rows_out: n point rows
+__global__ void __launch_bounds__(256) k_gen_points(uint32_t* rows_out, const uint32_t* tables, uint64_t n, uint64_t seed) {
+  using namespace msm;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Proj<F> acc;
+  proj_set_zero<F>(acc);
+#pragma unroll 1
+  for (int j = 0; j < N_BASIS; j++) {
+    uint32_t t = table_index(seed, i, j);
+    const uint32_t* row = tables + ((uint64_t)j * TBL + t) * ROW_WORDS;
+    Proj<F> Q;
+    fe_load<F>(Q.X, row);
+    fe_load<F>(Q.Y, row + 12);
+    proj_add_mixed<F>(acc, acc, Q, false);
+  }
+  uint32_t* out = rows_out + i * ROW_WORDS;
+  if (proj_is_zero<F>(acc)) {
+    uint4* r4 = reinterpret_cast<uint4*>(out);
+    for (int q = 0; q < 3; q++) {
+      r4[q] = make_uint4(INF_WORD, INF_WORD, INF_WORD, INF_WORD);
+      r4[3 + q] = make_uint4(0, 0, 0, 0);
+      r4[6 + q] = make_uint4(INF_WORD, INF_WORD, INF_WORD, INF_WORD);
+    }
+    return;
+  }
+  Fe<F> zi, x, y, bx, beta;
+  fe_inv<F>(zi, acc.Z);
+  fe_mul<F>(x, acc.X, zi);
+  fe_mul<F>(y, acc.Y, zi);
+  fe_reduce_2p<F>(x);
+  fe_reduce_2p<F>(y);
+#pragma unroll
+  for (int l = 0; l < NL; l++) beta.l[l] = F::BETAL[l];
+  fe_mul<F>(bx, x, beta);
+  fe_reduce_2p<F>(bx);
+  fe_store<F>(out, x);
+  fe_store<F>(out + 12, y);
+  fe_store<F>(out + 24, bx);
+}
+
+struct U256 {
+  uint64_t v[4];
+};
+
+inline void addmod_q(U256& r, const U256& a, const U256& b, const uint64_t* q) {
+  unsigned __int128 c = 0;
+  U256 t;
+  for (int i = 0; i < 4; i++) {
+    c += (unsigned __int128)a.v[i] + b.v[i];
+    t.v[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  if (c || ge_q(t.v, q)) {
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 4; i++) {
+      unsigned __int128 d = (unsigned __int128)t.v[i] - q[i] - (uint64_t)br;
+      t.v[i] = (uint64_t)d;
+      br = (d >> 64) & 1;
+    }
+  }
+  r = t;
+}
+
+inline int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
+  using namespace msm_host;
+  if (n >= (1ull << 30)) return MSM_ERR_ARG;
+  const Curve6& C = ctx->hc;
+  uint64_t q[4];
+  for (int j = 0; j < 4; j++) q[j] = (uint64_t)msm::GlvBls377::Q[2 * j] | ((uint64_t)msm::GlvBls377::Q[2 * j + 1] << 32);
+  // generator in host Montgomery form
+  Proj6 G;
+  {
+    Fe6 t;
+    for (int i = 0; i < 6; i++) t.v[i] = (uint64_t)msm::Fp377::GXW[2 * i] | ((uint64_t)msm::Fp377::GXW[2 * i + 1] << 32);
+    C.F.mul(G.X, t, ctx->k_dev_to_host);
+    for (int i = 0; i < 6; i++) t.v[i] = (uint64_t)msm::Fp377::GYW[2 * i] | ((uint64_t)msm::Fp377::GYW[2 * i + 1] << 32);
+    C.F.mul(G.Y, t, ctx->k_dev_to_host);
+    G.Z = C.F.one;
+  }
+  std::vector<uint8_t> wire((size_t)N_BASIS * TBL * 96);
+  std::vector<U256> tbl_scalar((size_t)N_BASIS * TBL);
+  Fe6 one_plain = {{1, 0, 0, 0, 0, 0}};
+  for (int j = 0; j < N_BASIS; j++) {
+    U256 b;
+    draw_scalar(b.v, seed ^ 0xba5e5ull, (uint64_t)j, q);
+    // B = b * G (MSB-first double and add)
+    Proj6 B = C.zero();
+    for (int bit = 255; bit >= 0; bit--) {
+      B = C.dbl(B);
+      if ((b.v[bit / 64] >> (bit % 64)) & 1) B = C.add(B, G);
+    }
+    Proj6 acc = C.zero();
+    U256 sacc = {{0, 0, 0, 0}};
+    for (int t = 0; t < TBL; t++) {
+      acc = C.add(acc, B);
+      addmod_q(sacc, sacc, b, q);
+      tbl_scalar[(size_t)j * TBL + t] = sacc;
+      Fe6 zi, x, y;
+      uint8_t* w = &wire[((size_t)j * TBL + t) * 96];
+      if (C.is_zero(acc)) {
+        memset(w, 0, 96);
+        continue;
+      }
+      C.F.inv(zi, acc.Z);
+      C.F.mul(x, acc.X, zi);
+      C.F.mul(y, acc.Y, zi);
+      C.F.mul(x, x, one_plain);
+      C.F.mul(y, y, one_plain);
+      for (int i = 0; i < 6; i++)
+        for (int k = 0; k < 8; k++) {
+          w[8 * i + k] = (uint8_t)(x.v[i] >> (8 * k));
+          w[48 + 8 * i + k] = (uint8_t)(y.v[i] >> (8 * k));
+        }
+    }
+  }
+  DevBuf d_wire, d_tbl;
+  ctx->ensure(d_wire, wire.size());
+  ctx->ensure(d_tbl, (size_t)N_BASIS * TBL * msm::ROW_WORDS * 4);
+  HIPCHK(hipMemcpyAsync(d_wire.p, wire.data(), wire.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(msm::k_points_from_wire, dim3((N_BASIS * TBL + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t*)d_tbl.p,
+                     (const uint32_t*)d_wire.p, (uint64_t)N_BASIS * TBL, 1, (uint32_t*)ctx->errflag.p);
+  ctx->n_points = 0;
+  ctx->ensure(ctx->rows, std::max<uint64_t>(n, 1) * msm::ROW_WORDS * 4);
+  if (n)
+    hipLaunchKernelGGL(k_gen_points, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p,
+                       (const uint32_t*)d_tbl.p, n, seed);
+  HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->errflag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  ctx->release(d_wire);
+  ctx->release(d_tbl);
+  if (ctx->h_info[0]) {
+    ctx->err = "msm_generate_points: table point failed validation";
+    return MSM_ERR_POINT;
+  }
+  ctx->n_points = n;
+  if (a_out) {
+    for (uint64_t i = 0; i < n; i++) {
+      U256 a = {{0, 0, 0, 0}};
+      for (int j = 0; j < N_BASIS; j++) addmod_q(a, a, tbl_scalar[(size_t)j * TBL + table_index(seed, i, j)], q);
+      for (int k = 0; k < 4; k++)
+        for (int bb = 0; bb < 8; bb++) a_out[i * 32 + 8 * k + bb] = (uint8_t)(a.v[k] >> (8 * bb));
+    }
+  }
+  return MSM_OK;
+}
+
+}  // namespace msm_gen

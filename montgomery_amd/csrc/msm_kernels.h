@@ -1,0 +1,689 @@
+// HIP kernels of the batched-affine Pippenger MSM for BLS12-377 G1 on gfx950.
+//
+// Phase map (reference: src/msm-batched-affine.ts:69-340):
+//   k_points_from_wire   pointsFromBytes + toMontgomery + endomorphism      src/parallel.ts:97-116, src/wasm/curve.ts:90-103
+//   k_digits             decompose + signed slices + bucket histogram       :350-421 (scalars), :175-203
+//   k_scan               integrateBucketCounts                              :423-447
+//   k_scatter            sortPoints (indices, not 116-byte points)          :456-502
+//   k_batch_add          bucket accumulation tree, one inversion per lane   :243-282, src/curve-affine.ts:376-522
+//   k_bucket_reduce      normalizeBucketsStorage + reduceBucketsColumnProjective :504-583
+//   k_window_sum         partition sums                                     :312-319
+// The Horner combination of the K partition sums (:322-333) runs on the host (msm_api.hip).
+//
+// Data layout in HBM
+//   point rows     : N x 36 words  [x | y | beta*x], canonical Montgomery (R = 2^390), 16-B aligned;
+//                    a gather touches one contiguous 96-byte window of the row (x,y or y,beta*x).
+//   digits         : Kg x 2N words, magnitude | sign << 31, entry j = 2*point + half
+//   slots          : bucket-sorted entry payloads ((j << 1) | neg), every bucket padded with
+//                    SLOT_EMPTY to a multiple of G = 2^g so that g tree rounds need no index math
+//   tree buffers   : "plane" layout, 16-byte piece c of element e at uint4 index c*cap + e
+//                    (planes 0-2 = x, 3-5 = y): consecutive lanes read consecutive 16-byte pieces
+//   prefix scratch : dword planes [(step*13 + limb)*T + thread]
+// The identity is encoded with x = all-ones words (never canonical), y = 0.
+#pragma once
+#include "curve.h"
+#include "glv.h"
+
+namespace msm {
+
+using F = Fp377;
+constexpr int NL = F::NL;
+constexpr int NW = F::NW;
+constexpr int ROW_WORDS = 36;
+constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t INF_WORD = 0xFFFFFFFFu;
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+
+MSM_DEV void load_words12(uint32_t (&w)[NW], const uint32_t* p) {
+  const uint4* p4 = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    uint4 v = p4[j];
+    w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+  }
+}
+
+MSM_DEV void load_planes3(uint32_t (&w)[NW], const uint4* base, uint64_t cap, int first_plane, uint64_t e) {
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    uint4 v = base[(uint64_t)(first_plane + j) * cap + e];
+    w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+  }
+}
+
+MSM_DEV void store_planes3(uint4* base, uint64_t cap, int first_plane, uint64_t e, const uint32_t (&w)[NW]) {
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+    base[(uint64_t)(first_plane + j) * cap + e] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+}
+
+MSM_DEV bool words_ge_p(const uint32_t (&w)[NW]) {  // w >= p ?
+  bool gt = false, lt = false;
+#pragma unroll
+  for (int j = NW - 1; j >= 0; j--) {
+    if (!gt && !lt) {
+      if (w[j] > F::PW[j]) gt = true;
+      else if (w[j] < F::PW[j]) lt = true;
+    }
+  }
+  return !lt;
+}
+
+MSM_DEV bool fe_equal(const Fe<F>& a, const Fe<F>& b) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) o |= a.l[i] ^ b.l[i];
+  return o == 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_points_from_wire: N x (x || y), 48-byte little-endian canonical integers -> point rows
+// ---------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_points_from_wire(uint32_t* rows, const uint32_t* wire, uint64_t n,
+                                                          int check_curve, uint32_t* err) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t xw[NW], yw[NW];
+  load_words12(xw, wire + i * 24);
+  load_words12(yw, wire + i * 24 + 12);
+  uint32_t* row = rows + i * ROW_WORDS;
+  uint32_t any = 0;
+#pragma unroll
+  for (int j = 0; j < NW; j++) any |= xw[j] | yw[j];
+  if (any == 0) {  // (0, 0) is not on y^2 = x^3 + 1: used as the wire encoding of the identity
+    uint32_t ones[NW], zeros[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) { ones[j] = INF_WORD; zeros[j] = 0; }
+    uint4* r4 = reinterpret_cast<uint4*>(row);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      r4[j] = make_uint4(ones[0], ones[0], ones[0], ones[0]);
+      r4[3 + j] = make_uint4(0, 0, 0, 0);
+      r4[6 + j] = make_uint4(ones[0], ones[0], ones[0], ones[0]);
+    }
+    return;
+  }
+  if (words_ge_p(xw) || words_ge_p(yw)) atomicOr(err, 1u);
+  Fe<F> x, y, r2, beta, bx;
+  fe_unpack<F>(x, xw);
+  fe_unpack<F>(y, yw);
+#pragma unroll
+  for (int l = 0; l < NL; l++) { r2.l[l] = F::R2[l]; beta.l[l] = F::BETAL[l]; }
+  fe_mul<F>(x, x, r2);
+  fe_reduce_2p<F>(x);
+  fe_mul<F>(y, y, r2);
+  fe_reduce_2p<F>(y);
+  fe_mul<F>(bx, x, beta);
+  fe_reduce_2p<F>(bx);
+  if (check_curve) {
+    Fe<F> lhs, rhs, bb;
+#pragma unroll
+    for (int l = 0; l < NL; l++) bb.l[l] = F::BL[l];
+    fe_sqr<F>(lhs, y);
+    fe_sqr<F>(rhs, x);
+    fe_mul<F>(rhs, rhs, x);
+    fe_add<F>(rhs, rhs, bb);          // < 3p
+    fe_sub_4p<F>(lhs, lhs, rhs);      // < 6p: reduce by 4p first
+    fe_cond_sub<F, 4>(lhs);
+    if (!fe_is_zero_mod_p<F>(lhs)) atomicOr(err, 2u);
+  }
+  fe_store<F>(row, x);
+  fe_store<F>(row + 12, y);
+  fe_store<F>(row + 24, bx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_digits: scalars (N x 32 B LE) -> signed window digits of both GLV halves + bucket histogram
+// ---------------------------------------------------------------------------------------------
+
+MSM_DEV bool words8_ge(const uint32_t (&a)[8], const uint32_t* q) {
+  bool gt = false, lt = false;
+#pragma unroll
+  for (int j = 7; j >= 0; j--) {
+    if (!gt && !lt) {
+      if (a[j] > q[j]) gt = true;
+      else if (a[j] < q[j]) lt = true;
+    }
+  }
+  return !lt;
+}
+
+// windows [k_lo, k_lo + k_cnt) of K_total are emitted (window groups / multi-GPU window shards)
+__global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts, const uint32_t* scalars, uint32_t n,
+                                                int c, int k_total, int k_lo, int k_cnt) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+  {
+    const uint4* p4 = reinterpret_cast<const uint4*>(scalars + (uint64_t)i * 8);
+    uint4 a = p4[0], b = p4[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  }
+  uint32_t q[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) q[j] = GlvBls377::Q[j];
+  // inputs are specified < q (src/curve-random.ts:151-194); larger values are reduced, not rejected
+  for (int it = 0; it < 16 && words8_ge(s, q); it++) bn_addsub<8, 8>(s, q, true);
+
+  GlvHalf h[2];
+  glv_decompose(h[0], h[1], s);
+  const uint32_t L = 1u << (c - 1);
+  const uint64_t two_n = 2ull * n;
+#pragma unroll
+  for (int hh = 0; hh < 2; hh++) {
+    uint32_t carry = 0;
+    for (int k = 0; k < k_total; k++) {
+      uint32_t l = bn_bits<4>(h[hh].mag, k * c, c) + carry;
+      if (l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
+      int kk = k - k_lo;
+      if (kk >= 0 && kk < k_cnt) {
+        uint32_t neg = carry ^ (h[hh].neg ? 1u : 0u);
+        dig[(uint64_t)kk * two_n + 2ull * i + hh] = l | (neg << 31);
+        if (l) atomicAdd(&counts[(uint64_t)kk * L + (l - 1)], 1u);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scan (single workgroup): bucket sizes -> padded slot offsets, cursor, tail-round offsets
+//   info[0] = total slots, info[1] = max bucket size, info[2] = RT (tail rounds),
+//   info[3 + r] = number of elements entering tail round r (r = 0..RT)
+//   tail_off[r] has nb + 1 entries: offsets of ceil(ceil(n/G) / 2^r)
+// ---------------------------------------------------------------------------------------------
+
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_ITEMS = 4;
+
+MSM_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wave, uint32_t& total) {
+  // inclusive scan inside the wave
+  uint32_t x = v;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  __syncthreads();
+  if (lane == 63) lds_wave[wave] = x;
+  __syncthreads();
+  uint32_t wave_base = 0, tot = 0;
+  const int nw = blockDim.x >> 6;
+  for (int w = 0; w < nw; w++) {
+    uint32_t t = lds_wave[w];
+    if (w < wave) wave_base += t;
+    tot += t;
+  }
+  total = tot;
+  return wave_base + x - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan(const uint32_t* counts, uint32_t nb, uint32_t logG,
+                                                       uint32_t* cursor, uint32_t* tail_off, uint32_t* info) {
+  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
+  __shared__ uint32_t lds_max;
+  const uint32_t G1 = (1u << logG) - 1;
+  if (threadIdx.x == 0) lds_max = 0;
+  __syncthreads();
+  // pass A: max bucket size
+  uint32_t mx = 0;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) mx = max(mx, counts[b]);
+  atomicMax(&lds_max, mx);
+  __syncthreads();
+  mx = lds_max;
+  uint32_t capmax = (mx + G1) >> logG;
+  int RT = 0;
+  while ((1u << RT) < capmax) RT++;
+  // pass B: slot offsets (cursor) with padding to multiples of G
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nb; base += SCAN_THREADS * SCAN_ITEMS) {
+    uint32_t v[SCAN_ITEMS], sum = 0;
+    uint32_t b0 = base + threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+      uint32_t b = b0 + j;
+      v[j] = b < nb ? ((counts[b] + G1) >> logG) << logG : 0u;
+      sum += v[j];
+    }
+    uint32_t tot;
+    uint32_t ex = block_excl_scan(sum, lds_wave, tot) + carry;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+      uint32_t b = b0 + j;
+      if (b < nb) cursor[b] = ex;
+      ex += v[j];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) { info[0] = carry; info[1] = mx; info[2] = (uint32_t)RT; }
+  // pass C: tail-round offsets
+  for (int r = 0; r <= RT; r++) {
+    uint32_t* off = tail_off + (uint64_t)r * (nb + 1);
+    const uint32_t rnd = (1u << r) - 1;
+    carry = 0;
+    for (uint32_t base = 0; base < nb; base += SCAN_THREADS * SCAN_ITEMS) {
+      uint32_t v[SCAN_ITEMS], sum = 0;
+      uint32_t b0 = base + threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+      for (int j = 0; j < SCAN_ITEMS; j++) {
+        uint32_t b = b0 + j;
+        uint32_t cg = b < nb ? (counts[b] + G1) >> logG : 0u;
+        v[j] = (cg + rnd) >> r;
+        sum += v[j];
+      }
+      uint32_t tot;
+      uint32_t ex = block_excl_scan(sum, lds_wave, tot) + carry;
+#pragma unroll
+      for (int j = 0; j < SCAN_ITEMS; j++) {
+        uint32_t b = b0 + j;
+        if (b < nb) off[b] = ex;
+        ex += v[j];
+      }
+      carry += tot;
+    }
+    if (threadIdx.x == 0) { off[nb] = carry; info[3 + r] = carry; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scatter: digits -> bucket-ordered payload slots (order inside a bucket is arbitrary; the
+// bucket sum does not depend on it)
+// ---------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_scatter(uint32_t* slots, uint32_t* cursor, const uint32_t* dig, uint64_t two_n,
+                                                 uint64_t total, uint32_t L) {
+  uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= total) return;
+  uint32_t d = dig[id];
+  uint32_t l = d & 0x7FFFFFFFu;
+  if (l == 0) return;
+  uint64_t kk = id / two_n;
+  uint32_t j = (uint32_t)(id - kk * two_n);
+  uint32_t pos = atomicAdd(&cursor[kk * L + (l - 1)], 1u);
+  slots[pos] = (j << 1) | (d >> 31);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_batch_add: one tree round of the bucket accumulation.
+//   output element e = input element 2e + input element 2e+1 (affine, edge cases included),
+//   each lane walks `steps` pairs e = i*T + t and shares ONE field inversion among them
+//   (Montgomery's trick: src/curve-affine.ts:484-516, src/wasm/inverse.ts:220-271).
+// ---------------------------------------------------------------------------------------------
+
+enum : int { MODE_GATHER = 0, MODE_REGULAR = 1, MODE_SEARCH = 2 };
+
+struct BatchArgs {
+  const uint32_t* points;   // MODE_GATHER: point rows
+  const uint32_t* slots;    // MODE_GATHER: payload slots, pair e = slots[2e], slots[2e+1]
+  const uint4* in;          // MODE_REGULAR / MODE_SEARCH: input planes
+  uint64_t in_cap;
+  uint4* out;               // output planes
+  uint64_t out_cap;
+  uint32_t* scratch;        // prefix products
+  uint64_t n_out;           // number of output elements
+  uint32_t steps;
+  const uint32_t* off_in;   // MODE_SEARCH: bucket offsets of the input / output round
+  const uint32_t* off_out;
+  uint32_t nb;
+};
+
+struct Side {
+  uint64_t idx;      // element index (planes) or row base word offset (gather)
+  uint32_t xoff;     // gather: word offset of x inside the row (0 or 24)
+  bool neg;          // gather: negate y
+  bool absent;       // no such element: identity
+};
+
+template <int MODE>
+MSM_DEV void locate(const BatchArgs& a, uint64_t e, Side& A, Side& B) {
+  A.xoff = B.xoff = 0; A.neg = B.neg = false; A.absent = B.absent = false;
+  if (MODE == MODE_GATHER) {
+    uint2 pp = reinterpret_cast<const uint2*>(a.slots)[e];
+    A.absent = pp.x == SLOT_EMPTY;
+    B.absent = pp.y == SLOT_EMPTY;
+    A.idx = (uint64_t)(pp.x >> 2) * ROW_WORDS; A.xoff = (pp.x & 2u) ? 24u : 0u; A.neg = pp.x & 1u;
+    B.idx = (uint64_t)(pp.y >> 2) * ROW_WORDS; B.xoff = (pp.y & 2u) ? 24u : 0u; B.neg = pp.y & 1u;
+  } else if (MODE == MODE_REGULAR) {
+    A.idx = 2 * e; B.idx = 2 * e + 1;
+  } else {
+    uint32_t lo = 0, hi = a.nb;
+    const uint32_t e32 = (uint32_t)e;
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (a.off_out[mid] <= e32) lo = mid; else hi = mid;
+    }
+    uint32_t j = e32 - a.off_out[lo];
+    uint32_t ibeg = a.off_in[lo], iend = a.off_in[lo + 1];
+    A.idx = (uint64_t)ibeg + 2ull * j;
+    B.idx = A.idx + 1;
+    B.absent = B.idx >= iend;
+  }
+}
+
+// returns true if the element is the identity
+template <int MODE>
+MSM_DEV bool load_x(const BatchArgs& a, const Side& s, Fe<F>& x) {
+  if (s.absent) return true;
+  uint32_t w[NW];
+  if (MODE == MODE_GATHER) load_words12(w, a.points + s.idx + s.xoff);
+  else load_planes3(w, a.in, a.in_cap, 0, s.idx);
+  fe_unpack<F>(x, w);
+  return w[NW - 1] == INF_WORD;
+}
+
+template <int MODE>
+MSM_DEV void load_y(const BatchArgs& a, const Side& s, Fe<F>& y) {
+  uint32_t w[NW];
+  if (MODE == MODE_GATHER) load_words12(w, a.points + s.idx + 12);
+  else load_planes3(w, a.in, a.in_cap, 3, s.idx);
+  fe_unpack<F>(y, w);
+  if (MODE == MODE_GATHER && s.neg && !fe_is_zero_canonical<F>(y)) {
+    Fe<F> z;
+    fe_set_zero<F>(z);
+    fe_sub_p<F>(y, z, y);  // p - y, canonical because 0 < y < p
+  }
+}
+
+enum : int { KIND_ADD = 0, KIND_DOUBLE = 1, KIND_COPY_A = 2, KIND_COPY_B = 3, KIND_ZERO = 4 };
+
+// classification + denominator shared by the forward and the backward sweep
+template <int MODE>
+MSM_DEV int classify(const BatchArgs& a, const Side& A, const Side& B, const Fe<F>& x1, bool inf1, const Fe<F>& x2,
+                     bool inf2, Fe<F>& den, Fe<F>& y1, Fe<F>& y2, bool& have_y) {
+  have_y = false;
+  fe_set_one<F>(den);
+  if (inf2) return KIND_COPY_A;
+  if (inf1) return KIND_COPY_B;
+  if (fe_equal(x1, x2)) {
+    load_y<MODE>(a, A, y1);
+    load_y<MODE>(a, B, y2);
+    have_y = true;
+    if (fe_equal(y1, y2) && !fe_is_zero_canonical<F>(y1)) {
+      fe_add<F>(den, y1, y1);
+      return KIND_DOUBLE;
+    }
+    return KIND_ZERO;
+  }
+  fe_sub_p<F>(den, x2, x1);
+  return KIND_ADD;
+}
+
+MSM_DEV void store_point(uint4* out, uint64_t cap, uint64_t e, const Fe<F>& x, const Fe<F>& y) {
+  uint32_t w[NW];
+  fe_pack<F>(w, x);
+  store_planes3(out, cap, 0, e, w);
+  fe_pack<F>(w, y);
+  store_planes3(out, cap, 3, e, w);
+}
+
+MSM_DEV void store_identity(uint4* out, uint64_t cap, uint64_t e) {
+  uint32_t w[NW];
+#pragma unroll
+  for (int j = 0; j < NW; j++) w[j] = INF_WORD;
+  store_planes3(out, cap, 0, e, w);
+#pragma unroll
+  for (int j = 0; j < NW; j++) w[j] = 0;
+  store_planes3(out, cap, 3, e, w);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
+  const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fe<F> acc;
+  fe_set_one<F>(acc);
+
+  // forward sweep: prefix products of the denominators
+#pragma unroll 1
+  for (uint32_t i = 0; i < a.steps; i++) {
+    uint64_t e = (uint64_t)i * T + t;
+    if (e >= a.n_out) break;
+    Side A, B;
+    locate<MODE>(a, e, A, B);
+    Fe<F> x1, x2, y1, y2, den;
+    bool inf1 = load_x<MODE>(a, A, x1);
+    bool inf2 = load_x<MODE>(a, B, x2);
+    bool have_y;
+    classify<MODE>(a, A, B, x1, inf1, x2, inf2, den, y1, y2, have_y);
+    uint32_t* sp = a.scratch + ((uint64_t)i * NL) * T + t;
+#pragma unroll
+    for (int l = 0; l < NL; l++) sp[(uint64_t)l * T] = acc.l[l];
+    fe_mul<F>(acc, acc, den);
+  }
+
+  Fe<F> inv;
+  fe_inv<F>(inv, acc);
+
+  // backward sweep
+#pragma unroll 1
+  for (int i = (int)a.steps - 1; i >= 0; i--) {
+    uint64_t e = (uint64_t)i * T + t;
+    if (e >= a.n_out) continue;
+    Side A, B;
+    locate<MODE>(a, e, A, B);
+    Fe<F> x1, x2, y1, y2, den, pre, d;
+    bool inf1 = load_x<MODE>(a, A, x1);
+    bool inf2 = load_x<MODE>(a, B, x2);
+    bool have_y;
+    int kind = classify<MODE>(a, A, B, x1, inf1, x2, inf2, den, y1, y2, have_y);
+    const uint32_t* sp = a.scratch + ((uint64_t)i * NL) * T + t;
+#pragma unroll
+    for (int l = 0; l < NL; l++) pre.l[l] = sp[(uint64_t)l * T];
+    fe_mul<F>(d, inv, pre);     // 1 / den_i
+    fe_mul<F>(inv, inv, den);   // strip den_i from the running inverse
+
+    if (kind == KIND_ZERO || (kind == KIND_COPY_A && inf1)) {
+      store_identity(a.out, a.out_cap, e);
+      continue;
+    }
+    if (kind == KIND_COPY_A) {
+      load_y<MODE>(a, A, y1);
+      store_point(a.out, a.out_cap, e, x1, y1);
+      continue;
+    }
+    if (kind == KIND_COPY_B) {
+      load_y<MODE>(a, B, y2);
+      store_point(a.out, a.out_cap, e, x2, y2);
+      continue;
+    }
+    if (!have_y) {
+      load_y<MODE>(a, A, y1);
+      load_y<MODE>(a, B, y2);
+    }
+    Fe<F> num, m, mm, x3, y3, tt;
+    if (kind == KIND_DOUBLE) {
+      fe_sqr<F>(tt, x1);
+      fe_add<F>(num, tt, tt);
+      fe_add<F>(num, num, tt);   // 3 x^2
+    } else {
+      fe_sub_p<F>(num, y2, y1);
+    }
+    fe_mul<F>(m, num, d);
+    fe_sqr<F>(mm, m);
+    fe_sub_p<F>(x3, mm, x1);
+    fe_sub_p<F>(x3, x3, x2);
+    fe_reduce_4p<F>(x3);
+    fe_sub_p<F>(tt, x1, x3);
+    fe_mul<F>(y3, m, tt);
+    fe_sub_p<F>(y3, y3, y1);
+    fe_reduce_4p<F>(y3);
+    store_point(a.out, a.out_cap, e, x3, y3);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bucket_reduce: per chunk of TC buckets of one window, triangle + (lstart-1)*row in projective
+// ---------------------------------------------------------------------------------------------
+
+struct ProjOut {
+  uint32_t w[3 * NL];
+};
+
+MSM_DEV void proj_store(uint32_t* dst, const Proj<F>& P) {
+#pragma unroll
+  for (int l = 0; l < NL; l++) { dst[l] = P.X.l[l]; dst[NL + l] = P.Y.l[l]; dst[2 * NL + l] = P.Z.l[l]; }
+}
+MSM_DEV void proj_load(Proj<F>& P, const uint32_t* src) {
+#pragma unroll
+  for (int l = 0; l < NL; l++) { P.X.l[l] = src[l]; P.Y.l[l] = src[NL + l]; P.Z.l[l] = src[2 * NL + l]; }
+}
+
+__global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, const uint4* fin, uint64_t fin_cap,
+                                                       const uint32_t* off_fin, uint32_t L, uint32_t TC,
+                                                       uint32_t nchunks, uint32_t k_cnt) {
+  uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= nchunks * k_cnt) return;
+  uint32_t kk = id / nchunks, ch = id - kk * nchunks;
+  uint32_t lstart = ch * TC + 1;                       // bucket indices l are 1-based
+  uint32_t lend = min(lstart + TC - 1, L);
+  Proj<F> row, tri;
+  proj_set_zero<F>(row);
+  proj_set_zero<F>(tri);
+#pragma unroll 1
+  for (uint32_t l = lend; l >= lstart; l--) {
+    uint64_t b = (uint64_t)kk * L + (l - 1);
+    uint32_t o0 = off_fin[b], o1 = off_fin[b + 1];
+    Proj<F> Q;
+    bool qinf = true;
+    if (o1 > o0) {
+      uint32_t w[NW];
+      load_planes3(w, fin, fin_cap, 0, o0);
+      qinf = w[NW - 1] == INF_WORD;
+      fe_unpack<F>(Q.X, w);
+      load_planes3(w, fin, fin_cap, 3, o0);
+      fe_unpack<F>(Q.Y, w);
+    }
+    proj_add_mixed<F>(row, row, Q, qinf);
+    proj_add<F>(tri, tri, row);
+  }
+  uint32_t ls = lstart - 1;
+  if (ls) {
+#pragma unroll 1
+    while (true) {
+      if (ls & 1) proj_add<F>(tri, tri, row);
+      ls >>= 1;
+      if (ls == 0) break;
+      proj_double<F>(row, row);
+    }
+  }
+  proj_store(columns + (uint64_t)id * (3 * NL), tri);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_window_sum: P_k = sum of the window's columns; one workgroup per window
+// output: 3 x 12 packed canonical Montgomery words (X, Y, Z) per window
+// ---------------------------------------------------------------------------------------------
+
+constexpr int WS_THREADS = 256;
+
+__global__ void __launch_bounds__(WS_THREADS) k_window_sum(uint32_t* partials, const uint32_t* columns, uint32_t nchunks) {
+  __shared__ uint32_t lds[3 * NL * WS_THREADS];
+  const uint32_t kk = blockIdx.x, tid = threadIdx.x;
+  Proj<F> acc;
+  proj_set_zero<F>(acc);
+#pragma unroll 1
+  for (uint32_t j = tid; j < nchunks; j += WS_THREADS) {
+    Proj<F> Q;
+    proj_load(Q, columns + ((uint64_t)kk * nchunks + j) * (3 * NL));
+    proj_add<F>(acc, acc, Q);
+  }
+#pragma unroll 1
+  for (uint32_t s = WS_THREADS / 2; s >= 1; s >>= 1) {
+    if (tid >= s && tid < 2 * s) {
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        lds[(l)*WS_THREADS + tid] = acc.X.l[l];
+        lds[(NL + l) * WS_THREADS + tid] = acc.Y.l[l];
+        lds[(2 * NL + l) * WS_THREADS + tid] = acc.Z.l[l];
+      }
+    }
+    __syncthreads();
+    if (tid < s) {
+      Proj<F> Q;
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        Q.X.l[l] = lds[(l)*WS_THREADS + tid + s];
+        Q.Y.l[l] = lds[(NL + l) * WS_THREADS + tid + s];
+        Q.Z.l[l] = lds[(2 * NL + l) * WS_THREADS + tid + s];
+      }
+      proj_add<F>(acc, acc, Q);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    fe_reduce_2p<F>(acc.X);
+    fe_reduce_2p<F>(acc.Y);
+    fe_reduce_2p<F>(acc.Z);
+    uint32_t* dst = partials + (uint64_t)kk * 36;
+    uint32_t w[NW];
+    fe_pack<F>(w, acc.X);
+#pragma unroll
+    for (int j = 0; j < NW; j++) dst[j] = w[j];
+    fe_pack<F>(w, acc.Y);
+#pragma unroll
+    for (int j = 0; j < NW; j++) dst[12 + j] = w[j];
+    fe_pack<F>(w, acc.Z);
+#pragma unroll
+    for (int j = 0; j < NW; j++) dst[24 + j] = w[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// test kernels: element-wise field / curve / GLV operations for parity tests against the oracle
+// (the fine-grained operator table of src/field-msm.ts:86-123 as a GPU debug surface)
+// ---------------------------------------------------------------------------------------------
+
+enum : int { OP_MUL = 0, OP_SQR = 1, OP_ADD = 2, OP_SUB = 3, OP_INV = 4, OP_TO_MONT = 5, OP_FROM_MONT = 6 };
+
+// a, b, out: n x 12 packed words; values are canonical Montgomery form unless the op says otherwise
+__global__ void __launch_bounds__(256) k_test_fp(uint32_t* out, const uint32_t* a, const uint32_t* b, uint32_t n, int op) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe<F> x, y, r;
+  fe_load<F>(x, a + (uint64_t)i * NW);
+  fe_load<F>(y, b + (uint64_t)i * NW);
+  switch (op) {
+    case OP_MUL: fe_mul<F>(r, x, y); break;
+    case OP_SQR: fe_sqr<F>(r, x); break;
+    case OP_ADD: fe_add<F>(r, x, y); break;
+    case OP_SUB: fe_sub_p<F>(r, x, y); break;
+    case OP_INV: fe_inv<F>(r, x); break;
+    case OP_TO_MONT: {
+      Fe<F> r2;
+#pragma unroll
+      for (int l = 0; l < NL; l++) r2.l[l] = F::R2[l];
+      fe_mul<F>(r, x, r2);
+      break;
+    }
+    default: {
+      Fe<F> one;
+      fe_set_zero<F>(one);
+      one.l[0] = 1;
+      fe_mul<F>(r, x, one);
+      break;
+    }
+  }
+  fe_reduce_4p<F>(r);
+  fe_store<F>(out + (uint64_t)i * NW, r);
+}
+
+// out: n x 10 words: |s0| (4), |s1| (4), neg0, neg1
+__global__ void __launch_bounds__(256) k_test_glv(uint32_t* out, const uint32_t* scalars, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) s[j] = scalars[(uint64_t)i * 8 + j];
+  GlvHalf h0, h1;
+  glv_decompose(h0, h1, s);
+  uint32_t* o = out + (uint64_t)i * 10;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { o[j] = h0.mag[j]; o[4 + j] = h1.mag[j]; }
+  o[8] = h0.neg; o[9] = h1.neg;
+}
+
+}  // namespace msm
