@@ -106,12 +106,13 @@ int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_ou
  * n resident points P_i = a_i * G and, if `a_out` is non-null, the n scalars a_i (32-byte LE) so a
  * caller can verify sum s_i P_i = (sum s_i a_i) G in O(n). */
 int msm_generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out);
-/* n uniformly random scalars < q, written to a device buffer owned by the context; returns its
- * device pointer (valid until the next call) and optionally copies them to the host. */
+/* n uniformly random scalars < q.  If *dev_ptr_out is NULL on entry they go to a device buffer owned by
+ * the context (valid until the next call) whose address is returned; otherwise *dev_ptr_out must be a
+ * caller-owned device buffer of n * 32 bytes.  host_out (optional) receives a copy. */
 int msm_generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void** dev_ptr_out, uint8_t* host_out);
 
-/* Read resident point i back in wire format (debug / tests). */
-int msm_get_point(msm_ctx* ctx, uint64_t i, uint8_t* out_xy);
+/* Read resident points [first, first + count) back in wire format (tests, CPU-baseline sampling). */
+int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy);
 
 /* ---- fine-grained GPU operators for parity tests (debug surface) ---- */
 enum { MSM_OP_MUL = 0, MSM_OP_SQR = 1, MSM_OP_ADD = 2, MSM_OP_SUB = 3, MSM_OP_INV = 4,

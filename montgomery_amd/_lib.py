@@ -22,7 +22,7 @@ OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_INV, OP_TO_MONT, OP_FROM_MONT = range(7)
 # every symbol include/msm_hip.h declares
 EXPORTS = (
     "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_set_points", "msm_run", "msm_window_sums",
-    "msm_combine", "msm_plan", "msm_generate_points", "msm_generate_scalars", "msm_get_point", "msm_test_fp",
+    "msm_combine", "msm_plan", "msm_generate_points", "msm_generate_scalars", "msm_get_points", "msm_test_fp",
     "msm_test_glv", "msm_test_batch_add",
 )
 
@@ -76,7 +76,7 @@ def load() -> C.CDLL:
     lib.msm_plan.argtypes = [vp, u64, C.POINTER(MsmOpts), C.POINTER(i32), C.POINTER(i32)]
     lib.msm_generate_points.argtypes = [vp, u64, u64, vp]
     lib.msm_generate_scalars.argtypes = [vp, u64, u64, C.POINTER(vp), vp]
-    lib.msm_get_point.argtypes = [vp, u64, vp]
+    lib.msm_get_points.argtypes = [vp, u64, u64, vp]
     lib.msm_test_fp.argtypes = [vp, C.c_int, vp, vp, vp, u64]
     lib.msm_test_glv.argtypes = [vp, vp, vp, u64]
     lib.msm_test_batch_add.argtypes = [vp, vp, vp, vp, u64]

@@ -139,16 +139,20 @@ class MsmContext:
         self.n_points = n
         return bytes(out) if out is not None else (b"" if want_scalars else None)
 
-    def generate_scalars(self, n: int, seed: int = 1, to_host: bool = False) -> Tuple[int, Optional[bytes]]:
-        dev = C.c_void_p()
+    def generate_scalars(self, n: int, seed: int = 1, to_host: bool = False, into: int = 0) -> Tuple[int, Optional[bytes]]:
+        """n random scalars < q on the device.  `into`: caller-owned device pointer (n * 32 bytes), 0 = library buffer."""
+        dev = C.c_void_p(into or None)
         out = (C.c_uint8 * (32 * n))() if to_host and n else None
         self._check(self._lib.msm_generate_scalars(self._h, n, seed, C.byref(dev), out))
         return int(dev.value or 0), (bytes(out) if out is not None else None)
 
+    def get_points(self, first: int, count: int) -> bytes:
+        out = (C.c_uint8 * max(96 * count, 1))()
+        self._check(self._lib.msm_get_points(self._h, first, count, out))
+        return bytes(out)[: 96 * count]
+
     def get_point(self, i: int) -> Optional[Tuple[int, int]]:
-        out = (C.c_uint8 * 96)()
-        self._check(self._lib.msm_get_point(self._h, i, out))
-        b = bytes(out)
+        b = self.get_points(i, 1)
         x, y = int.from_bytes(b[:48], "little"), int.from_bytes(b[48:], "little")
         return None if (x == 0 and y == 0) else (x, y)
 

@@ -603,20 +603,25 @@ int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const 
   return MSM_OK;
 }
 
-int msm_get_point(msm_ctx* ctx, uint64_t i, uint8_t* out_xy) {
-  if (!ctx || !out_xy || i >= ctx->n_points) return fail(ctx, MSM_ERR_ARG, "msm_get_point: bad argument");
+int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy) {
+  if (!ctx || !out_xy || first + count > ctx->n_points) return fail(ctx, MSM_ERR_ARG, "msm_get_points: bad argument");
   try {
     HIPCHK(hipSetDevice(ctx->device));
-    uint32_t row[ROW_WORDS];
-    HIPCHK(hipMemcpy(row, (const uint32_t*)ctx->rows.p + i * ROW_WORDS, sizeof row, hipMemcpyDeviceToHost));
-    memset(out_xy, 0, 96);
-    if (row[11] == INF_WORD) return MSM_OK;
-    msm_host::Fe6 t, one = {{1, 0, 0, 0, 0, 0}};
-    for (int j = 0; j < 2; j++) {
-      words_to_fe6(t, row + 12 * j);
-      ctx->hc.F.mul(t, t, ctx->k_dev_to_host);  // host Montgomery
-      ctx->hc.F.mul(t, t, one);                 // plain
-      fe6_to_bytes(out_xy + 48 * j, t);
+    std::vector<uint32_t> rows((size_t)count * ROW_WORDS);
+    if (count)
+      HIPCHK(hipMemcpy(rows.data(), (const uint32_t*)ctx->rows.p + first * ROW_WORDS, rows.size() * 4, hipMemcpyDeviceToHost));
+    memset(out_xy, 0, (size_t)count * 96);
+    msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
+    for (uint64_t i = 0; i < count; i++) {
+      const uint32_t* row = &rows[(size_t)i * ROW_WORDS];
+      if (row[11] == INF_WORD) continue;
+      for (int j = 0; j < 2; j++) {
+        msm_host::Fe6 t;
+        words_to_fe6(t, row + 12 * j);
+        ctx->hc.F.mul(t, t, ctx->k_dev_to_host);  // host Montgomery
+        ctx->hc.F.mul(t, t, one);                 // plain
+        fe6_to_bytes(out_xy + i * 96 + 48 * j, t);
+      }
     }
   } catch (const HipFail& f) {
     return fail_hip(ctx, f);

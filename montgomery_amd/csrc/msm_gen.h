@@ -53,14 +53,19 @@ __global__ void __launch_bounds__(256) k_gen_scalars(uint64_t* out, uint64_t n, 
 }
 
 inline int generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void** dev_ptr_out, uint8_t* host_out) {
-  ctx->ensure(ctx->scal, std::max<uint64_t>(n, 1) * 32);
+  // *dev_ptr_out != NULL on entry: caller-owned device buffer of n * 32 bytes; else the context's buffer
+  void* dst = *dev_ptr_out;
+  if (!dst) {
+    ctx->ensure(ctx->scal, std::max<uint64_t>(n, 1) * 32);
+    dst = ctx->scal.p;
+  }
   if (n) {
-    hipLaunchKernelGGL(k_gen_scalars, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint64_t*)ctx->scal.p, n, seed);
-    if (host_out) HIPCHK(hipMemcpyAsync(host_out, ctx->scal.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(k_gen_scalars, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint64_t*)dst, n, seed);
+    if (host_out) HIPCHK(hipMemcpyAsync(host_out, dst, n * 32, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipGetLastError());
-  *dev_ptr_out = ctx->scal.p;
+  *dev_ptr_out = dst;
   return MSM_OK;
 }
 

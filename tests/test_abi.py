@@ -1,0 +1,62 @@
+"""The C-ABI library loads and exports every symbol include/msm_hip.h declares (no compute: no GPU here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "msm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from montgomery_amd import _lib
+
+    names = declared_functions()
+    assert len(names) >= 10
+    assert sorted(_lib.EXPORTS) == names, "montgomery_amd/_lib.py EXPORTS is out of sync with include/msm_hip.h"
+    assert os.path.exists(_lib.LIB_PATH), "HIP extension not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"libmsm_hip.so does not export {n}"
+
+
+def test_result_struct_layout_matches_header():
+    from montgomery_amd._lib import MsmOpts, MsmResult
+
+    # msm_opts: 8 x int32; msm_result: 96 B + 4 x int32 + 8 floats + 2 x u64
+    assert ctypes.sizeof(MsmOpts) == 32
+    assert ctypes.sizeof(MsmResult) == 96 + 16 + 32 + 16
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Creating a context must fail loudly when no GPU is usable (this container has none)."""
+    import torch
+
+    from montgomery_amd import MsmError
+    from montgomery_amd.api import MsmContext
+
+    if torch.cuda.is_available():
+        return
+    try:
+        MsmContext()
+    except MsmError as e:
+        assert e.code in (2, 5)
+    else:
+        raise AssertionError("MsmContext() succeeded without a GPU: a fallback path exists")
+
+
+def test_product_does_not_import_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "montgomery_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                for line in src.splitlines():
+                    s = line.strip()
+                    if s.startswith(("import ", "from ", "#include")):
+                        assert "oracle" not in s, f"{f}: {s}"

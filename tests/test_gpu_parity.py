@@ -1,0 +1,329 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Needs an MI355X: `-m gpu`.
+
+Structure follows the reference's own tests: backend operator vs spec (src/field.test.ts),
+batch add vs single adds, MSM vs bigint MSM for N = 2^0 .. 2^12 (src/msm.test.ts:44-82), plus the
+fixed-point known-answer scripts (scripts/zprize23/submission-test-bls377.ts).  Everything is
+bit-exact: canonical affine (x, y) or the identity.
+"""
+import json
+import os
+
+import pytest
+
+from oracle import msm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+C = O.BLS12_377
+P_MOD = C.p
+R = 1 << 390
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def H(x):
+    return int(x, 16)
+
+
+def tb(v):
+    return v.to_bytes(48, "little")
+
+
+def fb(b, i):
+    return int.from_bytes(b[48 * i : 48 * i + 48], "little")
+
+
+def enc_pt(P):
+    return b"\0" * 96 if P is None else tb(P[0]) + tb(P[1])
+
+
+def run_msm(ctx, scalars, points, c=None):
+    ctx.set_points(b"".join(enc_pt(P) for P in points), check_curve=True)
+    res, info = ctx.run(O.scalars_to_bytes(scalars), c=c)
+    return res.as_tuple(), info
+
+
+# ---- the library that ran is the in-tree HIP extension ------------------------------------------
+
+
+def test_native_library_is_loaded(gpu_ctx):
+    from montgomery_amd import _lib
+
+    maps = open("/proc/self/maps").read()
+    assert os.path.realpath(_lib.LIB_PATH) in maps
+
+
+# ---- field operators (src/field.test.ts:27-155) --------------------------------------------------
+
+
+def field_inputs():
+    p = P_MOD
+    special = [0, 1, 2, p - 1, p - 2, (p + 1) // 2, 1 << 376, (1 << 30) - 1, 1 << 30, (1 << 360) + 5]
+    return special + O.prng_ints("gpu/fp", 500, p)
+
+
+def test_fp_mul_sqr_add_sub(gpu_ctx):
+    from montgomery_amd import _lib
+
+    vals = field_inputs()
+    n = len(vals)
+    a = b"".join(tb(v) for v in vals)
+    b = b"".join(tb(v) for v in reversed(vals))
+    rinv = pow(R, -1, P_MOD)
+    out = gpu_ctx.test_fp(_lib.OP_MUL, a, b)
+    assert all(fb(out, i) == vals[i] * vals[n - 1 - i] * rinv % P_MOD for i in range(n))
+    out = gpu_ctx.test_fp(_lib.OP_SQR, a)
+    assert all(fb(out, i) == vals[i] * vals[i] * rinv % P_MOD for i in range(n))
+    out = gpu_ctx.test_fp(_lib.OP_ADD, a, b)
+    assert all(fb(out, i) == (vals[i] + vals[n - 1 - i]) % P_MOD for i in range(n))
+    out = gpu_ctx.test_fp(_lib.OP_SUB, a, b)
+    assert all(fb(out, i) == (vals[i] - vals[n - 1 - i]) % P_MOD for i in range(n))
+
+
+def test_fp_montgomery_roundtrip_and_inverse(gpu_ctx):
+    from montgomery_amd import _lib
+
+    vals = [v for v in field_inputs() if v]
+    a = b"".join(tb(v) for v in vals)
+    mont = gpu_ctx.test_fp(_lib.OP_TO_MONT, a)
+    assert all(fb(mont, i) == v * R % P_MOD for i, v in enumerate(vals))
+    assert gpu_ctx.test_fp(_lib.OP_FROM_MONT, mont) == a
+    inv = gpu_ctx.test_fp(_lib.OP_INV, mont)            # (a R)^-1 R^2 = a^-1 R
+    back = gpu_ctx.test_fp(_lib.OP_FROM_MONT, inv)
+    assert all(fb(back, i) == pow(v, -1, P_MOD) for i, v in enumerate(vals))
+
+
+def test_fp_golden(gpu_ctx):
+    from montgomery_amd import _lib
+
+    cases = load("fp377.json")["cases"]
+    a = b"".join(tb(H(c["a"])) for c in cases)
+    b = b"".join(tb(H(c["b"])) for c in cases)
+    am, bm = gpu_ctx.test_fp(_lib.OP_TO_MONT, a), gpu_ctx.test_fp(_lib.OP_TO_MONT, b)
+    for op, key in ((_lib.OP_MUL, "mul"), (_lib.OP_ADD, "add"), (_lib.OP_SUB, "sub"), (_lib.OP_SQR, "sqr")):
+        out = gpu_ctx.test_fp(_lib.OP_FROM_MONT, gpu_ctx.test_fp(op, am, bm))
+        assert [fb(out, i) for i in range(len(cases))] == [H(c[key]) for c in cases], key
+
+
+# ---- GLV decomposition (src/glv/glv-test.ts:92-125) ------------------------------------------------
+
+
+def test_glv_decompose(gpu_ctx, c_oracle):
+    g = O.glv_params(C.q, C.lam)
+    scalars = [H(c["s"]) for c in load("glv377.json")["cases"]] + O.prng_ints("gpu/glv", 20000, C.q)
+    got = gpu_ctx.test_glv(O.scalars_to_bytes(scalars))
+    for s, r in zip(scalars[:3000], got):
+        assert tuple(r) == O.glv_decompose(s, g)
+    for s, r in zip(scalars[3000:], got[3000:]):
+        assert tuple(r) == c_oracle.glv_decompose(s)
+
+
+# ---- batched affine addition (src/curve-affine.ts:376-522) -----------------------------------------
+
+
+def test_batch_add_golden_and_random(gpu_ctx):
+    dec = lambda P: None if P is None else (H(P[0]), H(P[1]))
+    cases = load("point_add377.json")["cases"]
+    gs = [dec(c["g"]) for c in cases]
+    hs = [dec(c["h"]) for c in cases]
+    exp = [dec(c["sum"]) for c in cases]
+    pts, _ = O.random_points_bls377("gpu/batch", 600)
+    gs += pts[:300]
+    hs += pts[300:]
+    exp += [O.aff_add(a, b, P_MOD) for a, b in zip(pts[:300], pts[300:])]
+    out = gpu_ctx.test_batch_add(b"".join(map(enc_pt, gs)), b"".join(map(enc_pt, hs)))
+    for i, e in enumerate(exp):
+        got = (fb(out, 2 * i), fb(out, 2 * i + 1))
+        assert got == ((0, 0) if e is None else e), i
+
+
+# ---- MSM vs oracle --------------------------------------------------------------------------------
+
+
+def test_msm_golden_vectors(gpu_ctx):
+    for c in load("msm377.json")["cases"]:
+        gpu_ctx.set_points(bytes.fromhex(c["points"]))
+        exp = None if c["result"] is None else (H(c["result"][0]), H(c["result"][1]))
+        for cc in (c["c"], None, 3, 11):
+            res, info = gpu_ctx.run(bytes.fromhex(c["scalars"]), c=cc)
+            assert res.as_tuple() == exp, (c["name"], cc, info)
+
+
+def test_msm_sizes_like_reference_msm_test(gpu_ctx, c_oracle):
+    """N = 2^0, 2^2, ..., 2^12 (src/msm.test.ts:44-82): GPU == C oracle == known-discrete-log answer."""
+    pts, ks = O.random_points_bls377("gpu/sizes", 4096)
+    G = (C.gx, C.gy)
+    for lg in range(0, 13, 2):
+        n = 1 << lg
+        sc = O.prng_ints(f"gpu/sizes/{lg}", n, C.q)
+        got, info = run_msm(gpu_ctx, sc, pts[:n])
+        exp = O.aff_scale(sum(a * b for a, b in zip(sc, ks[:n])) % C.q, G, P_MOD)
+        assert got == exp, (lg, info)
+        ref, _ = c_oracle.msm_bls377(O.points_to_bytes(pts[:n], 48), O.scalars_to_bytes(sc), 0)
+        assert ref == exp
+
+
+def test_msm_ragged_sizes_and_windows(gpu_ctx, c_oracle):
+    pts, _ = O.random_points_bls377("gpu/ragged", 777)
+    for n, c in ((1, 2), (2, 16), (3, 5), (17, 9), (100, 13), (255, 6), (777, 8), (777, 10), (513, 12)):
+        sc = O.prng_ints(f"gpu/ragged/{n}/{c}", n, C.q)
+        got, info = run_msm(gpu_ctx, sc, pts[:n], c)
+        ref, _ = c_oracle.msm_bls377(O.points_to_bytes(pts[:n], 48), O.scalars_to_bytes(sc), 0)
+        assert got == ref, (n, c, info)
+        assert info["c"] == c
+
+
+def test_msm_edge_cases(gpu_ctx):
+    pts, _ = O.random_points_bls377("gpu/edge", 64)
+    P = O.ZPRIZE_BLS377_POINT
+    q = C.q
+    # empty input
+    gpu_ctx.set_points(b"")
+    res, _ = gpu_ctx.run(b"")
+    assert res.isZero
+    # reference fixed-point KATs
+    assert run_msm(gpu_ctx, [2, q - 1], [P, P])[0] == P
+    sc = O.prng_ints("gpu/edge/same", 1000, q)
+    assert run_msm(gpu_ctx, sc, [P] * 1000)[0] == run_msm(gpu_ctx, [sum(sc) % q], [P])[0]
+    # all scalars zero / cancellation -> identity
+    assert run_msm(gpu_ctx, [0] * 10, pts[:10])[0] is None
+    assert run_msm(gpu_ctx, [5, q - 5], [pts[0], pts[0]])[0] is None
+    assert run_msm(gpu_ctx, [9, 9], [pts[0], O.aff_neg(pts[0], P_MOD)])[0] is None
+    # scalar extremes
+    for s in (1, q - 1, q - 2, C.lam, (1 << 252) + 12345, (1 << 126) - 1, 1 << 126):
+        assert run_msm(gpu_ctx, [s], [pts[1]])[0] == O.aff_scale(s, pts[1], P_MOD), hex(s)
+    # scalars >= q are reduced
+    assert run_msm(gpu_ctx, [q + 5], [pts[2]])[0] == O.aff_scale(5, pts[2], P_MOD)
+    # identity among the inputs, repeated points, P and -P in one bucket
+    sc = O.prng_ints("gpu/edge/mix", 48, q)
+    mix = list(pts[:48])
+    mix[3] = None
+    mix[5] = mix[4]; sc[5] = sc[4]
+    mix[7] = O.aff_neg(mix[6], P_MOD); sc[7] = sc[6]
+    for c in (4, 7, None):
+        assert run_msm(gpu_ctx, sc, mix, c)[0] == O.msm_batched_affine(sc, mix, c=6), c
+    # fewer scalars than resident points uses the first n points
+    gpu_ctx.set_points(b"".join(enc_pt(Q) for Q in pts))
+    sc = O.prng_ints("gpu/edge/prefix", 20, q)
+    res, _ = gpu_ctx.run(O.scalars_to_bytes(sc))
+    assert res.as_tuple() == O.msm_batched_affine(sc, pts[:20], c=5)
+
+
+def test_msm_error_codes(gpu_ctx):
+    from montgomery_amd import MsmError
+
+    pts, _ = O.random_points_bls377("gpu/err", 4)
+    with pytest.raises(MsmError) as e:
+        gpu_ctx.set_points(tb(P_MOD) + tb(1))             # coordinate >= p
+    assert e.value.code == 3
+    with pytest.raises(MsmError) as e:
+        gpu_ctx.set_points(tb(5) + tb(7), check_curve=True)  # not on the curve
+    assert e.value.code == 3
+    gpu_ctx.set_points(b"".join(enc_pt(Q) for Q in pts))
+    with pytest.raises(MsmError) as e:
+        gpu_ctx.run(O.scalars_to_bytes([1] * 5))            # more scalars than points
+    assert e.value.code == 4
+    with pytest.raises(MsmError) as e:
+        gpu_ctx.run(O.scalars_to_bytes([1]), c=40)          # bad window size
+    assert e.value.code == 1
+
+
+def test_window_shards_combine_to_full_msm(gpu_ctx):
+    """The multi-GPU decomposition on one GPU: P_k shards -> msm_combine == msm_run."""
+    n = 300
+    pts, _ = O.random_points_bls377("gpu/shard", n)
+    sc = O.prng_ints("gpu/shard/s", n, C.q)
+    full, info = run_msm(gpu_ctx, sc, pts, 8)
+    K = info["K"]
+    sb = O.scalars_to_bytes(sc)
+    parts = b""
+    for lo in range(0, K, 3):
+        pb, _ = gpu_ctx.window_sums(sb, n, lo, min(K, lo + 3), c=8)
+        parts += pb
+    assert gpu_ctx.combine(parts, K, 8).as_tuple() == full
+    # each shard agrees with the oracle's partition sum as a group element
+    g = O.glv_params(C.q, C.lam)
+    for k in range(K):
+        X, Y, Z = (int.from_bytes(parts[144 * k + 48 * j : 144 * k + 48 * j + 48], "little") for j in range(3))
+        got = O.proj_to_affine((X, Y, Z), P_MOD)
+        exp = None
+        for s, Pt in zip(sc, pts):
+            a0, a1, n0, n1 = O.glv_decompose(s, g)
+            for a, neg, Q in ((a0, n0, Pt), (a1, n1, (C.beta * Pt[0] % P_MOD, Pt[1]))):
+                l, dneg = O.signed_digits(a, 8, K)[k]
+                if l:
+                    T = O.aff_scale(l, Q, P_MOD)
+                    exp = O.aff_add(exp, O.aff_neg(T, P_MOD) if neg ^ dneg else T, P_MOD)
+        assert got == exp, k
+
+
+# ---- large sizes: size-independent properties --------------------------------------------------------
+
+
+def test_generated_points_are_valid_and_known(gpu_ctx):
+    n = 2000
+    a = O.scalars_from_bytes(gpu_ctx.generate_points(n, seed=11, want_scalars=True))
+    G = (C.gx, C.gy)
+    for i in (0, 1, 2, 999, 1999):
+        assert gpu_ctx.get_point(i) == O.aff_scale(a[i], G, P_MOD)
+    dev, sb = gpu_ctx.generate_scalars(n, seed=5, to_host=True)
+    s = O.scalars_from_bytes(sb)
+    assert all(v < C.q for v in s) and len(set(s)) == n
+    res, _ = gpu_ctx.run_device(dev, n)
+    assert res.as_tuple() == O.aff_scale(sum(x * y for x, y in zip(a, s)) % C.q, G, P_MOD)
+
+
+@pytest.mark.parametrize("lg", [16, 20])
+def test_msm_large_known_discrete_logs(gpu_ctx, lg):
+    """sum s_i P_i = (sum s_i a_i) G with P_i = a_i G generated on the GPU (BASELINE configs[1] = 2^20)."""
+    n = 1 << lg
+    a = O.scalars_from_bytes(gpu_ctx.generate_points(n, seed=100 + lg, want_scalars=True))
+    dev, sb = gpu_ctx.generate_scalars(n, seed=200 + lg, to_host=True)
+    s = O.scalars_from_bytes(sb)
+    res, info = gpu_ctx.run_device(dev, n)
+    G = (C.gx, C.gy)
+    assert res.as_tuple() == O.aff_scale(sum(x * y for x, y in zip(a, s)) % C.q, G, P_MOD), info
+    # independence of the window size (the result is a group element, not a function of c)
+    res2, _ = gpu_ctx.run_device(dev, n, c=11)
+    assert res2.as_tuple() == res.as_tuple()
+
+
+def test_msm_large_linearity(gpu_ctx):
+    """MSM(s) + MSM(t) = MSM(s + t) and MSM(q - s) = -MSM(s) at 2^18, host scalars (PCIe path)."""
+    n = 1 << 18
+    gpu_ctx.generate_points(n, seed=31)
+    _, sb = gpu_ctx.generate_scalars(n, seed=32, to_host=True)
+    _, tb_ = gpu_ctx.generate_scalars(n, seed=33, to_host=True)
+    s, t = O.scalars_from_bytes(sb), O.scalars_from_bytes(tb_)
+    rs, _ = gpu_ctx.run(sb)
+    rt, _ = gpu_ctx.run(tb_)
+    rst, _ = gpu_ctx.run(O.scalars_to_bytes([(x + y) % C.q for x, y in zip(s, t)]))
+    assert O.aff_add(rs.as_tuple(), rt.as_tuple(), P_MOD) == rst.as_tuple()
+    rneg, _ = gpu_ctx.run(O.scalars_to_bytes([(C.q - x) % C.q for x in s]))
+    assert rneg.as_tuple() == O.aff_neg(rs.as_tuple(), P_MOD)
+
+
+def test_reference_shaped_api(gpu_ctx):
+    """`Weierstraß.create(...).Parallel.msm` / `compute_msm` facade (src/parallel.ts, submission-bls377.ts)."""
+    from montgomery_amd.api import BLS12_377_PARAMS, Weierstrass, compute_msm
+
+    cv = Weierstrass.create(BLS12_377_PARAMS)
+    pts, _ = O.random_points_bls377("gpu/api", 50)
+    sc = O.prng_ints("gpu/api/s", 50, C.q)
+    par = cv.Parallel
+    pp, sp = par.getPointer(50 * 96), par.getScalarPointer(50 * 32)
+    par.pointsFromBytes(pp, O.points_to_bytes(pts, 48), 50)
+    par.scalarsFromBytes(sp, O.scalars_to_bytes(sc), 50)
+    out = par.msmUnsafe(sp, pp, 50, True, {"c": 6})
+    exp = O.msm_batched_affine(sc, pts, c=6)
+    assert out["result"].as_tuple() == exp and out["log"]
+    r = compute_msm([{"x": x, "y": y, "isZero": False} for x, y in pts], sc, curve=cv)
+    assert (r["x"], r["y"]) == exp
+    P = O.ZPRIZE_BLS377_POINT
+    r = compute_msm(O.points_to_bytes([P, P], 48), O.scalars_to_bytes([2, C.q - 1]), curve=cv)
+    assert (r["x"], r["y"]) == P
+    cv.context.close()
