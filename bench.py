@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BLS12-377 G1 MSM throughput (points/s) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 26] [--c C]
+
+One "step" = one MSM over resident base points with FRESH scalars already in HBM (the reference's
+protocol: points pre-loaded, new random scalars every run, scripts/msm-weierstrass.ts:12-51).
+N = 1: the whole MSM on one GPU.  N > 1 (launched by torch.distributed.run, one rank per GPU): the
+same MSM sharded by scalar window -- every rank holds all points and scalars, computes the window
+sums P_k of its windows, ONE RCCL all-gather of K x 144 bytes, rank 0 does the Horner combination
+(SURVEY.md section 8e).  Total work is fixed as N grows: scaling = "strong".
+
+Prints ONE JSON line on rank 0 with the driver's contract plus `roofline` (dominant kernel
+k_batch_add, HIP-event timed inside the library on its own stream) and `cpu_baseline` (the C port
+of the oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes of one affine pair addition in k_batch_add: read two 96-byte points, write one
+PAIR_ALGO_BYTES = 288
+# 32x32->64 multiply-adds of one pair addition: 5 multiplications (325 each) + 1 squaring (247), 13 x 30-bit limbs
+PAIR_MADS = 5 * 325 + 247
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+INT_MAD_PEAK = 30.3e12         # v_mad_u64_u32 lane-ops/s measured on MI355X by tools/ubench_int.hip (profiles/ubench_int_r01.txt)
+
+
+def window_shards(K, world):
+    """Contiguous window ranges, one per rank (ranks beyond K get an empty range)."""
+    out = []
+    base, rem = divmod(K, world)
+    lo = 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((lo, lo + n))
+        lo += n
+    return out
+
+
+def cpu_baseline(ctx, log2n_sample, seed):
+    """Times oracle/msm_oracle.c (kind "port") on the host cores over the first 2^log2n_sample
+    resident points.  The reference's WASM path cannot run here."""
+    from oracle import c_oracle
+
+    n = 1 << log2n_sample
+    pts = ctx.get_points(0, n)
+    _, sc = ctx.generate_scalars(n, seed=seed, to_host=True)
+    c_oracle.load()
+    t0 = time.perf_counter()
+    ref, threads = c_oracle.msm_bls377(pts, sc, 0)
+    dt = time.perf_counter() - t0
+    dev, _ = ctx.generate_scalars(n, seed=seed)
+    got, _ = ctx.run_device(dev, n)
+    assert got.as_tuple() == ref, "GPU result differs from the CPU oracle on the cpu_baseline sample"
+    return {
+        "value": n / dt,
+        "unit": "points/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"one 2^{log2n_sample}-point BLS12-377 G1 MSM (first 2^{log2n_sample} of the resident points, reference window table), "
+                  f"{dt:.2f} s, OpenMP over windows; GPU result on the same inputs checked equal",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=26)
+    ap.add_argument("--c", type=int, default=0)
+    ap.add_argument("--cpu-log2n", type=int, default=18)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from montgomery_amd.api import MsmContext
+
+    n = 1 << args.log2n
+    ctx = MsmContext(device=local_rank)
+    ctx.generate_points(n, seed=20261002)   # identical on every rank
+    c, K = ctx.plan(n, args.c or None)
+    shards = window_shards(K, world)
+    k_lo, k_hi = shards[rank]
+
+    dev = torch.device("cuda", local_rank)
+    n_bufs = args.steps + args.warmup
+    # fresh scalars per step, generated on the GPU before the timed region (resident in HBM)
+    scal = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(n_bufs)]
+    for i, t in enumerate(scal):
+        ctx.generate_scalars(n, seed=1000 + i, into=t.data_ptr())
+    gather = torch.zeros(world * 144 * K, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step(i):
+        if world == 1:
+            return ctx.run_device(scal[i].data_ptr(), n, c=c)
+        info = None
+        mine = torch.zeros(144 * K, dtype=torch.uint8, device=dev)
+        if k_hi > k_lo:
+            parts, info = ctx.window_sums(scal[i].data_ptr(), n, k_lo, k_hi, c=c, on_device=True)
+            mine[144 * k_lo : 144 * k_hi] = torch.frombuffer(bytearray(parts), dtype=torch.uint8).to(dev)
+        dist.all_gather_into_tensor(gather, mine)
+        res = None
+        if rank == 0:
+            g = gather.cpu().numpy().tobytes()
+            allp = b"".join(g[r * 144 * K + 144 * lo : r * 144 * K + 144 * hi] for r, (lo, hi) in enumerate(shards))
+            res = ctx.combine(allp, K, c)
+        return res, info
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    infos = []
+    last = None
+    for i in range(args.steps):
+        last, info = step(args.warmup + i)
+        infos.append(info)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        infos = [x for x in infos if x]
+        acc_ms = sum(x["phase_ms"]["accumulate"] for x in infos)
+        pairs = sum(x["n_pairs"] for x in infos)
+        launches = sum(x["rounds"] for x in infos) or 1
+        phase = {k: sum(x["phase_ms"][k] for x in infos) / max(len(infos), 1) for k in infos[0]["phase_ms"]} if infos else {}
+        achieved = pairs * PAIR_ALGO_BYTES / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
+        out = {
+            "metric": "BLS12-377 G1 MSM throughput",
+            "value": n * args.steps / dt,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"bls12-377-g1-msm-2^{args.log2n}",
+                "log2_n": args.log2n,
+                "window_bits": c,
+                "windows": K,
+                "parallelism": "single-gpu" if world == 1 else f"window-shard x{world}, one RCCL all-gather of {K}x144 B",
+                "points": "P_i = a_i*G generated on GPU (resident)",
+                "scalars": "uniform < q, fresh per step, resident in HBM before the timed region",
+            },
+            "roofline": {
+                "kernel": "k_batch_add (bucket accumulation tree, all rounds)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_pair_add": PAIR_ALGO_BYTES,
+                "pair_adds_per_step": pairs / max(len(infos), 1),
+                "avg_launch_ms": acc_ms / launches,
+                "launches_per_step": launches / max(len(infos), 1),
+                "int_mad": {
+                    "achieved": pairs * PAIR_MADS / (acc_ms * 1e-3) if acc_ms else 0.0,
+                    "peak": INT_MAD_PEAK,
+                    "unit": "v_mad_u64_u32 lane-ops/s",
+                    "frac": (pairs * PAIR_MADS / (acc_ms * 1e-3) / INT_MAD_PEAK) if acc_ms else 0.0,
+                },
+            },
+            "phase_ms": phase,
+            "result_is_infinity": bool(last.isZero) if last is not None else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ctx, min(args.cpu_log2n, args.log2n), seed=777)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
