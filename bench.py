@@ -31,18 +31,6 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 INT_MAD_PEAK = 30.3e12         # v_mad_u64_u32 lane-ops/s measured on MI355X by tools/ubench_int.hip (profiles/ubench_int_r01.txt)
 
 
-def window_shards(K, world):
-    """Contiguous window ranges, one per rank (ranks beyond K get an empty range)."""
-    out = []
-    base, rem = divmod(K, world)
-    lo = 0
-    for r in range(world):
-        n = base + (1 if r < rem else 0)
-        out.append((lo, lo + n))
-        lo += n
-    return out
-
-
 def cpu_baseline(ctx, log2n_sample, seed):
     """Times oracle/msm_oracle.c (kind "port") on the host cores over the first 2^log2n_sample
     resident points.  The reference's WASM path cannot run here."""
@@ -75,7 +63,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=26)
     ap.add_argument("--c", type=int, default=0)
-    ap.add_argument("--cpu-log2n", type=int, default=18)
+    ap.add_argument("--cpu-log2n", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -96,14 +84,14 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
-    from montgomery_amd.api import MsmContext
+    from montgomery_amd.api import AffineResult, MsmContext
+    from montgomery_amd.distributed import sharded_msm, window_shards
 
     n = 1 << args.log2n
     ctx = MsmContext(device=local_rank)
     ctx.generate_points(n, seed=20261002)   # identical on every rank
     c, K = ctx.plan(n, args.c or None)
     shards = window_shards(K, world)
-    k_lo, k_hi = shards[rank]
 
     dev = torch.device("cuda", local_rank)
     n_bufs = args.steps + args.warmup
@@ -111,23 +99,21 @@ def main():
     scal = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(n_bufs)]
     for i, t in enumerate(scal):
         ctx.generate_scalars(n, seed=1000 + i, into=t.data_ptr())
-    gather = torch.zeros(world * 144 * K, dtype=torch.uint8, device=dev) if world > 1 else None
-
     def step(i):
         if world == 1:
             return ctx.run_device(scal[i].data_ptr(), n, c=c)
-        info = None
-        mine = torch.zeros(144 * K, dtype=torch.uint8, device=dev)
-        if k_hi > k_lo:
-            parts, info = ctx.window_sums(scal[i].data_ptr(), n, k_lo, k_hi, c=c, on_device=True)
-            mine[144 * k_lo : 144 * k_hi] = torch.frombuffer(bytearray(parts), dtype=torch.uint8).to(dev)
-        dist.all_gather_into_tensor(gather, mine)
+        box = {}
+
+        def my_window_sums(lo, hi):
+            parts, box["info"] = ctx.window_sums(scal[i].data_ptr(), n, lo, hi, c=c, on_device=True)
+            return parts
+
+        out = sharded_msm(my_window_sums, K, c, device=dev)
         res = None
-        if rank == 0:
-            g = gather.cpu().numpy().tobytes()
-            allp = b"".join(g[r * 144 * K + 144 * lo : r * 144 * K + 144 * hi] for r, (lo, hi) in enumerate(shards))
-            res = ctx.combine(allp, K, c)
-        return res, info
+        if out is not None:
+            xy = out[1]
+            res = AffineResult(x=xy[0] if xy else 0, y=xy[1] if xy else 0, isZero=xy is None)
+        return res, box.get("info")
 
     def sync():
         if world > 1:

@@ -96,7 +96,7 @@ int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device
                     uint8_t* partials_out, msm_result* stats);
 
 /* S = sum_k 2^(c k) P_k over all K windows, then to affine (src/msm-batched-affine.ts:322-333,
- * src/curve-projective.ts:335-349). */
+ * src/curve-projective.ts:335-349).  Host arithmetic only: `ctx` may be NULL. */
 int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm_result* out);
 
 /* Window plan for n points: the c the library would pick and the resulting K. */

@@ -333,8 +333,7 @@ msm_host::Proj6 partial_to_host(const msm_ctx* ctx, const uint32_t* w) {
 }
 
 // S = sum_k 2^(ck) P_k, then affine (src/msm-batched-affine.ts:322-333, src/curve-projective.ts:335-349)
-void horner_to_affine(const msm_ctx* ctx, const std::vector<msm_host::Proj6>& P, int c, msm_result* out) {
-  const auto& C = ctx->hc;
+void horner_to_affine(const msm_host::Curve6& C, const std::vector<msm_host::Proj6>& P, int c, msm_result* out) {
   int K = (int)P.size();
   msm_host::Proj6 acc = P[K - 1];
   for (int k = K - 2; k >= 0; k--) {
@@ -547,7 +546,15 @@ int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device
 }
 
 int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
-  if (!ctx || !partials || !out || K <= 0 || c <= 0) return fail(ctx, MSM_ERR_ARG, "msm_combine: bad argument");
+  // pure host arithmetic: ctx may be NULL (rank 0 of a sharded run only needs the curve constants)
+  if (!partials || !out || K <= 0 || c <= 0) return fail(ctx, MSM_ERR_ARG, "msm_combine: bad argument");
+  static msm_host::Curve6 hc_static;
+  static bool hc_ready = false;
+  if (!hc_ready) {
+    hc_static.F.init(Fp377::PW);
+    hc_ready = true;
+  }
+  const msm_host::Curve6& C = ctx ? ctx->hc : hc_static;
   std::vector<msm_host::Proj6> P(K);
   for (int k = 0; k < K; k++) {
     msm_host::Fe6 t[3];
@@ -558,12 +565,13 @@ int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm
         for (int q = 0; q < 8; q++) v |= (uint64_t)b[8 * i + q] << (8 * q);
         t[j].v[i] = v;
       }
-      if (msm_host::Field6::ge(t[j], ctx->hc.F.p)) return fail(ctx, MSM_ERR_ARG, "msm_combine: coordinate >= p");
-      ctx->hc.F.mul(t[j], t[j], ctx->hc.F.r2);  // to host Montgomery form
+      if (msm_host::Field6::ge(t[j], C.F.p)) return fail(ctx, MSM_ERR_ARG, "msm_combine: coordinate >= p");
+      C.F.mul(t[j], t[j], C.F.r2);  // to host Montgomery form
     }
     P[k].X = t[0]; P[k].Y = t[1]; P[k].Z = t[2];
   }
-  horner_to_affine(ctx, P, c, out);
+  memset(out, 0, sizeof(*out));
+  horner_to_affine(C, P, c, out);
   out->c = c;
   out->K = K;
   return MSM_OK;
@@ -590,7 +598,7 @@ int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const 
     HIPCHK(hipEventRecord(ctx->ev[10], ctx->stream));
     std::vector<msm_host::Proj6> P(pl.K);
     for (int k = 0; k < pl.K; k++) P[k] = partial_to_host(ctx, &words[(size_t)k * 36]);
-    horner_to_affine(ctx, P, pl.c, out);
+    horner_to_affine(ctx->hc, P, pl.c, out);
     HIPCHK(hipEventRecord(ctx->ev[11], ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms;

@@ -1,0 +1,115 @@
+"""N > 1 path on CPU: world_size 2, gloo.  The window sums of each rank come from the oracle (there is no
+GPU here); sharding, the all-gather layout and the host-side Horner combination are the product's."""
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_window_sums(scalars, points, c, K):
+    """P_k for every window k as 144-byte (X, Y, Z) records, from the oracle's spec arithmetic."""
+    from oracle import msm_oracle as O
+
+    C = O.BLS12_377
+    g = O.glv_params(C.q, C.lam)
+    sums = [None] * K
+    for s, P in zip(scalars, points):
+        a0, a1, n0, n1 = O.glv_decompose(s, g)
+        for a, neg, Q in ((a0, n0, P), (a1, n1, (C.beta * P[0] % C.p, P[1]))):
+            for k, (l, dneg) in enumerate(O.signed_digits(a, c, K)):
+                if l:
+                    T = O.aff_scale(l, Q, C.p)
+                    sums[k] = O.aff_add(sums[k], O.aff_neg(T, C.p) if neg ^ dneg else T, C.p)
+    out = []
+    for S in sums:
+        X, Y, Z = (0, 1, 0) if S is None else (S[0] * 7 % C.p, S[1] * 7 % C.p, 7)   # any projective representative
+        out.append(X.to_bytes(48, "little") + Y.to_bytes(48, "little") + Z.to_bytes(48, "little"))
+    return out
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from montgomery_amd.distributed import sharded_msm
+    from oracle import msm_oracle as O
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        C = O.BLS12_377
+        results = []
+        for name, n, c in (("a", 24, 9), ("b", 5, 16), ("cancel", 2, 7)):
+            pts, _ = O.random_points_bls377("dist/" + name, n)
+            sc = O.prng_ints("dist/s/" + name, n, C.q)
+            if name == "cancel":
+                pts = [pts[0], pts[0]]
+                sc = [11, C.q - 11]
+            K = -(-127 // c)
+            allw = _oracle_window_sums(sc, pts, c, K)
+            out = sharded_msm(lambda lo, hi: b"".join(allw[lo:hi]), K, c)
+            if rank == 0:
+                results.append((out[1], O.msm_batched_affine(sc, pts, c=c)))
+            else:
+                assert out is None
+        if rank == 0:
+            q.put(results)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_window_shards_partition():
+    from montgomery_amd.distributed import window_shards
+
+    for K in (1, 5, 8, 10, 32):
+        for world in (1, 2, 3, 4, 8, 16):
+            sh = window_shards(K, world)
+            assert len(sh) == world and sh[0][0] == 0 and sh[-1][1] == K
+            assert all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
+            sizes = [hi - lo for lo, hi in sh]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_combine_host_matches_oracle():
+    from montgomery_amd.distributed import combine_host
+    from oracle import msm_oracle as O
+
+    C = O.BLS12_377
+    pts, _ = O.random_points_bls377("dist/combine", 12)
+    sc = O.prng_ints("dist/combine/s", 12, C.q)
+    for c in (4, 13):
+        K = -(-127 // c)
+        allw = _oracle_window_sums(sc, pts, c, K)
+        assert combine_host(b"".join(allw), K, c) == O.msm_batched_affine(sc, pts, c=c)
+
+
+@pytest.mark.timeout(300)
+def test_sharded_msm_world2_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(results) == 3
+    for got, exp in results:
+        assert got == exp
