@@ -19,3 +19,9 @@ clean:
 	rm -f $(LIB)
 
 .PHONY: all clean
+
+# CPU build of the field / GLV templates for tests/test_host_field.py (no GPU needed)
+HOSTTEST := tests/csrc/libfield_host.so
+hosttest: $(HOSTTEST)
+$(HOSTTEST): tests/csrc/field_host.hip $(CSRC)/field.h $(CSRC)/glv.h $(CSRC)/constants_gen.h
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -I$(CSRC) tests/csrc/field_host.hip -o $(HOSTTEST)

@@ -14,7 +14,9 @@
 
 namespace msm {
 
-#define MSM_DEV __device__ __forceinline__
+#ifndef MSM_DEV
+#define MSM_DEV __host__ __device__ __forceinline__
+#endif
 
 // r[0..NA+NB) = a * b
 template <int NA, int NB>

@@ -55,7 +55,7 @@ struct msm_ctx {
   uint64_t n_points = 0;
 
   // workspace
-  DevBuf scal, dig, counts, cursor, tail_off, info, slots, bufA, bufB, scratch, columns, partials, errflag, misc;
+  DevBuf scal, dig, counts, cursor, tail_off, info, slots, block_hist, bufA, bufB, scratch, columns, partials, errflag, misc;
   uint32_t* h_info = nullptr;      // pinned
   uint32_t* h_partials = nullptr;  // pinned, up to 64 windows x 36 words
   uint64_t ws_budget = 0;          // bytes the tree buffers of one window group may take
@@ -101,11 +101,20 @@ int fail_hip(msm_ctx* ctx, const HipFail& f) {
 // threads and copies points; here the trade is 2N*K pair additions against K*2^(c-1) buckets to
 // reduce, with histogram/scatter counters that must stay cache friendly).
 int pick_window(uint64_t n) {
-  uint32_t lg = ceil_log2_u64(std::max<uint64_t>(n, 1));
-  int c = (int)lg - 6;
-  if (lg >= 22) c = 16;
-  c = std::max(4, std::min(16, c));
-  return c;
+  // candidates whose top window is not degenerate (127 - c (K - 1) bits left for the last digit):
+  //   c = 16 (K = 8, 15 bits), 13 (K = 10, 10 bits), 10 (K = 13, 7 bits), 8 (K = 16, 7 bits), 5, 4.
+  // cost model in field multiplications: ~8 per pair addition, ~64 per bucket (two projective additions on
+  // poorly filled lanes).  c <= 16 keeps one window's counters inside the 160 KB LDS for the sort.
+  static const int cand[] = {4, 5, 8, 10, 13, 16};
+  const int b = GlvBls377::MAX_BITS;
+  int best = 4;
+  double best_cost = 1e300;
+  for (int c : cand) {
+    int K = (b + 1 + c - 1) / c;
+    double cost = 2.0 * (double)n * K * 8.0 + (double)K * (double)(1u << (c - 1)) * 64.0;
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
 }
 
 struct Plan {
@@ -170,14 +179,32 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
   ctx->ensure(ctx->tail_off, (size_t)34 * (nb + 1) * 4);
   ctx->ensure(ctx->info, 64 * 4);
 
+  // sort path: LDS-privatised histogram/ranking when one window's counters fit the LDS
+  const bool lds_sort = (size_t)L * 4 <= 128 * 1024;
+  uint32_t sortB = 1;
+  uint64_t chunk = two_n;
+  if (lds_sort) {
+    uint64_t want = std::max<uint64_t>(1, (2ull * ctx->n_cu + kc - 1) / kc);
+    uint64_t maxb = std::max<uint64_t>(1, two_n / 8192);
+    sortB = (uint32_t)std::min<uint64_t>(want, maxb);
+    chunk = (two_n + sortB - 1) / sortB;
+    ctx->ensure(ctx->block_hist, (size_t)kc * sortB * L * 4);
+  }
+
   HIPCHK(hipEventRecord(ctx->ev[0], s));
-  HIPCHK(hipMemsetAsync(ctx->counts.p, 0, nb * 4, s));
+  if (!lds_sort) HIPCHK(hipMemsetAsync(ctx->counts.p, 0, nb * 4, s));
   {
     uint32_t grid = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)ctx->dig.p, (uint32_t*)ctx->counts.p, d_scalars,
-                       (uint32_t)n, pl.c, pl.K, k_lo, kc);
+    hipLaunchKernelGGL(k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)ctx->dig.p,
+                       lds_sort ? (uint32_t*)nullptr : (uint32_t*)ctx->counts.p, d_scalars, (uint32_t)n, pl.c, pl.K, k_lo, kc);
   }
   HIPCHK(hipEventRecord(ctx->ev[1], s));
+  if (lds_sort) {
+    hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)ctx->block_hist.p,
+                       (const uint32_t*)ctx->dig.p, two_n, chunk, L);
+    hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)ctx->block_hist.p,
+                       (uint32_t*)ctx->counts.p, sortB, L, (uint32_t)kc);
+  }
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, (const uint32_t*)ctx->counts.p, (uint32_t)nb, logG,
                      (uint32_t*)ctx->cursor.p, (uint32_t*)ctx->tail_off.p, (uint32_t*)ctx->info.p);
   HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->info.p, 64 * 4, hipMemcpyDeviceToHost, s));
@@ -190,7 +217,11 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
   // scatter
   ctx->ensure(ctx->slots, std::max<uint64_t>(total_slots, 2) * 4);
   HIPCHK(hipMemsetAsync(ctx->slots.p, 0xFF, std::max<uint64_t>(total_slots, 2) * 4, s));
-  {
+  if (lds_sort) {
+    hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)ctx->slots.p,
+                       (const uint32_t*)ctx->cursor.p, (const uint32_t*)ctx->block_hist.p, (const uint32_t*)ctx->dig.p, two_n,
+                       chunk, L);
+  } else {
     uint64_t grid = (n_entries + 255) / 256;
     hipLaunchKernelGGL(k_scatter, dim3((uint32_t)grid), dim3(256), 0, s, (uint32_t*)ctx->slots.p, (uint32_t*)ctx->cursor.p,
                        (const uint32_t*)ctx->dig.p, two_n, n_entries, L);
@@ -436,6 +467,8 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     // leave room for the resident points (144 B/point at 2^26 = 9.7 GB) and fragmentation
     ctx->ws_budget = (uint64_t)(free_b * 0.55);
     ctx->ensure(ctx->errflag, 16);
+    HIPCHK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   } catch (const HipFail& f) {
     fprintf(stderr, "msm_ctx_create: HIP error %s at line %d\n", hipGetErrorString(f.e), f.line);
     delete ctx;
@@ -451,7 +484,7 @@ void msm_ctx_destroy(msm_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
-  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->dig, &ctx->counts, &ctx->cursor, &ctx->tail_off, &ctx->info, &ctx->slots,
+  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->dig, &ctx->counts, &ctx->cursor, &ctx->tail_off, &ctx->info, &ctx->slots, &ctx->block_hist,
                     &ctx->bufA, &ctx->bufB, &ctx->scratch, &ctx->columns, &ctx->partials, &ctx->errflag, &ctx->misc})
     ctx->release(*b);
   if (ctx->h_info) hipHostFree(ctx->h_info);

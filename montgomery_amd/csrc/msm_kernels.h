@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts,
       if (kk >= 0 && kk < k_cnt) {
         uint32_t neg = carry ^ (h[hh].neg ? 1u : 0u);
         dig[(uint64_t)kk * two_n + 2ull * i + hh] = l | (neg << 31);
-        if (l) atomicAdd(&counts[(uint64_t)kk * L + (l - 1)], 1u);
+        if (counts && l) atomicAdd(&counts[(uint64_t)kk * L + (l - 1)], 1u);  // only on the global-atomic sort path
       }
     }
   }
@@ -305,6 +305,72 @@ __global__ void __launch_bounds__(256) k_scatter(uint32_t* slots, uint32_t* curs
   uint32_t j = (uint32_t)(id - kk * two_n);
   uint32_t pos = atomicAdd(&cursor[kk * L + (l - 1)], 1u);
   slots[pos] = (j << 1) | (d >> 31);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-privatised counting sort (used whenever one window's L counters fit the 160 KB LDS, c <= 16).
+//   k_hist      : grid (B, Kg); block (b, kk) histograms its slice of window kk's digits in LDS and
+//                 writes the L counters to block_hist[kk][b][.] with plain coalesced stores
+//   k_colscan   : per bucket, exclusive prefix over the B blocks (in place) and the bucket total
+//   k_scatter_lds: block (b, kk) loads its L start positions (bucket slot offset + block prefix) into
+//                 LDS and ranks its entries with returning LDS atomics
+// The only global atomics left are none at all; the reference's Atomics.add histogram
+// (src/msm-batched-affine.ts:197) becomes ds_add_u32 on a CU-private copy.
+// ---------------------------------------------------------------------------------------------
+
+constexpr int SORT_THREADS = 1024;
+
+__global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, const uint32_t* dig, uint64_t two_n,
+                                                       uint64_t chunk, uint32_t L) {
+  extern __shared__ uint32_t lds_hist[];
+  const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
+  for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) lds_hist[l] = 0;
+  __syncthreads();
+  const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
+  const uint32_t* d = dig + (uint64_t)kk * two_n;
+  for (uint64_t j = beg + threadIdx.x; j < end; j += SORT_THREADS) {
+    uint32_t l = d[j] & 0x7FFFFFFFu;
+    if (l) atomicAdd(&lds_hist[l - 1], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = block_hist + ((uint64_t)kk * B + b) * L;
+  for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) out[l] = lds_hist[l];
+}
+
+__global__ void __launch_bounds__(256) k_colscan(uint32_t* block_hist, uint32_t* counts, uint32_t B, uint32_t L,
+                                                 uint32_t k_cnt) {
+  uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (uint64_t)k_cnt * L) return;
+  uint32_t kk = (uint32_t)(id / L), l = (uint32_t)(id - (uint64_t)kk * L);
+  uint32_t* p = block_hist + (uint64_t)kk * B * L + l;
+  uint32_t run = 0;
+  for (uint32_t b = 0; b < B; b++) {
+    uint32_t v = p[(uint64_t)b * L];
+    p[(uint64_t)b * L] = run;
+    run += v;
+  }
+  counts[id] = run;
+}
+
+__global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(uint32_t* slots, const uint32_t* cursor,
+                                                              const uint32_t* block_hist, const uint32_t* dig,
+                                                              uint64_t two_n, uint64_t chunk, uint32_t L) {
+  extern __shared__ uint32_t lds_pos[];
+  const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
+  const uint32_t* base = block_hist + ((uint64_t)kk * B + b) * L;
+  const uint32_t* cur = cursor + (uint64_t)kk * L;
+  for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) lds_pos[l] = cur[l] + base[l];
+  __syncthreads();
+  const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
+  const uint32_t* d = dig + (uint64_t)kk * two_n;
+  for (uint64_t j = beg + threadIdx.x; j < end; j += SORT_THREADS) {
+    uint32_t v = d[j];
+    uint32_t l = v & 0x7FFFFFFFu;
+    if (l) {
+      uint32_t pos = atomicAdd(&lds_pos[l - 1], 1u);
+      slots[pos] = ((uint32_t)j << 1) | (v >> 31);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

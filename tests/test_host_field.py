@@ -1,0 +1,78 @@
+"""The product's field / GLV templates (montgomery_amd/csrc/field.h, glv.h) compiled for the CPU and
+checked against Python integers and the oracle -- host logic, no GPU needed."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+from oracle import msm_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tests", "csrc", "libfield_host.so")
+
+FIELDS = {
+    0: (O.BLS12_377.p, 12, 13),   # modulus, packed words, 30-bit limbs
+    1: (O.ED_ON_BLS12_377.p, 8, 9),
+}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    subprocess.check_call(["make", "-C", ROOT, "-s", "hosttest"])
+    lib = C.CDLL(LIB)
+    lib.host_fp_op.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.host_glv.argtypes = [C.c_void_p, C.c_void_p]
+    return lib
+
+
+def fp_op(lib, field, which, a, b=0):
+    _, nw, _ = FIELDS[field]
+    A = (C.c_uint32 * nw)(*[(a >> (32 * i)) & 0xFFFFFFFF for i in range(nw)])
+    B = (C.c_uint32 * nw)(*[(b >> (32 * i)) & 0xFFFFFFFF for i in range(nw)])
+    out = (C.c_uint32 * nw)()
+    lib.host_fp_op(field, which, A, B, out)
+    return sum(int(w) << (32 * i) for i, w in enumerate(out))
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_mul_sqr_add_sub(lib, field):
+    p, _, nl = FIELDS[field]
+    R = 1 << (30 * nl)
+    rinv = pow(R, -1, p)
+    vals = [0, 1, 2, p - 1, p - 2, (p + 1) // 2, (1 << 30) - 1, 1 << 30] + O.prng_ints(f"host/fp{field}", 300, p)
+    for i, a in enumerate(vals):
+        b = vals[-1 - i]
+        assert fp_op(lib, field, 0, a, b) == a * b * rinv % p
+        assert fp_op(lib, field, 1, a) == a * a * rinv % p
+        assert fp_op(lib, field, 2, a, b) == (a + b) % p
+        assert fp_op(lib, field, 3, a, b) == (a - b) % p
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_inverse_divsteps_and_fermat(lib, field):
+    """fe_inv (division steps) == fe_inv_fermat == a^-1 R^2 for Montgomery-form input a R."""
+    p, _, nl = FIELDS[field]
+    R = 1 << (30 * nl)
+    vals = [1, 2, p - 1, p - 2, (p + 1) // 2, 3, 1 << 200, (1 << 252) - 1] + O.prng_ints(f"host/inv{field}", 400, p)
+    for a in vals:
+        a %= p
+        if a == 0:
+            continue
+        exp = pow(a, -1, p) * R * R % p
+        assert fp_op(lib, field, 4, a) == exp, hex(a)
+    for a in vals[:40]:
+        assert fp_op(lib, field, 5, a % p) == pow(a % p, -1, p) * R * R % p
+    assert fp_op(lib, field, 4, 0) == 0
+
+
+def test_glv_decompose_host_build(lib):
+    Cc = O.BLS12_377
+    g = O.glv_params(Cc.q, Cc.lam)
+    for s in O.prng_ints("host/glv", 3000, Cc.q) + [0, 1, Cc.q - 1, Cc.lam, Cc.lam + 1]:
+        S = (C.c_uint32 * 8)(*[(s >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+        out = (C.c_uint32 * 10)()
+        lib.host_glv(S, out)
+        a0 = sum(int(out[i]) << (32 * i) for i in range(4))
+        a1 = sum(int(out[4 + i]) << (32 * i) for i in range(4))
+        assert (a0, a1, bool(out[8]), bool(out[9])) == O.glv_decompose(s, g)
