@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
+# MSM_HIP_LIB: A/B experiments with alternative builds of the same extension (tools/ab_time.py)
+LIB_PATH = os.environ.get("MSM_HIP_LIB") or os.path.join(_HERE, "libmsm_hip.so")
 
 MSM_OK, MSM_ERR_ARG, MSM_ERR_HIP, MSM_ERR_POINT, MSM_ERR_NO_POINTS, MSM_ERR_NO_DEVICE = range(6)
 CURVE_BLS12_377_G1 = 0

@@ -37,6 +37,15 @@ struct Fe {
 
 // ---------------------------------------------------------------- pack / unpack
 
+// low 32 bits of (hi:lo) >> sh, 0 < sh < 32 (v_alignbit_b32 on the device)
+MSM_DEV uint32_t fe_funnel_r(uint32_t lo, uint32_t hi, int sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+#endif
+}
+
 // words (32-bit packed, little endian) -> 30-bit limbs
 template <class C>
 MSM_DEV void fe_unpack(Fe<C>& r, const uint32_t (&w)[C::NW]) {
@@ -46,7 +55,7 @@ MSM_DEV void fe_unpack(Fe<C>& r, const uint32_t (&w)[C::NW]) {
     const int wi = bit / 32, sh = bit % 32;
     uint32_t lo = wi < C::NW ? w[wi] : 0u;
     uint32_t hi = (wi + 1) < C::NW ? w[wi + 1] : 0u;
-    uint32_t v = sh == 0 ? lo : (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);  // v_alignbit_b32
+    uint32_t v = sh == 0 ? lo : fe_funnel_r(lo, hi, sh);
     r.l[i] = v & LMASK;
   }
 }

@@ -658,7 +658,7 @@ int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy
       if (row[11] == INF_WORD) continue;
       for (int j = 0; j < 2; j++) {
         msm_host::Fe6 t;
-        words_to_fe6(t, row + 12 * j);
+        words_to_fe6(t, row + ROW_Y * j);
         ctx->hc.F.mul(t, t, ctx->k_dev_to_host);  // host Montgomery
         ctx->hc.F.mul(t, t, one);                 // plain
         fe6_to_bytes(out_xy + i * 96 + 48 * j, t);

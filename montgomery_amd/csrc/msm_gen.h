@@ -88,17 +88,12 @@ __global__ void __launch_bounds__(256) k_gen_points(uint32_t* rows_out, const ui
     const uint32_t* row = tables + ((uint64_t)j * TBL + t) * ROW_WORDS;
     Proj<F> Q;
     fe_load<F>(Q.X, row);
-    fe_load<F>(Q.Y, row + 12);
+    fe_load<F>(Q.Y, row + ROW_Y);
     proj_add_mixed<F>(acc, acc, Q, false);
   }
   uint32_t* out = rows_out + i * ROW_WORDS;
   if (proj_is_zero<F>(acc)) {
-    uint4* r4 = reinterpret_cast<uint4*>(out);
-    for (int q = 0; q < 3; q++) {
-      r4[q] = make_uint4(INF_WORD, INF_WORD, INF_WORD, INF_WORD);
-      r4[3 + q] = make_uint4(0, 0, 0, 0);
-      r4[6 + q] = make_uint4(INF_WORD, INF_WORD, INF_WORD, INF_WORD);
-    }
+    store_row_identity(out);
     return;
   }
   Fe<F> zi, x, y, bx, beta;
@@ -111,9 +106,7 @@ __global__ void __launch_bounds__(256) k_gen_points(uint32_t* rows_out, const ui
   for (int l = 0; l < NL; l++) beta.l[l] = F::BETAL[l];
   fe_mul<F>(bx, x, beta);
   fe_reduce_2p<F>(bx);
-  fe_store<F>(out, x);
-  fe_store<F>(out + 12, y);
-  fe_store<F>(out + 24, bx);
+  store_row(out, x, y, bx);
 }
 
 struct U256 {

@@ -11,8 +11,10 @@
 // The Horner combination of the K partition sums (:322-333) runs on the host (msm_api.hip).
 //
 // Data layout in HBM
-//   point rows     : N x 36 words  [x | y | beta*x], canonical Montgomery (R = 2^390), 16-B aligned;
-//                    a gather touches one contiguous 96-byte window of the row (x,y or y,beta*x).
+//   point rows     : N x 64 words (256 B): two 128-byte lines [x | y | pad] and [beta*x | y | pad], canonical
+//                    Montgomery (R = 2^390).  A gather of either GLV half touches exactly one 128-byte
+//                    line (x alone = its first 64-byte sector): random 64-byte sectors are what bounds
+//                    round 1, so no window may straddle sectors it does not need.
 //   digits         : Kg x 2N words, magnitude | sign << 31, entry j = 2*point + half
 //   slots          : bucket-sorted entry payloads ((j << 1) | neg), every bucket padded with
 //                    SLOT_EMPTY to a multiple of G = 2^g so that g tree rounds need no index math
@@ -29,7 +31,9 @@ namespace msm {
 using F = Fp377;
 constexpr int NL = F::NL;
 constexpr int NW = F::NW;
-constexpr int ROW_WORDS = 36;
+constexpr int ROW_WORDS = 64;   // 256 B per point
+constexpr int ROW_HALF = 32;    // word offset of the endomorphism image (second 128-byte line)
+constexpr int ROW_Y = 12;       // word offset of y inside a line
 constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t INF_WORD = 0xFFFFFFFFu;
 
@@ -79,6 +83,25 @@ MSM_DEV bool fe_equal(const Fe<F>& a, const Fe<F>& b) {
   return o == 0;
 }
 
+MSM_DEV void store_row(uint32_t* row, const Fe<F>& x, const Fe<F>& y, const Fe<F>& bx) {
+  fe_store<F>(row, x);
+  fe_store<F>(row + ROW_Y, y);
+  fe_store<F>(row + ROW_HALF, bx);
+  fe_store<F>(row + ROW_HALF + ROW_Y, y);
+}
+
+MSM_DEV void store_row_identity(uint32_t* row) {
+  uint4* r4 = reinterpret_cast<uint4*>(row);
+  const uint4 ones = make_uint4(INF_WORD, INF_WORD, INF_WORD, INF_WORD), zeros = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      r4[h * (ROW_HALF / 4) + j] = ones;
+      r4[h * (ROW_HALF / 4) + 3 + j] = zeros;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_points_from_wire: N x (x || y), 48-byte little-endian canonical integers -> point rows
 // ---------------------------------------------------------------------------------------------
@@ -95,16 +118,7 @@ __global__ void __launch_bounds__(256) k_points_from_wire(uint32_t* rows, const 
 #pragma unroll
   for (int j = 0; j < NW; j++) any |= xw[j] | yw[j];
   if (any == 0) {  // (0, 0) is not on y^2 = x^3 + 1: used as the wire encoding of the identity
-    uint32_t ones[NW], zeros[NW];
-#pragma unroll
-    for (int j = 0; j < NW; j++) { ones[j] = INF_WORD; zeros[j] = 0; }
-    uint4* r4 = reinterpret_cast<uint4*>(row);
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      r4[j] = make_uint4(ones[0], ones[0], ones[0], ones[0]);
-      r4[3 + j] = make_uint4(0, 0, 0, 0);
-      r4[6 + j] = make_uint4(ones[0], ones[0], ones[0], ones[0]);
-    }
+    store_row_identity(row);
     return;
   }
   if (words_ge_p(xw) || words_ge_p(yw)) atomicOr(err, 1u);
@@ -131,9 +145,7 @@ __global__ void __launch_bounds__(256) k_points_from_wire(uint32_t* rows, const 
     fe_cond_sub<F, 4>(lhs);
     if (!fe_is_zero_mod_p<F>(lhs)) atomicOr(err, 2u);
   }
-  fe_store<F>(row, x);
-  fe_store<F>(row + 12, y);
-  fe_store<F>(row + 24, bx);
+  store_row(row, x, y, bx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -397,22 +409,28 @@ struct BatchArgs {
   uint32_t nb;
 };
 
+// One operand of a pair: where it lives and how to read it.
 struct Side {
-  uint64_t idx;      // element index (planes) or row base word offset (gather)
-  uint32_t xoff;     // gather: word offset of x inside the row (0 or 24)
+  uint64_t idx;      // element index (planes) or word offset of the point row (gather); always a valid address
+  uint32_t xoff;     // gather: word offset of the 128-byte line inside the row (0 or ROW_HALF)
   bool neg;          // gather: negate y
   bool absent;       // no such element: identity
 };
 
 template <int MODE>
+MSM_DEV void sides_from_payload(uint2 pp, Side& A, Side& B) {
+  A.absent = pp.x == SLOT_EMPTY;
+  B.absent = pp.y == SLOT_EMPTY;
+  // absent operands read row 0 (valid memory) and are then ignored: no divergent loads
+  A.idx = A.absent ? 0 : (uint64_t)(pp.x >> 2) * ROW_WORDS; A.xoff = (!A.absent && (pp.x & 2u)) ? (uint32_t)ROW_HALF : 0u; A.neg = pp.x & 1u;
+  B.idx = B.absent ? 0 : (uint64_t)(pp.y >> 2) * ROW_WORDS; B.xoff = (!B.absent && (pp.y & 2u)) ? (uint32_t)ROW_HALF : 0u; B.neg = pp.y & 1u;
+}
+
+template <int MODE>
 MSM_DEV void locate(const BatchArgs& a, uint64_t e, Side& A, Side& B) {
   A.xoff = B.xoff = 0; A.neg = B.neg = false; A.absent = B.absent = false;
   if (MODE == MODE_GATHER) {
-    uint2 pp = reinterpret_cast<const uint2*>(a.slots)[e];
-    A.absent = pp.x == SLOT_EMPTY;
-    B.absent = pp.y == SLOT_EMPTY;
-    A.idx = (uint64_t)(pp.x >> 2) * ROW_WORDS; A.xoff = (pp.x & 2u) ? 24u : 0u; A.neg = pp.x & 1u;
-    B.idx = (uint64_t)(pp.y >> 2) * ROW_WORDS; B.xoff = (pp.y & 2u) ? 24u : 0u; B.neg = pp.y & 1u;
+    sides_from_payload<MODE>(reinterpret_cast<const uint2*>(a.slots)[e], A, B);
   } else if (MODE == MODE_REGULAR) {
     A.idx = 2 * e; B.idx = 2 * e + 1;
   } else {
@@ -427,25 +445,25 @@ MSM_DEV void locate(const BatchArgs& a, uint64_t e, Side& A, Side& B) {
     A.idx = (uint64_t)ibeg + 2ull * j;
     B.idx = A.idx + 1;
     B.absent = B.idx >= iend;
+    if (B.absent) B.idx = A.idx;
   }
 }
 
-// returns true if the element is the identity
+// raw (packed) coordinate loads; the unpack happens where the value is consumed so that the loads
+// of the NEXT pair can be in flight while the current one is being computed
 template <int MODE>
-MSM_DEV bool load_x(const BatchArgs& a, const Side& s, Fe<F>& x) {
-  if (s.absent) return true;
-  uint32_t w[NW];
+MSM_DEV void load_x_raw(const BatchArgs& a, const Side& s, uint32_t (&w)[NW]) {
   if (MODE == MODE_GATHER) load_words12(w, a.points + s.idx + s.xoff);
   else load_planes3(w, a.in, a.in_cap, 0, s.idx);
-  fe_unpack<F>(x, w);
-  return w[NW - 1] == INF_WORD;
+}
+template <int MODE>
+MSM_DEV void load_y_raw(const BatchArgs& a, const Side& s, uint32_t (&w)[NW]) {
+  if (MODE == MODE_GATHER) load_words12(w, a.points + s.idx + s.xoff + ROW_Y);
+  else load_planes3(w, a.in, a.in_cap, 3, s.idx);
 }
 
 template <int MODE>
-MSM_DEV void load_y(const BatchArgs& a, const Side& s, Fe<F>& y) {
-  uint32_t w[NW];
-  if (MODE == MODE_GATHER) load_words12(w, a.points + s.idx + 12);
-  else load_planes3(w, a.in, a.in_cap, 3, s.idx);
+MSM_DEV void finish_y(const Side& s, const uint32_t (&w)[NW], Fe<F>& y) {
   fe_unpack<F>(y, w);
   if (MODE == MODE_GATHER && s.neg && !fe_is_zero_canonical<F>(y)) {
     Fe<F> z;
@@ -455,28 +473,6 @@ MSM_DEV void load_y(const BatchArgs& a, const Side& s, Fe<F>& y) {
 }
 
 enum : int { KIND_ADD = 0, KIND_DOUBLE = 1, KIND_COPY_A = 2, KIND_COPY_B = 3, KIND_ZERO = 4 };
-
-// classification + denominator shared by the forward and the backward sweep
-template <int MODE>
-MSM_DEV int classify(const BatchArgs& a, const Side& A, const Side& B, const Fe<F>& x1, bool inf1, const Fe<F>& x2,
-                     bool inf2, Fe<F>& den, Fe<F>& y1, Fe<F>& y2, bool& have_y) {
-  have_y = false;
-  fe_set_one<F>(den);
-  if (inf2) return KIND_COPY_A;
-  if (inf1) return KIND_COPY_B;
-  if (fe_equal(x1, x2)) {
-    load_y<MODE>(a, A, y1);
-    load_y<MODE>(a, B, y2);
-    have_y = true;
-    if (fe_equal(y1, y2) && !fe_is_zero_canonical<F>(y1)) {
-      fe_add<F>(den, y1, y1);
-      return KIND_DOUBLE;
-    }
-    return KIND_ZERO;
-  }
-  fe_sub_p<F>(den, x2, x1);
-  return KIND_ADD;
-}
 
 MSM_DEV void store_point(uint4* out, uint64_t cap, uint64_t e, const Fe<F>& x, const Fe<F>& y) {
   uint32_t w[NW];
@@ -496,88 +492,159 @@ MSM_DEV void store_identity(uint4* out, uint64_t cap, uint64_t e) {
   store_planes3(out, cap, 3, e, w);
 }
 
+// what one lane needs to start working on a pair; filled one step ahead of its use
+template <int MODE>
+struct PairFetch {
+  Side A, B;
+  uint32_t ax[NW], bx[NW];
+};
+
+template <int MODE>
+MSM_DEV void copy_fetch(PairFetch<MODE>& d, const PairFetch<MODE>& s) {  // element-wise: keeps everything in VGPRs
+  d.A.idx = s.A.idx; d.A.xoff = s.A.xoff; d.A.neg = s.A.neg; d.A.absent = s.A.absent;
+  d.B.idx = s.B.idx; d.B.xoff = s.B.xoff; d.B.neg = s.B.neg; d.B.absent = s.B.absent;
+#pragma unroll
+  for (int j = 0; j < NW; j++) { d.ax[j] = s.ax[j]; d.bx[j] = s.bx[j]; }
+}
+
+template <int MODE>
+MSM_DEV void fetch_pair_x(const BatchArgs& a, uint64_t e, PairFetch<MODE>& pf) {
+  locate<MODE>(a, e, pf.A, pf.B);
+  load_x_raw<MODE>(a, pf.A, pf.ax);
+  load_x_raw<MODE>(a, pf.B, pf.bx);
+}
+
+// classification + denominator from the x coordinates (y only for the rare equal-x case)
+template <int MODE>
+MSM_DEV int classify(const BatchArgs& a, const PairFetch<MODE>& pf, Fe<F>& x1, Fe<F>& x2, bool& inf1, bool& inf2,
+                     Fe<F>& den) {
+  fe_unpack<F>(x1, pf.ax);
+  fe_unpack<F>(x2, pf.bx);
+  inf1 = pf.A.absent || pf.ax[NW - 1] == INF_WORD;
+  inf2 = pf.B.absent || pf.bx[NW - 1] == INF_WORD;
+  fe_set_one<F>(den);
+  if (inf2) return KIND_COPY_A;
+  if (inf1) return KIND_COPY_B;
+  if (fe_equal(x1, x2)) {
+    uint32_t w[NW];
+    Fe<F> y1, y2;
+    load_y_raw<MODE>(a, pf.A, w);
+    finish_y<MODE>(pf.A, w, y1);
+    load_y_raw<MODE>(a, pf.B, w);
+    finish_y<MODE>(pf.B, w, y2);
+    if (fe_equal(y1, y2) && !fe_is_zero_canonical<F>(y1)) {
+      fe_add<F>(den, y1, y1);
+      return KIND_DOUBLE;
+    }
+    return KIND_ZERO;
+  }
+  fe_sub_p<F>(den, x2, x1);
+  return KIND_ADD;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
   const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.n_out) return;   // whole lane idle (steps * T >= n_out, lane t owns e = t, t + T, ...)
+  // number of pairs this lane owns
+  const uint32_t my_steps = (uint32_t)min((uint64_t)a.steps, (a.n_out - t + T - 1) / T);
+
   Fe<F> acc;
   fe_set_one<F>(acc);
 
-  // forward sweep: prefix products of the denominators
+  // ---- forward sweep: prefix products of the denominators -------------------------------------
+  {
+    PairFetch<MODE> nxt;
+    fetch_pair_x<MODE>(a, t, nxt);
 #pragma unroll 1
-  for (uint32_t i = 0; i < a.steps; i++) {
-    uint64_t e = (uint64_t)i * T + t;
-    if (e >= a.n_out) break;
-    Side A, B;
-    locate<MODE>(a, e, A, B);
-    Fe<F> x1, x2, y1, y2, den;
-    bool inf1 = load_x<MODE>(a, A, x1);
-    bool inf2 = load_x<MODE>(a, B, x2);
-    bool have_y;
-    classify<MODE>(a, A, B, x1, inf1, x2, inf2, den, y1, y2, have_y);
-    uint32_t* sp = a.scratch + ((uint64_t)i * NL) * T + t;
+    for (uint32_t i = 0; i < my_steps; i++) {
+      PairFetch<MODE> cur;
+      copy_fetch<MODE>(cur, nxt);
+      if (i + 1 < my_steps) fetch_pair_x<MODE>(a, (uint64_t)(i + 1) * T + t, nxt);   // in flight during the multiply
+      Fe<F> x1, x2, den;
+      bool inf1, inf2;
+      classify<MODE>(a, cur, x1, x2, inf1, inf2, den);
+      uint32_t* sp = a.scratch + ((uint64_t)i * NL) * T + t;
 #pragma unroll
-    for (int l = 0; l < NL; l++) sp[(uint64_t)l * T] = acc.l[l];
-    fe_mul<F>(acc, acc, den);
+      for (int l = 0; l < NL; l++) sp[(uint64_t)l * T] = acc.l[l];
+      fe_mul<F>(acc, acc, den);
+    }
   }
 
   Fe<F> inv;
   fe_inv<F>(inv, acc);
 
-  // backward sweep
-#pragma unroll 1
-  for (int i = (int)a.steps - 1; i >= 0; i--) {
-    uint64_t e = (uint64_t)i * T + t;
-    if (e >= a.n_out) continue;
-    Side A, B;
-    locate<MODE>(a, e, A, B);
-    Fe<F> x1, x2, y1, y2, den, pre, d;
-    bool inf1 = load_x<MODE>(a, A, x1);
-    bool inf2 = load_x<MODE>(a, B, x2);
-    bool have_y;
-    int kind = classify<MODE>(a, A, B, x1, inf1, x2, inf2, den, y1, y2, have_y);
-    const uint32_t* sp = a.scratch + ((uint64_t)i * NL) * T + t;
+  // ---- backward sweep ------------------------------------------------------------------------
+  {
+    PairFetch<MODE> nxt;
+    uint32_t npre[NL];
+    {
+      const uint32_t i = my_steps - 1;
+      fetch_pair_x<MODE>(a, (uint64_t)i * T + t, nxt);
+      const uint32_t* sp = a.scratch + ((uint64_t)i * NL) * T + t;
 #pragma unroll
-    for (int l = 0; l < NL; l++) pre.l[l] = sp[(uint64_t)l * T];
-    fe_mul<F>(d, inv, pre);     // 1 / den_i
-    fe_mul<F>(inv, inv, den);   // strip den_i from the running inverse
+      for (int l = 0; l < NL; l++) npre[l] = sp[(uint64_t)l * T];
+    }
+#pragma unroll 1
+    for (int i = (int)my_steps - 1; i >= 0; i--) {
+      const uint64_t e = (uint64_t)i * T + t;
+      PairFetch<MODE> cur;
+      copy_fetch<MODE>(cur, nxt);
+      Fe<F> pre;
+#pragma unroll
+      for (int l = 0; l < NL; l++) pre.l[l] = npre[l];
+      // this pair's y coordinates: issued now, consumed after two multiplications
+      uint32_t ay[NW], by[NW];
+      load_y_raw<MODE>(a, cur.A, ay);
+      load_y_raw<MODE>(a, cur.B, by);
+      // next pair's x coordinates and prefix product: in flight during this pair's arithmetic
+      if (i > 0) {
+        fetch_pair_x<MODE>(a, (uint64_t)(i - 1) * T + t, nxt);
+        const uint32_t* sp = a.scratch + ((uint64_t)(i - 1) * NL) * T + t;
+#pragma unroll
+        for (int l = 0; l < NL; l++) npre[l] = sp[(uint64_t)l * T];
+      }
+      Fe<F> x1, x2, den, d;
+      bool inf1, inf2;
+      int kind = classify<MODE>(a, cur, x1, x2, inf1, inf2, den);
+      fe_mul<F>(d, inv, pre);     // 1 / den_i
+      fe_mul<F>(inv, inv, den);   // strip den_i from the running inverse
 
-    if (kind == KIND_ZERO || (kind == KIND_COPY_A && inf1)) {
-      store_identity(a.out, a.out_cap, e);
-      continue;
+      Fe<F> y1, y2;
+      finish_y<MODE>(cur.A, ay, y1);
+      finish_y<MODE>(cur.B, by, y2);
+      if (kind == KIND_ZERO || (kind == KIND_COPY_A && inf1)) {
+        store_identity(a.out, a.out_cap, e);
+        continue;
+      }
+      if (kind == KIND_COPY_A) {
+        store_point(a.out, a.out_cap, e, x1, y1);
+        continue;
+      }
+      if (kind == KIND_COPY_B) {
+        store_point(a.out, a.out_cap, e, x2, y2);
+        continue;
+      }
+      Fe<F> num, m, mm, x3, y3, tt;
+      if (kind == KIND_DOUBLE) {
+        fe_sqr<F>(tt, x1);
+        fe_add<F>(num, tt, tt);
+        fe_add<F>(num, num, tt);   // 3 x^2
+      } else {
+        fe_sub_p<F>(num, y2, y1);
+      }
+      fe_mul<F>(m, num, d);
+      fe_sqr<F>(mm, m);
+      fe_sub_p<F>(x3, mm, x1);
+      fe_sub_p<F>(x3, x3, x2);
+      fe_reduce_4p<F>(x3);
+      fe_sub_p<F>(tt, x1, x3);
+      fe_mul<F>(y3, m, tt);
+      fe_sub_p<F>(y3, y3, y1);
+      fe_reduce_4p<F>(y3);
+      store_point(a.out, a.out_cap, e, x3, y3);
     }
-    if (kind == KIND_COPY_A) {
-      load_y<MODE>(a, A, y1);
-      store_point(a.out, a.out_cap, e, x1, y1);
-      continue;
-    }
-    if (kind == KIND_COPY_B) {
-      load_y<MODE>(a, B, y2);
-      store_point(a.out, a.out_cap, e, x2, y2);
-      continue;
-    }
-    if (!have_y) {
-      load_y<MODE>(a, A, y1);
-      load_y<MODE>(a, B, y2);
-    }
-    Fe<F> num, m, mm, x3, y3, tt;
-    if (kind == KIND_DOUBLE) {
-      fe_sqr<F>(tt, x1);
-      fe_add<F>(num, tt, tt);
-      fe_add<F>(num, num, tt);   // 3 x^2
-    } else {
-      fe_sub_p<F>(num, y2, y1);
-    }
-    fe_mul<F>(m, num, d);
-    fe_sqr<F>(mm, m);
-    fe_sub_p<F>(x3, mm, x1);
-    fe_sub_p<F>(x3, x3, x2);
-    fe_reduce_4p<F>(x3);
-    fe_sub_p<F>(tt, x1, x3);
-    fe_mul<F>(y3, m, tt);
-    fe_sub_p<F>(y3, y3, y1);
-    fe_reduce_4p<F>(y3);
-    store_point(a.out, a.out_cap, e, x3, y3);
   }
 }
 
