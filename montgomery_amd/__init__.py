@@ -5,9 +5,11 @@ of libmsm_hip.so.  See DESIGN.md and INTEGRATION.md.
 """
 from .api import (  # noqa: F401
     BLS12377,
+    TwistedEdwards,
     Weierstrass,
     MsmContext,
     compute_msm,
+    compute_msm_ed,
     create_weierstrass,
 )
 from ._lib import MsmError  # noqa: F401

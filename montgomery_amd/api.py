@@ -59,6 +59,31 @@ BLS12_377_PARAMS = WeierstrassParams(
 )
 
 
+@dataclass(frozen=True)
+class TwistedEdwardsParams:
+    """src/concrete/ed-on-bls12-377.params.ts:5-31"""
+
+    label: str
+    modulus: int
+    order: int
+    cofactor: int
+    d: int
+    generator: Tuple[int, int]
+
+
+ED_ON_BLS12_377_PARAMS = TwistedEdwardsParams(
+    label="ed-on-bls12-377",
+    modulus=0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001,
+    order=0x4AAD957A68B2955982D1347970DEC005293A3AFC43C8AFEB95AEE9AC33FD9FF,
+    cofactor=4,
+    d=3021,
+    generator=(
+        0x9F1B5A5BAF6ACF06FED91C9AE9EBFA06068DD2835790980894E2328F3EBCA05,
+        0x9A20DF36571AC3CD906B256080BA8454453C177AAF3131BB50A67BF1A806781,
+    ),
+)
+
+
 # ---------------------------------------------------------------------------------------------
 # low-level context
 # ---------------------------------------------------------------------------------------------
@@ -147,13 +172,15 @@ class MsmContext:
         return int(dev.value or 0), (bytes(out) if out is not None else None)
 
     def get_points(self, first: int, count: int) -> bytes:
-        out = (C.c_uint8 * max(96 * count, 1))()
+        step = 2 * self.coord_bytes
+        out = (C.c_uint8 * max(step * count, 1))()
         self._check(self._lib.msm_get_points(self._h, first, count, out))
-        return bytes(out)[: 96 * count]
+        return bytes(out)[: step * count]
 
     def get_point(self, i: int) -> Optional[Tuple[int, int]]:
         b = self.get_points(i, 1)
-        x, y = int.from_bytes(b[:48], "little"), int.from_bytes(b[48:], "little")
+        nb = self.coord_bytes
+        x, y = int.from_bytes(b[:nb], "little"), int.from_bytes(b[nb:], "little")
         return None if (x == 0 and y == 0) else (x, y)
 
     # -- msm ------------------------------------------------------------------------------
@@ -262,9 +289,9 @@ class ScalarPtr:
 
 
 class _Parallel:
-    """`Curve.Parallel` (src/parallel.ts:135-145)."""
+    """`Curve.Parallel` (src/parallel.ts:135-145 Weierstrass, :251-259 twisted Edwards)."""
 
-    def __init__(self, ctx: MsmContext, params: WeierstrassParams):
+    def __init__(self, ctx: MsmContext, params):
         self._ctx = ctx
         self._params = params
 
@@ -275,8 +302,8 @@ class _Parallel:
         return ScalarPtr(size=size)
 
     def pointsFromBytes(self, pointPtr: PointPtr, pointInput: BytesLike, n: int) -> None:
-        """src/parallel.ts:97-116: n points of 96 bytes (x || y little-endian) -> resident device points."""
-        self._ctx.set_points(bytes(pointInput)[: 96 * n])
+        """src/parallel.ts:97-116 (96 B/point) / :215-229 (64 B/point): x || y little-endian -> resident device points."""
+        self._ctx.set_points(bytes(pointInput)[: 2 * self._ctx.coord_bytes * n])
         pointPtr.n = n
 
     def scalarsFromBytes(self, scalarPtr: ScalarPtr, scalarInput: BytesLike, n: int) -> None:
@@ -341,6 +368,22 @@ def create_weierstrass(params: WeierstrassParams = BLS12_377_PARAMS, device: int
     return Weierstrass.create(params, device)
 
 
+class TwistedEdwards:
+    """Curve module as `TwistedEdwards.create(params)` returns it (src/parallel.ts:179-289), MSM path only:
+    `Parallel.msm` is `msmBasic` (src/msm-basic.ts:45-164) on extended points."""
+
+    def __init__(self, params: TwistedEdwardsParams, device: int = 0):
+        if params.label != "ed-on-bls12-377":
+            raise MsmError(_lib.MSM_ERR_ARG, f"curve {params.label!r} has no device constants (only ed-on-bls12-377)")
+        self.params = params
+        self.context = MsmContext(_lib.CURVE_ED_ON_BLS12_377, device)
+        self.Parallel = _Parallel(self.context, params)
+
+    @classmethod
+    def create(cls, params: TwistedEdwardsParams, device: int = 0) -> "TwistedEdwards":
+        return cls(params, device)
+
+
 class _LazyCurve:
     """`BLS12377` of src/concrete/bls12-377.ts: created on first use (needs a GPU)."""
 
@@ -358,6 +401,29 @@ class _LazyCurve:
 
 
 BLS12377 = _LazyCurve(BLS12_377_PARAMS)
+
+
+def compute_msm_ed(inputPoints, inputScalars, curve: Optional[TwistedEdwards] = None) -> Dict[str, int]:
+    """ZPrize entry point for the twisted Edwards curve, scripts/zprize23/submission.ts:19-60.
+
+    inputPoints: bytes (n x 64, x || y little-endian) or a list of {"x", "y", ...} dicts (z = 1 assumed);
+    inputScalars: bytes (n x 32) or a list of ints.  Returns {"x": int, "y": int} (the identity is (0, 1))."""
+    cv = curve or TwistedEdwards.create(ED_ON_BLS12_377_PARAMS)
+    if isinstance(inputScalars, (bytes, bytearray, memoryview)):
+        sbytes = bytes(inputScalars)
+    else:
+        sbytes = b"".join(int(s).to_bytes(32, "little") for s in inputScalars)
+    n = len(sbytes) // 32
+    if isinstance(inputPoints, (bytes, bytearray, memoryview)):
+        pbytes = bytes(inputPoints)
+    else:
+        pbytes = b"".join(int(P["x"]).to_bytes(32, "little") + int(P["y"]).to_bytes(32, "little") for P in inputPoints)
+    par = cv.Parallel
+    pp, sp = par.getPointer(len(pbytes)), par.getScalarPointer(len(sbytes))
+    par.pointsFromBytes(pp, pbytes, n)
+    par.scalarsFromBytes(sp, sbytes, n)
+    res = par.msm(sp, pp, n)["result"]
+    return {"x": res.x, "y": res.y}
 
 
 def compute_msm(inputPoints, inputScalars, curve: Optional[Weierstrass] = None) -> Dict[str, int]:

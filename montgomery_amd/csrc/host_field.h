@@ -221,4 +221,39 @@ struct Curve6 {
   }
 };
 
+// twisted Edwards a = -1 in extended coordinates over the same 6-limb field code (the 253-bit prime
+// simply has two zero top limbs): unified add-2008-hwcd-3, src/curve-twisted-edwards.ts:84-165
+struct Ext6 {
+  Fe6 X, Y, Z, T;
+};
+
+struct TeCurve6 {
+  Field6 F;
+  Fe6 k;  // 2d, Montgomery form
+
+  void init(const uint32_t* p_words12, uint64_t d) {
+    F.init(p_words12);
+    Fe6 t = {{2 * d, 0, 0, 0, 0, 0}};
+    F.mul(k, t, F.r2);
+  }
+  Ext6 zero() const {
+    Ext6 P;
+    memset(&P, 0, sizeof(P));
+    P.Y = F.one;
+    P.Z = F.one;
+    return P;
+  }
+  Ext6 add(const Ext6& P, const Ext6& Q) const {
+    Fe6 a, b, A, B, C, D, E, Fv, G, H;
+    F.sub(a, P.Y, P.X); F.sub(b, Q.Y, Q.X); F.mul(A, a, b);
+    F.add(a, P.Y, P.X); F.add(b, Q.Y, Q.X); F.mul(B, a, b);
+    F.mul(C, P.T, Q.T); F.mul(C, C, k);
+    F.mul(D, P.Z, Q.Z); F.add(D, D, D);
+    F.sub(E, B, A); F.sub(Fv, D, C); F.add(G, D, C); F.add(H, B, A);
+    Ext6 R;
+    F.mul(R.X, E, Fv); F.mul(R.Y, G, H); F.mul(R.T, E, H); F.mul(R.Z, Fv, G);
+    return R;
+  }
+};
+
 }  // namespace msm_host

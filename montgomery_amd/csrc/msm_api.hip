@@ -3,6 +3,7 @@
 // (reference src/msm-batched-affine.ts:69-340); the per-thread SPMD phases separated by
 // `barrier()` there become kernel launches on one HIP stream here.
 #include "msm_kernels.h"
+#include "te_kernels.h"
 #include "host_field.h"
 #include "../../include/msm_hip.h"
 
@@ -62,6 +63,9 @@ struct msm_ctx {
 
   msm_host::Curve6 hc;
   msm_host::Fe6 k_dev_to_host;  // 2^378: device Montgomery (2^390) -> host Montgomery (2^384)
+  msm_host::TeCurve6 hte;       // Ed-on-BLS12-377 over the 253-bit field (same 6-limb host field code)
+  msm_host::Fe6 k_te_to_host;   // 2^498: device Montgomery (2^270) -> host Montgomery (2^384)
+  bool is_te() const { return curve == MSM_CURVE_ED_ON_BLS12_377; }
 
   void ensure(DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return;
@@ -100,18 +104,22 @@ int fail_hip(msm_ctx* ctx, const HipFail& f) {
 // GPU-tuned window size (the reference's table, src/msm-common.ts:25-41, was tuned for 16 CPU
 // threads and copies points; here the trade is 2N*K pair additions against K*2^(c-1) buckets to
 // reduce, with histogram/scatter counters that must stay cache friendly).
-int pick_window(uint64_t n) {
-  // candidates whose top window is not degenerate (127 - c (K - 1) bits left for the last digit):
-  //   c = 16 (K = 8, 15 bits), 13 (K = 10, 10 bits), 10 (K = 13, 7 bits), 8 (K = 16, 7 bits), 5, 4.
-  // cost model in field multiplications: ~8 per pair addition, ~64 per bucket (two projective additions on
-  // poorly filled lanes).  c <= 16 keeps one window's counters inside the 160 KB LDS for the sort.
-  static const int cand[] = {4, 5, 8, 10, 13, 16};
-  const int b = GlvBls377::MAX_BITS;
+int pick_window(bool te, uint64_t n) {
+  // candidates whose top window is not degenerate (bits left for the last digit close to c):
+  //   Weierstrass + GLV, b + 1 = 127: c = 16 (K = 8, 15 bits), 13 (K = 10, 10 bits), 10, 8, 5, 4
+  //   twisted Edwards, b + 1 = 252:   c = 16 (K = 16, 12 bits), 14 (K = 18), 12 (K = 21), 9, 7, 6, 4 (exact)
+  // cost model in field multiplications: ~8 per pair addition (9 extended), ~64 per bucket (two projective
+  // additions on poorly filled lanes).  c <= 16 keeps one window's counters inside the 160 KB LDS for the sort.
+  static const int cand_w[] = {4, 5, 8, 10, 13, 16};
+  static const int cand_te[] = {4, 6, 7, 9, 12, 14, 16};
+  const int b1 = te ? 252 : GlvBls377::MAX_BITS + 1;
+  const double entries = te ? (double)n : 2.0 * (double)n;
   int best = 4;
   double best_cost = 1e300;
-  for (int c : cand) {
-    int K = (b + 1 + c - 1) / c;
-    double cost = 2.0 * (double)n * K * 8.0 + (double)K * (double)(1u << (c - 1)) * 64.0;
+  for (int i = 0; i < (te ? 7 : 6); i++) {
+    int c = te ? cand_te[i] : cand_w[i];
+    int K = (b1 + c - 1) / c;
+    double cost = entries * K * 8.0 + (double)K * (double)(1u << (c - 1)) * 64.0;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;
@@ -123,14 +131,15 @@ struct Plan {
 };
 
 int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
-  int c = (opts && opts->c > 0) ? opts->c : pick_window(n);
+  const bool te = ctx && ctx->is_te();
+  int c = (opts && opts->c > 0) ? opts->c : pick_window(te, n);
   if (c < 2 || c > 24) return MSM_ERR_ARG;
-  const int b = GlvBls377::MAX_BITS;
+  // b = Scalar.maxBits (126 after GLV, src/wasm/glv.ts:216-226) or Scalar.sizeInBits (251, src/msm-basic.ts:56)
+  const int b = te ? 251 : GlvBls377::MAX_BITS;
   pl.c = c;
-  pl.K = (b + 1 + c - 1) / c;  // K = ceil((b + 1) / c), src/msm-batched-affine.ts:90
+  pl.K = (b + 1 + c - 1) / c;  // K = ceil((b + 1) / c), src/msm-batched-affine.ts:90, src/msm-basic.ts:59
   pl.L_log = c - 1;
   pl.L = 1u << (c - 1);
-  (void)ctx;
   return MSM_OK;
 }
 
@@ -165,8 +174,11 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
   const int kc = k_hi - k_lo;
   const uint32_t L = pl.L;
   const uint64_t nb = (uint64_t)kc * L;
-  const uint64_t two_n = 2 * n;
+  const bool te = ctx->is_te();
+  const uint64_t two_n = te ? n : 2 * n;   // entries per window: both GLV halves, or the plain scalar
   const uint64_t n_entries = (uint64_t)kc * two_n;
+  const size_t elem_bytes = te ? 128 : 96;  // tree node: extended (X, Y, Z, T) x 32 B, or affine (x, y) x 48 B
+  const int part_words = te ? 32 : 36;
 
   // padding granule G = 2^g: about 1/16 of the mean bucket population
   uint64_t mean = std::max<uint64_t>(1, two_n / L);
@@ -195,8 +207,13 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
   if (!lds_sort) HIPCHK(hipMemsetAsync(ctx->counts.p, 0, nb * 4, s));
   {
     uint32_t grid = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)ctx->dig.p,
-                       lds_sort ? (uint32_t*)nullptr : (uint32_t*)ctx->counts.p, d_scalars, (uint32_t)n, pl.c, pl.K, k_lo, kc);
+    uint32_t* cnt = lds_sort ? (uint32_t*)nullptr : (uint32_t*)ctx->counts.p;
+    if (te)
+      hipLaunchKernelGGL(te::k_te_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)ctx->dig.p, cnt, d_scalars, (uint32_t)n, pl.c,
+                         pl.K, k_lo, kc);
+    else
+      hipLaunchKernelGGL(k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)ctx->dig.p, cnt, d_scalars, (uint32_t)n, pl.c, pl.K,
+                         k_lo, kc);
   }
   HIPCHK(hipEventRecord(ctx->ev[1], s));
   if (lds_sort) {
@@ -245,8 +262,8 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
       which ^= 1;
     }
   }
-  ctx->ensure(ctx->bufA, capA * 96);
-  ctx->ensure(ctx->bufB, capB * 96);
+  ctx->ensure(ctx->bufA, capA * elem_bytes);
+  ctx->ensure(ctx->bufB, capB * elem_bytes);
   uint4* buf[2] = {(uint4*)ctx->bufA.p, (uint4*)ctx->bufB.p};
   uint64_t cap[2] = {capA, capB};
   int cur = 0;  // buffer that receives the next round's output
@@ -259,7 +276,7 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
     for (uint32_t r = 1; r <= logG; r++) {
       uint64_t n_out = n_in / 2;
       RoundGeom g = round_geom(ctx, n_out);
-      ctx->ensure(ctx->scratch, (size_t)g.steps * NL * g.T * 4);
+      if (!te) ctx->ensure(ctx->scratch, (size_t)g.steps * NL * g.T * 4);
       BatchArgs a{};
       a.points = (const uint32_t*)ctx->rows.p;
       a.slots = (const uint32_t*)ctx->slots.p;
@@ -271,10 +288,12 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
       a.n_out = n_out;
       a.steps = g.steps;
       if (r == 1) {
-        hipLaunchKernelGGL(k_batch_add<MODE_GATHER>, dim3(g.grid), dim3(256), 0, s, a);
+        if (te) hipLaunchKernelGGL(te::k_te_add<MODE_GATHER>, dim3(g.grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_batch_add<MODE_GATHER>, dim3(g.grid), dim3(256), 0, s, a);
         HIPCHK(hipEventRecord(ctx->ev[6], s));
       } else {
-        hipLaunchKernelGGL(k_batch_add<MODE_REGULAR>, dim3(g.grid), dim3(256), 0, s, a);
+        if (te) hipLaunchKernelGGL(te::k_te_add<MODE_REGULAR>, dim3(g.grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_batch_add<MODE_REGULAR>, dim3(g.grid), dim3(256), 0, s, a);
       }
       st.n_pairs += n_out;
       fin = buf[cur];
@@ -286,7 +305,7 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
     for (int r = 1; r <= RT; r++) {
       uint64_t n_out = ctx->h_info[3 + r];
       RoundGeom g = round_geom(ctx, n_out);
-      ctx->ensure(ctx->scratch, (size_t)g.steps * NL * g.T * 4);
+      if (!te) ctx->ensure(ctx->scratch, (size_t)g.steps * NL * g.T * 4);
       BatchArgs a{};
       a.in = buf[cur ^ 1];
       a.in_cap = cap[cur ^ 1];
@@ -298,7 +317,8 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
       a.off_in = (const uint32_t*)ctx->tail_off.p + (uint64_t)(r - 1) * (nb + 1);
       a.off_out = (const uint32_t*)ctx->tail_off.p + (uint64_t)r * (nb + 1);
       a.nb = (uint32_t)nb;
-      hipLaunchKernelGGL(k_batch_add<MODE_SEARCH>, dim3(g.grid), dim3(256), 0, s, a);
+      if (te) hipLaunchKernelGGL(te::k_te_add<MODE_SEARCH>, dim3(g.grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(k_batch_add<MODE_SEARCH>, dim3(g.grid), dim3(256), 0, s, a);
       st.n_pairs += n_out;
       fin = buf[cur];
       fin_cap = cap[cur];
@@ -315,16 +335,23 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
   uint32_t TC = (uint32_t)std::max<uint64_t>(2, (nb + 65535) / 65536);
   TC = std::min<uint32_t>(TC, L);
   uint32_t nchunks = (L + TC - 1) / TC;
-  ctx->ensure(ctx->columns, (size_t)kc * nchunks * 3 * NL * 4);
+  ctx->ensure(ctx->columns, (size_t)kc * nchunks * 4 * NL * 4);
   ctx->ensure(ctx->partials, (size_t)kc * 36 * 4);
   {
     uint32_t threads = nchunks * (uint32_t)kc;
-    hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)ctx->columns.p, fin, fin_cap,
-                       off_fin, L, TC, nchunks, (uint32_t)kc);
-    hipLaunchKernelGGL(k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
-                       (const uint32_t*)ctx->columns.p, nchunks);
+    if (te) {
+      hipLaunchKernelGGL(te::k_te_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)ctx->columns.p, fin, fin_cap,
+                         off_fin, L, TC, nchunks, (uint32_t)kc);
+      hipLaunchKernelGGL(te::k_te_window_sum, dim3(kc), dim3(te::TE_WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
+                         (const uint32_t*)ctx->columns.p, nchunks);
+    } else {
+      hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)ctx->columns.p, fin, fin_cap,
+                         off_fin, L, TC, nchunks, (uint32_t)kc);
+      hipLaunchKernelGGL(k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
+                         (const uint32_t*)ctx->columns.p, nchunks);
+    }
   }
-  HIPCHK(hipMemcpyAsync(h_partials_out, ctx->partials.p, (size_t)kc * 36 * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h_partials_out, ctx->partials.p, (size_t)kc * part_words * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipEventRecord(ctx->ev[4], s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
@@ -339,7 +366,8 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
 // how many windows fit one group under the workspace budget
 int windows_per_group(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
   // per window: digits 8n, slots ~8n(+pad), bufA ~ n*96, bufB ~ n*48, scratch ~ n*52
-  long double per = (long double)n * (8 + 9 + 96 + 48 + 56) + (long double)pl.L * 4 * 40;
+  long double per = ctx->is_te() ? (long double)n * (4 + 5 + 64 + 32) + (long double)pl.L * 4 * 40
+                                 : (long double)n * (8 + 9 + 96 + 48 + 56) + (long double)pl.L * 4 * 40;
   int w = (int)std::max<long double>(1, (long double)ctx->ws_budget / per);
   return std::min(w, pl.K);
 }
@@ -388,6 +416,38 @@ void horner_to_affine(const msm_host::Curve6& C, const std::vector<msm_host::Pro
   fe6_to_bytes(out->y, y);
 }
 
+// twisted Edwards tail: S = sum_k 2^(ck) P_k with unified additions (src/msm-basic.ts:142-158), then x = X/Z, y = Y/Z
+void te_horner_to_affine(const msm_ctx* ctx, const std::vector<uint32_t>& words, int K, int c, msm_result* out) {
+  const auto& C = ctx->hte;
+  std::vector<msm_host::Ext6> P(K);
+  for (int k = 0; k < K; k++) {
+    const uint32_t* w = &words[(size_t)k * 32];
+    msm_host::Fe6* dst[4] = {&P[k].X, &P[k].Y, &P[k].Z, &P[k].T};
+    for (int j = 0; j < 4; j++) {
+      msm_host::Fe6 t = {{0, 0, 0, 0, 0, 0}};
+      for (int i = 0; i < 4; i++) t.v[i] = (uint64_t)w[8 * j + 2 * i] | ((uint64_t)w[8 * j + 2 * i + 1] << 32);
+      if (msm_host::Field6::ge(t, C.F.p)) C.F.sub_raw(t, t, C.F.p);   // device values are < 2p
+      C.F.mul(*dst[j], t, ctx->k_te_to_host);
+    }
+  }
+  msm_host::Ext6 acc = P[K - 1];
+  for (int k = K - 2; k >= 0; k--) {
+    for (int j = 0; j < c; j++) acc = C.add(acc, acc);
+    acc = C.add(acc, P[k]);
+  }
+  msm_host::Fe6 zi, x, y, one = {{1, 0, 0, 0, 0, 0}};
+  C.F.inv(zi, acc.Z);
+  C.F.mul(x, acc.X, zi);
+  C.F.mul(y, acc.Y, zi);
+  C.F.mul(x, x, one);
+  C.F.mul(y, y, one);
+  memset(out->x, 0, 48);
+  memset(out->y, 0, 48);
+  fe6_to_bytes(out->x, x);
+  fe6_to_bytes(out->y, y);
+  out->is_infinity = 0;
+}
+
 int stage_scalars(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const uint32_t** d_out) {
   if (on_device) {
     *d_out = (const uint32_t*)scalars;
@@ -406,12 +466,13 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   stage_scalars(ctx, scalars, n, on_device, &d_scal);
   HIPCHK(hipEventRecord(ctx->ev[9], ctx->stream));
   GroupStats st;
-  words.assign((size_t)(k_hi - k_lo) * 36, 0);
-  int wpg = windows_per_group(ctx, n, pl);
+  const int pw = ctx->is_te() ? 32 : 36;
+  words.assign((size_t)(k_hi - k_lo) * pw, 0);
+  int wpg = std::min(windows_per_group(ctx, n, pl), 128);
   for (int k = k_lo; k < k_hi; k += wpg) {
     int ke = std::min(k_hi, k + wpg);
     run_window_group(ctx, d_scal, n, pl, k, ke, ctx->h_partials, st);
-    memcpy(&words[(size_t)(k - k_lo) * 36], ctx->h_partials, (size_t)(ke - k) * 36 * 4);
+    memcpy(&words[(size_t)(k - k_lo) * pw], ctx->h_partials, (size_t)(ke - k) * pw * 4);
   }
   HIPCHK(hipEventRecord(ctx->ev[10], ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -476,6 +537,12 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
   }
   ctx->hc.F.init(Fp377::PW);
   ctx->k_dev_to_host = ctx->hc.F.pow2(378);
+  {
+    uint32_t pw[12] = {0};
+    for (int i = 0; i < 8; i++) pw[i] = Fp253::PW[i];
+    ctx->hte.init(pw, 3021);
+    ctx->k_te_to_host = ctx->hte.F.pow2(498);
+  }
   *out = ctx;
   return MSM_OK;
 }
@@ -498,23 +565,29 @@ const char* msm_last_error(const msm_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, int check_curve) {
   if (!ctx || (!points && n)) return fail(ctx, MSM_ERR_ARG, "msm_set_points: null argument");
-  if (ctx->curve != MSM_CURVE_BLS12_377_G1) return fail(ctx, MSM_ERR_ARG, "msm_set_points: curve not supported yet");
   if (n >= (1ull << 30)) return fail(ctx, MSM_ERR_ARG, "msm_set_points: n must be < 2^30");
+  const bool te = ctx->is_te();
+  const size_t wire_bytes = te ? 64 : 96;
+  const size_t row_words = te ? te::TE_ROW_WORDS : ROW_WORDS;
   try {
     HIPCHK(hipSetDevice(ctx->device));
     ctx->n_points = 0;
-    ctx->ensure(ctx->rows, std::max<uint64_t>(n, 1) * ROW_WORDS * 4);
+    ctx->ensure(ctx->rows, std::max<uint64_t>(n, 1) * row_words * 4);
     const uint32_t* d_wire = (const uint32_t*)points;
     if (!on_device && n) {
-      ctx->ensure(ctx->misc, n * 96);
-      HIPCHK(hipMemcpyAsync(ctx->misc.p, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
+      ctx->ensure(ctx->misc, n * wire_bytes);
+      HIPCHK(hipMemcpyAsync(ctx->misc.p, points, n * wire_bytes, hipMemcpyHostToDevice, ctx->stream));
       d_wire = (const uint32_t*)ctx->misc.p;
     }
     HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
     if (n) {
       uint64_t grid = (n + 255) / 256;
-      hipLaunchKernelGGL(k_points_from_wire, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p, d_wire, n,
-                         check_curve, (uint32_t*)ctx->errflag.p);
+      if (te)
+        hipLaunchKernelGGL(te::k_te_points_from_wire, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p, d_wire,
+                           n, check_curve, (uint32_t*)ctx->errflag.p);
+      else
+        hipLaunchKernelGGL(k_points_from_wire, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p, d_wire, n,
+                           check_curve, (uint32_t*)ctx->errflag.p);
     }
     HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->errflag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -612,7 +685,6 @@ int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm
 
 int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, msm_result* out) {
   if (!ctx || !out || (!scalars && n)) return fail(ctx, MSM_ERR_ARG, "msm_run: null argument");
-  if (ctx->curve != MSM_CURVE_BLS12_377_G1) return fail(ctx, MSM_ERR_ARG, "msm_run: curve not supported yet");
   if (n > ctx->n_points) return fail(ctx, MSM_ERR_NO_POINTS, "msm_run: %llu scalars but %llu resident points",
                                      (unsigned long long)n, (unsigned long long)ctx->n_points);
   Plan pl;
@@ -621,7 +693,8 @@ int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const 
   out->c = pl.c;
   out->K = pl.K;
   if (n == 0) {
-    out->is_infinity = 1;
+    if (ctx->is_te()) out->y[0] = 1;   // identity (0, 1)
+    else out->is_infinity = 1;
     return MSM_OK;
   }
   try {
@@ -629,9 +702,13 @@ int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const 
     std::vector<uint32_t> words;
     window_sums_impl(ctx, scalars, n, on_device, opts, 0, pl.K, pl, words, out);
     HIPCHK(hipEventRecord(ctx->ev[10], ctx->stream));
-    std::vector<msm_host::Proj6> P(pl.K);
-    for (int k = 0; k < pl.K; k++) P[k] = partial_to_host(ctx, &words[(size_t)k * 36]);
-    horner_to_affine(ctx->hc, P, pl.c, out);
+    if (ctx->is_te()) {
+      te_horner_to_affine(ctx, words, pl.K, pl.c, out);
+    } else {
+      std::vector<msm_host::Proj6> P(pl.K);
+      for (int k = 0; k < pl.K; k++) P[k] = partial_to_host(ctx, &words[(size_t)k * 36]);
+      horner_to_affine(ctx->hc, P, pl.c, out);
+    }
     HIPCHK(hipEventRecord(ctx->ev[11], ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms;
@@ -646,6 +723,28 @@ int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const 
 
 int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy) {
   if (!ctx || !out_xy || first + count > ctx->n_points) return fail(ctx, MSM_ERR_ARG, "msm_get_points: bad argument");
+  if (ctx->is_te()) {
+    try {
+      HIPCHK(hipSetDevice(ctx->device));
+      std::vector<uint32_t> rows((size_t)count * te::TE_ROW_WORDS);
+      if (count)
+        HIPCHK(hipMemcpy(rows.data(), (const uint32_t*)ctx->rows.p + first * te::TE_ROW_WORDS, rows.size() * 4, hipMemcpyDeviceToHost));
+      msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
+      for (uint64_t i = 0; i < count; i++)
+        for (int j = 0; j < 2; j++) {
+          msm_host::Fe6 t = {{0, 0, 0, 0, 0, 0}};
+          const uint32_t* w = &rows[(size_t)i * te::TE_ROW_WORDS + 8 * j];
+          for (int q = 0; q < 4; q++) t.v[q] = (uint64_t)w[2 * q] | ((uint64_t)w[2 * q + 1] << 32);
+          ctx->hte.F.mul(t, t, ctx->k_te_to_host);
+          ctx->hte.F.mul(t, t, one);
+          for (int q = 0; q < 4; q++)
+            for (int b = 0; b < 8; b++) out_xy[i * 64 + 32 * j + 8 * q + b] = (uint8_t)(t.v[q] >> (8 * b));
+        }
+    } catch (const HipFail& f) {
+      return fail_hip(ctx, f);
+    }
+    return MSM_OK;
+  }
   try {
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<uint32_t> rows((size_t)count * ROW_WORDS);
@@ -672,16 +771,20 @@ int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy
 
 int msm_test_fp(msm_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, uint64_t n) {
   if (!ctx || !a || !b || !out) return fail(ctx, MSM_ERR_ARG, "msm_test_fp: null argument");
-  if (ctx->curve != MSM_CURVE_BLS12_377_G1) return fail(ctx, MSM_ERR_ARG, "msm_test_fp: curve not supported yet");
+  const size_t nb = ctx->is_te() ? 32 : 48;
   try {
     HIPCHK(hipSetDevice(ctx->device));
-    ctx->ensure(ctx->misc, n * 48 * 3 + 64);
+    ctx->ensure(ctx->misc, n * nb * 3 + 64);
     uint8_t* d = (uint8_t*)ctx->misc.p;
-    HIPCHK(hipMemcpyAsync(d, a, n * 48, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d + n * 48, b, n * 48, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_test_fp, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)(d + 2 * n * 48),
-                       (const uint32_t*)d, (const uint32_t*)(d + n * 48), (uint32_t)n, op);
-    HIPCHK(hipMemcpyAsync(out, d + 2 * n * 48, n * 48, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d, a, n * nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d + n * nb, b, n * nb, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->is_te())
+      hipLaunchKernelGGL(te::k_te_test_fp, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)(d + 2 * n * nb),
+                         (const uint32_t*)d, (const uint32_t*)(d + n * nb), (uint32_t)n, op);
+    else
+      hipLaunchKernelGGL(k_test_fp, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)(d + 2 * n * nb),
+                         (const uint32_t*)d, (const uint32_t*)(d + n * nb), (uint32_t)n, op);
+    HIPCHK(hipMemcpyAsync(out, d + 2 * n * nb, n * nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
   } catch (const HipFail& f) {
@@ -692,6 +795,7 @@ int msm_test_fp(msm_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_
 
 int msm_test_glv(msm_ctx* ctx, const uint8_t* scalars, uint8_t* out, uint64_t n) {
   if (!ctx || !scalars || !out) return fail(ctx, MSM_ERR_ARG, "msm_test_glv: null argument");
+  if (ctx->is_te()) return fail(ctx, MSM_ERR_ARG, "msm_test_glv: the twisted Edwards path has no GLV step");
   try {
     HIPCHK(hipSetDevice(ctx->device));
     ctx->ensure(ctx->misc, n * 72 + 64);

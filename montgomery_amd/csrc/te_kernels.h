@@ -1,0 +1,425 @@
+// HIP kernels of the generic ("msmBasic") MSM path for the twisted Edwards curve Ed-on-BLS12-377
+// (a = -1, d = 3021) in extended coordinates (X, Y, Z, T).
+//
+// Reference: src/msm-basic.ts:45-211 (digit map :72-91, bucket accumulation with mixed add / sub
+// :103-123, reduceBucketsChunk :180-211, Horner :142-158) over src/curve-twisted-edwards.ts:84-165
+// (unified add-2008-hwcd-3 with k = 2d; subtraction by negating X2 and T2; mixed form when Z2 = 1).
+//
+// The GPU keeps the reference's arithmetic (unified extended additions, no inversions, identity is
+// the ordinary point (0, 1, 1, 0), src/bigint/twisted-edwards.ts:34) but not its loop shape: the
+// reference lets every thread scan all N points for its bucket chunk; here the digits are counting-
+// sorted exactly like on the Weierstrass path (same k_hist / k_colscan / k_scan / k_scatter_lds) and
+// each bucket is summed by the same padded halving tree, whose node operation is the unified
+// addition -- no edge cases, so padding with the identity needs no flags at all.
+//
+// Field: 253-bit prime (the BLS12-377 scalar field), 9 x 30-bit limbs, R = 2^270 >= 2^17 p: every
+// sum / difference below feeds a multiplication unreduced, and tree nodes are stored as the raw
+// multiplication outputs (< 2p, 8 packed words per coordinate); nothing on this path compares values.
+//
+// Layouts: point rows 128 B = [x | y | t = xy | k t], Montgomery form; tree buffers: 8 planes of 16 B
+// (X, Y, Z, T two planes each); payload = (point index << 1) | negative.
+#pragma once
+#include "msm_kernels.h"
+
+namespace msm {
+namespace te {
+
+using FT = Fp253;
+constexpr int TL = FT::NL;   // 9
+constexpr int TW = FT::NW;   // 8
+constexpr int TE_ROW_WORDS = 32;
+
+struct Ext {
+  Fe<FT> X, Y, Z, T;
+};
+
+// constant tables are only ever value-used (compile-time constants in device code)
+#define TE_CONST(dst, NAME)                                \
+  do {                                                     \
+    _Pragma("unroll") for (int _l = 0; _l < TL; _l++)(dst).l[_l] = FT::NAME[_l]; \
+  } while (0)
+
+MSM_DEV void te_set_identity(Ext& P) {
+  fe_set_zero<FT>(P.X);
+  fe_set_one<FT>(P.Y);
+  fe_set_one<FT>(P.Z);
+  fe_set_zero<FT>(P.T);
+}
+
+MSM_DEV void load_words8(uint32_t (&w)[TW], const uint32_t* p) {
+  const uint4* p4 = reinterpret_cast<const uint4*>(p);
+  uint4 a = p4[0], b = p4[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+
+MSM_DEV void load_coord_planes(Fe<FT>& r, const uint4* base, uint64_t cap, int coord, uint64_t e) {
+  uint32_t w[TW];
+  uint4 a = base[(uint64_t)(2 * coord) * cap + e], b = base[(uint64_t)(2 * coord + 1) * cap + e];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  fe_unpack<FT>(r, w);
+}
+
+MSM_DEV void store_coord_planes(uint4* base, uint64_t cap, int coord, uint64_t e, const Fe<FT>& v) {
+  uint32_t w[TW];
+  fe_pack<FT>(w, v);
+  base[(uint64_t)(2 * coord) * cap + e] = make_uint4(w[0], w[1], w[2], w[3]);
+  base[(uint64_t)(2 * coord + 1) * cap + e] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+MSM_DEV void load_ext(Ext& P, const uint4* base, uint64_t cap, uint64_t e) {
+  load_coord_planes(P.X, base, cap, 0, e);
+  load_coord_planes(P.Y, base, cap, 1, e);
+  load_coord_planes(P.Z, base, cap, 2, e);
+  load_coord_planes(P.T, base, cap, 3, e);
+}
+MSM_DEV void store_ext(uint4* base, uint64_t cap, uint64_t e, const Ext& P) {
+  store_coord_planes(base, cap, 0, e, P.X);
+  store_coord_planes(base, cap, 1, e, P.Y);
+  store_coord_planes(base, cap, 2, e, P.Z);
+  store_coord_planes(base, cap, 3, e, P.T);
+}
+
+// tail of add-2008-hwcd-3 from A, B, C, D (all < 2p): 4 multiplications
+MSM_DEV void te_finish(Ext& R, const Fe<FT>& A, const Fe<FT>& B, const Fe<FT>& C, const Fe<FT>& D) {
+  Fe<FT> E, Fv, G, H;
+  fe_sub_2p<FT>(E, B, A);
+  fe_sub_2p<FT>(Fv, D, C);
+  fe_add<FT>(G, D, C);
+  fe_add<FT>(H, B, A);
+  fe_mul<FT>(R.X, E, Fv);
+  fe_mul<FT>(R.Y, G, H);
+  fe_mul<FT>(R.T, E, H);
+  fe_mul<FT>(R.Z, Fv, G);
+}
+
+// general unified addition, 9M (src/curve-twisted-edwards.ts:84-165); coordinates < 2p in and out
+MSM_DEV void te_add(Ext& R, const Ext& P, const Ext& Q) {
+  Fe<FT> a, b, A, B, C, D, k;
+  fe_sub_2p<FT>(a, P.Y, P.X);
+  fe_sub_2p<FT>(b, Q.Y, Q.X);
+  fe_mul<FT>(A, a, b);
+  fe_add<FT>(a, P.Y, P.X);
+  fe_add<FT>(b, Q.Y, Q.X);
+  fe_mul<FT>(B, a, b);
+  TE_CONST(k, K2DL);
+  fe_mul<FT>(C, P.T, Q.T);
+  fe_mul<FT>(C, C, k);
+  fe_mul<FT>(D, P.Z, Q.Z);
+  fe_add<FT>(D, D, D);
+  te_finish(R, A, B, C, D);
+}
+
+// both operands affine rows (Z = 1) with precomputed k*t: 7M
+struct AffRow {
+  Fe<FT> x, y, t, kt;
+};
+MSM_DEV void te_add_rows(Ext& R, const AffRow& P, const AffRow& Q) {
+  Fe<FT> a, b, A, B, C, D;
+  fe_sub_2p<FT>(a, P.y, P.x);
+  fe_sub_2p<FT>(b, Q.y, Q.x);
+  fe_mul<FT>(A, a, b);
+  fe_add<FT>(a, P.y, P.x);
+  fe_add<FT>(b, Q.y, Q.x);
+  fe_mul<FT>(B, a, b);
+  fe_mul<FT>(C, P.t, Q.kt);
+  fe_set_one<FT>(D);
+  fe_add<FT>(D, D, D);
+  te_finish(R, A, B, C, D);
+}
+
+// row -> registers; neg: (x, y, t, kt) -> (-x, y, -t, -kt); absent: identity (0, 1, 0, 0)
+MSM_DEV void load_row(AffRow& P, const uint32_t* rows, uint32_t payload) {
+  if (payload == SLOT_EMPTY) {
+    fe_set_zero<FT>(P.x);
+    fe_set_one<FT>(P.y);
+    fe_set_zero<FT>(P.t);
+    fe_set_zero<FT>(P.kt);
+    return;
+  }
+  const uint32_t* row = rows + (uint64_t)(payload >> 1) * TE_ROW_WORDS;
+  uint32_t w[TW];
+  load_words8(w, row);      fe_unpack<FT>(P.x, w);
+  load_words8(w, row + 8);  fe_unpack<FT>(P.y, w);
+  load_words8(w, row + 16); fe_unpack<FT>(P.t, w);
+  load_words8(w, row + 24); fe_unpack<FT>(P.kt, w);
+  if (payload & 1u) {
+    Fe<FT> z;
+    fe_set_zero<FT>(z);
+    fe_sub_2p<FT>(P.x, z, P.x);    // 2p - x: any representative works, nothing is compared
+    fe_sub_2p<FT>(P.t, z, P.t);
+    fe_sub_2p<FT>(P.kt, z, P.kt);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_te_points_from_wire: N x (x || y) 32-byte little-endian -> rows [x | y | xy | 2d xy]
+// ---------------------------------------------------------------------------------------------
+
+MSM_DEV bool words8_ge_p(const uint32_t (&w)[TW]) {
+  bool gt = false, lt = false;
+#pragma unroll
+  for (int j = TW - 1; j >= 0; j--) {
+    if (!gt && !lt) {
+      if (w[j] > FT::PW[j]) gt = true;
+      else if (w[j] < FT::PW[j]) lt = true;
+    }
+  }
+  return !lt;
+}
+
+__global__ void __launch_bounds__(256) k_te_points_from_wire(uint32_t* rows, const uint32_t* wire, uint64_t n, int check_curve,
+                                                             uint32_t* err) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t xw[TW], yw[TW];
+  load_words8(xw, wire + i * 16);
+  load_words8(yw, wire + i * 16 + 8);
+  if (words8_ge_p(xw) || words8_ge_p(yw)) atomicOr(err, 1u);
+  Fe<FT> x, y, t, kt, r2, k;
+  fe_unpack<FT>(x, xw);
+  fe_unpack<FT>(y, yw);
+  TE_CONST(r2, R2);
+  TE_CONST(k, K2DL);
+  fe_mul<FT>(x, x, r2);
+  fe_mul<FT>(y, y, r2);
+  fe_mul<FT>(t, x, y);
+  fe_mul<FT>(kt, t, k);
+  if (check_curve) {
+    // -x^2 + y^2 = 1 + d x^2 y^2   (src/bigint/twisted-edwards.ts:150-158 with Z = 1)
+    Fe<FT> xx, yy, lhs, rhs, dd, one;
+    fe_sqr<FT>(xx, x);
+    fe_sqr<FT>(yy, y);
+    fe_sub_2p<FT>(lhs, yy, xx);
+    TE_CONST(dd, DL);
+    fe_sqr<FT>(rhs, t);
+    fe_mul<FT>(rhs, rhs, dd);
+    fe_set_one<FT>(one);
+    fe_add<FT>(rhs, rhs, one);
+    fe_sub_4p<FT>(lhs, lhs, rhs);
+    fe_cond_sub<FT, 4>(lhs);
+    fe_reduce_4p<FT>(lhs);
+    if (!fe_is_zero_canonical<FT>(lhs)) atomicOr(err, 2u);
+  }
+  fe_reduce_2p<FT>(x);
+  fe_reduce_2p<FT>(y);
+  fe_reduce_2p<FT>(t);
+  fe_reduce_2p<FT>(kt);
+  uint32_t* row = rows + i * TE_ROW_WORDS;
+  fe_store<FT>(row, x);
+  fe_store<FT>(row + 8, y);
+  fe_store<FT>(row + 16, t);
+  fe_store<FT>(row + 24, kt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_te_digits: signed window digits of full-width scalars (no GLV), src/msm-basic.ts:72-91
+// ---------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_te_digits(uint32_t* dig, uint32_t* counts, const uint32_t* scalars, uint32_t n, int c,
+                                                   int k_total, int k_lo, int k_cnt) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+  {
+    const uint4* p4 = reinterpret_cast<const uint4*>(scalars + (uint64_t)i * 8);
+    uint4 a = p4[0], b = p4[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  }
+  uint32_t q[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) q[j] = FRED_Q[j];
+  for (int it = 0; it < 40 && words8_ge(s, q); it++) bn_addsub<8, 8>(s, q, true);   // scalars >= q are reduced
+  const uint32_t L = 1u << (c - 1);
+  uint32_t carry = 0;
+  for (int k = 0; k < k_total; k++) {
+    uint32_t l = bn_bits<8>(s, k * c, c) + carry;
+    if (l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
+    int kk = k - k_lo;
+    if (kk >= 0 && kk < k_cnt) {
+      dig[(uint64_t)kk * n + i] = l | (carry << 31);
+      if (counts && l) atomicAdd(&counts[(uint64_t)kk * L + (l - 1)], 1u);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_te_add: one round of the bucket tree, output e = input 2e + input 2e+1 (unified addition)
+// ---------------------------------------------------------------------------------------------
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_te_add(BatchArgs a) {
+  const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll 1
+  for (uint64_t e = t; e < a.n_out; e += T) {
+    Ext R;
+    if (MODE == MODE_GATHER) {
+      uint2 pp = reinterpret_cast<const uint2*>(a.slots)[e];
+      AffRow P, Q;
+      load_row(P, a.points, pp.x);
+      load_row(Q, a.points, pp.y);
+      te_add_rows(R, P, Q);
+    } else {
+      uint64_t ia, ib;
+      bool has_b = true;
+      if (MODE == MODE_REGULAR) {
+        ia = 2 * e; ib = 2 * e + 1;
+      } else {
+        uint32_t lo = 0, hi = a.nb;
+        const uint32_t e32 = (uint32_t)e;
+        while (hi - lo > 1) {
+          uint32_t mid = (lo + hi) >> 1;
+          if (a.off_out[mid] <= e32) lo = mid; else hi = mid;
+        }
+        uint32_t j = e32 - a.off_out[lo];
+        ia = (uint64_t)a.off_in[lo] + 2ull * j;
+        ib = ia + 1;
+        has_b = ib < a.off_in[lo + 1];
+      }
+      Ext P, Q;
+      load_ext(P, a.in, a.in_cap, ia);
+      if (has_b) load_ext(Q, a.in, a.in_cap, ib); else te_set_identity(Q);
+      te_add(R, P, Q);
+    }
+    store_ext(a.out, a.out_cap, e, R);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_te_bucket_reduce / k_te_window_sum: reduceBucketsChunk (src/msm-basic.ts:180-211) per chunk of TC
+// buckets, then the per-window sum of the chunk columns
+// ---------------------------------------------------------------------------------------------
+
+MSM_DEV void ext_store_raw(uint32_t* dst, const Ext& P) {
+#pragma unroll
+  for (int l = 0; l < TL; l++) { dst[l] = P.X.l[l]; dst[TL + l] = P.Y.l[l]; dst[2 * TL + l] = P.Z.l[l]; dst[3 * TL + l] = P.T.l[l]; }
+}
+MSM_DEV void ext_load_raw(Ext& P, const uint32_t* src) {
+#pragma unroll
+  for (int l = 0; l < TL; l++) { P.X.l[l] = src[l]; P.Y.l[l] = src[TL + l]; P.Z.l[l] = src[2 * TL + l]; P.T.l[l] = src[3 * TL + l]; }
+}
+
+__global__ void __launch_bounds__(64) k_te_bucket_reduce(uint32_t* columns, const uint4* fin, uint64_t fin_cap, const uint32_t* off_fin,
+                                                          uint32_t L, uint32_t TC, uint32_t nchunks, uint32_t k_cnt) {
+  uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= nchunks * k_cnt) return;
+  uint32_t kk = id / nchunks, ch = id - kk * nchunks;
+  uint32_t lstart = ch * TC + 1;
+  uint32_t lend = min(lstart + TC - 1, L);
+  Ext row, tri;
+  te_set_identity(row);
+  te_set_identity(tri);
+#pragma unroll 1
+  for (uint32_t l = lend; l >= lstart; l--) {
+    uint64_t b = (uint64_t)kk * L + (l - 1);
+    uint32_t o0 = off_fin[b], o1 = off_fin[b + 1];
+    if (o1 > o0) {
+      Ext Q;
+      load_ext(Q, fin, fin_cap, o0);
+      te_add(row, row, Q);
+    }
+    te_add(tri, tri, row);
+  }
+  uint32_t ls = lstart - 1;
+  if (ls) {
+#pragma unroll 1
+    while (true) {
+      if (ls & 1) te_add(tri, tri, row);
+      ls >>= 1;
+      if (ls == 0) break;
+      te_add(row, row, row);   // doubling = unified add, src/curve-twisted-edwards.ts:215-217
+    }
+  }
+  ext_store_raw(columns + (uint64_t)id * (4 * TL), tri);
+}
+
+constexpr int TE_WS_THREADS = 256;
+
+// output: 4 x 8 packed words (X, Y, Z, T), Montgomery form, values < 2p
+__global__ void __launch_bounds__(TE_WS_THREADS) k_te_window_sum(uint32_t* partials, const uint32_t* columns, uint32_t nchunks) {
+  __shared__ uint32_t lds[4 * TL * TE_WS_THREADS];
+  const uint32_t kk = blockIdx.x, tid = threadIdx.x;
+  Ext acc;
+  te_set_identity(acc);
+#pragma unroll 1
+  for (uint32_t j = tid; j < nchunks; j += TE_WS_THREADS) {
+    Ext Q;
+    ext_load_raw(Q, columns + ((uint64_t)kk * nchunks + j) * (4 * TL));
+    te_add(acc, acc, Q);
+  }
+#pragma unroll 1
+  for (uint32_t s = TE_WS_THREADS / 2; s >= 1; s >>= 1) {
+    if (tid >= s && tid < 2 * s) {
+#pragma unroll
+      for (int l = 0; l < TL; l++) {
+        lds[(l)*TE_WS_THREADS + tid] = acc.X.l[l];
+        lds[(TL + l) * TE_WS_THREADS + tid] = acc.Y.l[l];
+        lds[(2 * TL + l) * TE_WS_THREADS + tid] = acc.Z.l[l];
+        lds[(3 * TL + l) * TE_WS_THREADS + tid] = acc.T.l[l];
+      }
+    }
+    __syncthreads();
+    if (tid < s) {
+      Ext Q;
+#pragma unroll
+      for (int l = 0; l < TL; l++) {
+        Q.X.l[l] = lds[(l)*TE_WS_THREADS + tid + s];
+        Q.Y.l[l] = lds[(TL + l) * TE_WS_THREADS + tid + s];
+        Q.Z.l[l] = lds[(2 * TL + l) * TE_WS_THREADS + tid + s];
+        Q.T.l[l] = lds[(3 * TL + l) * TE_WS_THREADS + tid + s];
+      }
+      te_add(acc, acc, Q);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    uint32_t* dst = partials + (uint64_t)kk * 32;
+    uint32_t w[TW];
+    fe_pack<FT>(w, acc.X);
+#pragma unroll
+    for (int j = 0; j < TW; j++) dst[j] = w[j];
+    fe_pack<FT>(w, acc.Y);
+#pragma unroll
+    for (int j = 0; j < TW; j++) dst[8 + j] = w[j];
+    fe_pack<FT>(w, acc.Z);
+#pragma unroll
+    for (int j = 0; j < TW; j++) dst[16 + j] = w[j];
+    fe_pack<FT>(w, acc.T);
+#pragma unroll
+    for (int j = 0; j < TW; j++) dst[24 + j] = w[j];
+  }
+}
+
+// element-wise base-field operators for parity tests (same op codes as k_test_fp)
+__global__ void __launch_bounds__(256) k_te_test_fp(uint32_t* out, const uint32_t* a, const uint32_t* b, uint32_t n, int op) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe<FT> x, y, r;
+  fe_load<FT>(x, a + (uint64_t)i * TW);
+  fe_load<FT>(y, b + (uint64_t)i * TW);
+  switch (op) {
+    case OP_MUL: fe_mul<FT>(r, x, y); break;
+    case OP_SQR: fe_sqr<FT>(r, x); break;
+    case OP_ADD: fe_add<FT>(r, x, y); break;
+    case OP_SUB: fe_sub_p<FT>(r, x, y); break;
+    case OP_INV: fe_inv<FT>(r, x); break;
+    case OP_TO_MONT: {
+      Fe<FT> r2;
+      TE_CONST(r2, R2);
+      fe_mul<FT>(r, x, r2);
+      break;
+    }
+    default: {
+      Fe<FT> one;
+      fe_set_zero<FT>(one);
+      one.l[0] = 1;
+      fe_mul<FT>(r, x, one);
+      break;
+    }
+  }
+  fe_reduce_4p<FT>(r);
+  fe_store<FT>(out + (uint64_t)i * TW, r);
+}
+
+}  // namespace te
+}  // namespace msm
