@@ -25,3 +25,10 @@ HOSTTEST := tests/csrc/libfield_host.so
 hosttest: $(HOSTTEST)
 $(HOSTTEST): tests/csrc/field_host.hip $(CSRC)/field.h $(CSRC)/glv.h $(CSRC)/constants_gen.h
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -I$(CSRC) tests/csrc/field_host.hip -o $(HOSTTEST)
+
+# Node N-API shim (the image's node 12 exposes N-API 8 through /usr/include/node)
+NAPI := montgomery_amd/msm_hip.node
+napi: $(NAPI)
+$(NAPI): napi/msm_addon.cc include/msm_hip.h $(LIB)
+	g++ -O2 -std=c++14 -fPIC -shared -Iinclude -I/usr/include/node napi/msm_addon.cc -o $(NAPI) \
+	    -Lmontgomery_amd -lmsm_hip -Wl,-rpath,'$$ORIGIN'

@@ -1,0 +1,84 @@
+// JS facade over the N-API shim: the reference's curve-module surface for the MSM path.
+//   Weierstraß.create(params) -> { params, Parallel }            src/parallel.ts:40-177
+//   Parallel.{getPointer, getScalarPointer, pointsFromBytes, scalarsFromBytes, msm, msmUnsafe}
+//                                                                src/parallel.ts:135-145
+//   compute_msm(points, scalars) -> {x: bigint, y: bigint}       scripts/zprize23/submission-bls377.ts:20-65
+// Plain CommonJS without top-level await so the image's node 12 can load it (the reference's own
+// sources need node >= 20).  In the reference "pointers" are offsets into wasm memory; here they are
+// small handle objects, the data lives in buffers owned by libmsm_hip.so.
+"use strict";
+const path = require("path");
+const hip = require(path.join(__dirname, "..", "montgomery_amd", "msm_hip.node"));
+
+const bls12377Params = {
+  label: "bls12-377",
+  modulus: BigInt("0x01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001"),
+  order: BigInt("0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001"),
+};
+const edOnBls12377Params = {
+  label: "ed-on-bls12-377",
+  modulus: BigInt("0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001"),
+  order: BigInt("0x4aad957a68b2955982d1347970dec005293a3afc43c8afeb95aee9ac33fd9ff"),
+};
+
+function leBytesToBigint(buf) {
+  let x = BigInt(0);
+  for (let i = buf.length - 1; i >= 0; i--) x = (x << BigInt(8)) | BigInt(buf[i]);
+  return x;
+}
+function bigintToLeBytes(x, n) {
+  const out = Buffer.alloc(n);
+  for (let i = 0; i < n; i++) { out[i] = Number(x & BigInt(255)); x >>= BigInt(8); }
+  return out;
+}
+
+function createCurve(params, curveId, coordBytes, device) {
+  const ctx = hip.createContext(curveId, device || 0);
+  const pointBytes = 2 * coordBytes;
+  const Parallel = {
+    getPointer(size) { return { size, n: 0 }; },
+    getScalarPointer(size) { return { size, bytes: null, n: 0 }; },
+    async pointsFromBytes(pointPtr, input, n) {
+      const b = Buffer.from(input.buffer, input.byteOffset, n * pointBytes);
+      pointPtr.n = hip.setPoints(ctx, b, pointBytes, 0);
+    },
+    async scalarsFromBytes(scalarPtr, input, n) {
+      scalarPtr.bytes = Buffer.from(Buffer.from(input.buffer, input.byteOffset, n * 32));
+      scalarPtr.n = n;
+    },
+    async msm(scalarPtr, pointPtr, N, verboseTiming, options) {
+      const c = (options && options.c) || 0;
+      const r = hip.msm(ctx, scalarPtr.bytes.slice(0, 32 * N), c, coordBytes);
+      const result = { x: leBytesToBigint(r.x), y: leBytesToBigint(r.y), isZero: r.isZero };
+      const log = verboseTiming ? [[{ n: Math.ceil(Math.log2(Math.max(N, 1))), K: r.K, c: r.c }], [`msm total... ${r.phaseMs[0].toFixed(3)}ms`]] : [];
+      return { result, log };
+    },
+    msmUnsafe(scalarPtr, pointPtr, N, verboseTiming, options) {
+      return Parallel.msm(scalarPtr, pointPtr, N, verboseTiming, options);   // the GPU kernels always handle the edge cases
+    },
+  };
+  return { params, Parallel, close() { hip.destroyContext(ctx); } };
+}
+
+const Weierstrass = { create(params, device) { return createCurve(params, hip.CURVE_BLS12_377_G1, 48, device); } };
+const TwistedEdwards = { create(params, device) { return createCurve(params, hip.CURVE_ED_ON_BLS12_377, 32, device); } };
+
+// compute_msm(points: {x, y, isZero}[] | Buffer, scalars: bigint[] | Buffer) -> {x, y}
+async function compute_msm(curve, coordBytes, inputPoints, inputScalars) {
+  const pointBytes = 2 * coordBytes;
+  let sbytes, pbytes;
+  if (Buffer.isBuffer(inputScalars) || inputScalars instanceof Uint8Array) sbytes = Buffer.from(inputScalars);
+  else sbytes = Buffer.concat(inputScalars.map((s) => bigintToLeBytes(BigInt(s), 32)));
+  const n = sbytes.length / 32;
+  if (Buffer.isBuffer(inputPoints) || inputPoints instanceof Uint8Array) pbytes = Buffer.from(inputPoints);
+  else pbytes = Buffer.concat(inputPoints.map((P) => (P.isZero ? Buffer.alloc(pointBytes) : Buffer.concat([bigintToLeBytes(BigInt(P.x), coordBytes), bigintToLeBytes(BigInt(P.y), coordBytes)]))));
+  const pp = curve.Parallel.getPointer(pbytes.length);
+  const sp = curve.Parallel.getScalarPointer(sbytes.length);
+  await curve.Parallel.pointsFromBytes(pp, pbytes, n);
+  await curve.Parallel.scalarsFromBytes(sp, sbytes, n);
+  const same = n > 1 && pbytes.slice(0, pointBytes).equals(pbytes.slice(pointBytes, 2 * pointBytes));
+  const { result } = same ? await curve.Parallel.msm(sp, pp, n) : await curve.Parallel.msmUnsafe(sp, pp, n);
+  return { x: result.x, y: result.y, isZero: result.isZero };
+}
+
+module.exports = { hip, Weierstrass, TwistedEdwards, bls12377Params, edOnBls12377Params, compute_msm, leBytesToBigint, bigintToLeBytes };

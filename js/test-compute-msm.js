@@ -1,0 +1,65 @@
+// Mirrors the reference's self-tests scripts/zprize23/submission-test-bls377.ts and submission-test.ts through
+// the N-API shim, plus the committed golden vectors (tests/golden/*.json).  Run on a GPU box: node js/test-compute-msm.js
+"use strict";
+const fs = require("fs");
+const path = require("path");
+const M = require("./montgomery-hip.js");
+
+function assert(c, msg) { if (!c) { console.error("FAILED: " + msg); process.exit(1); } }
+
+async function main() {
+  // --- BLS12-377 G1 (submission-test-bls377.ts:6-45)
+  const bls = M.Weierstrass.create(M.bls12377Params);
+  const point = {
+    x: BigInt("111871295567327857271108656266735188604298176728428155068227918632083036401841336689521497731900230387779623820740"),
+    y: BigInt("76860045326390600098227152997486448974650822224305058012700629806287380625419427989664237630603922765089083164740"),
+    isZero: false,
+  };
+  const q = M.bls12377Params.order;
+  let r = await M.compute_msm(bls, 48, [point, point], [BigInt(2), q - BigInt(1)]);
+  assert(r.x === point.x && r.y === point.y, "2P + (q-1)P = P");
+  console.log("2 points ok");
+  const n = 1000;
+  let scalars = [], sum = BigInt(0);
+  let seed = BigInt(12345);
+  for (let i = 0; i < n; i++) {
+    seed = (seed * BigInt("6364136223846793005") + BigInt("1442695040888963407")) % (BigInt(1) << BigInt(250));
+    scalars.push(seed % q);
+    sum = (sum + scalars[i]) % q;
+  }
+  const r2 = await M.compute_msm(bls, 48, Array(n).fill(point), scalars);
+  const r3 = await M.compute_msm(bls, 48, [point], [sum]);
+  assert(r2.x === r3.x && r2.y === r3.y, "same points: msm = (sum s) P");
+  console.log("same points ok");
+  const gold = JSON.parse(fs.readFileSync(path.join(__dirname, "..", "tests", "golden", "msm377.json"), "utf8"));
+  for (const c of gold.cases) {
+    const pts = Buffer.from(c.points, "hex"), sc = Buffer.from(c.scalars, "hex");
+    const pp = bls.Parallel.getPointer(pts.length), sp = bls.Parallel.getScalarPointer(sc.length);
+    await bls.Parallel.pointsFromBytes(pp, pts, c.n);
+    await bls.Parallel.scalarsFromBytes(sp, sc, c.n);
+    const { result, log } = await bls.Parallel.msmUnsafe(sp, pp, c.n, true, { c: c.c || 0 });
+    if (c.result === null) assert(result.isZero, c.name + " should be the identity");
+    else assert(!result.isZero && result.x === BigInt(c.result[0]) && result.y === BigInt(c.result[1]), "golden " + c.name);
+    assert(log.length > 0, "log");
+  }
+  console.log("golden bls12-377 ok:", gold.cases.length, "cases");
+  bls.close();
+
+  // --- Ed-on-BLS12-377 (submission-test.ts:5-21)
+  const ed = M.TwistedEdwards.create(M.edOnBls12377Params);
+  const ep = {
+    x: BigInt("2796670805570508460920584878396618987767121022598342527208237783066948667246"),
+    y: BigInt("8134280397689638111748378379571739274369602049665521098046934931245960532166"),
+  };
+  r = await M.compute_msm(ed, 32, [ep, ep], [BigInt(2), M.edOnBls12377Params.order - BigInt(1)]);
+  assert(r.x === ep.x && r.y === ep.y, "ed: 2P + (q-1)P = P");
+  const goldEd = JSON.parse(fs.readFileSync(path.join(__dirname, "..", "tests", "golden", "msm_ed377.json"), "utf8"));
+  for (const c of goldEd.cases) {
+    const rr = await M.compute_msm(ed, 32, Buffer.from(c.points, "hex"), Buffer.from(c.scalars, "hex"));
+    assert(rr.x === BigInt(c.result[0]) && rr.y === BigInt(c.result[1]), "golden ed " + c.name);
+  }
+  console.log("ed-on-bls12-377 ok");
+  ed.close();
+  console.log("ALL OK");
+}
+main().catch((e) => { console.error(e); process.exit(1); });

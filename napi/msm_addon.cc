@@ -1,0 +1,167 @@
+// Node N-API shim over the C ABI of libmsm_hip.so (include/msm_hip.h).
+//
+// This is the "thin Node N-API C-ABI shim into HIP" that replaces the reference's wasm backend for
+// the MSM path: the JS facade in js/montgomery-hip.js rebuilds the reference's
+// `Curve.Parallel.{pointsFromBytes, scalarsFromBytes, msm, msmUnsafe}` (src/parallel.ts:135-145) and
+// `compute_msm` (scripts/zprize23/submission-bls377.ts:20-65) on top of the functions exported here.
+// Plain N-API (C), version 8 as shipped with the image's node 12; no node-addon-api / node-gyp.
+//
+// Exports: createContext(curve, device) -> external handle, destroyContext(h), setPoints(h, Buffer, check),
+//          msm(h, Buffer scalars, c) -> {x: Buffer, y: Buffer, isZero, c, K, phaseMs: Float64Array(8)},
+//          plan(h, n, c) -> {c, K}, lastError(h)
+#include <node_api.h>
+#include <stdio.h>
+#include <string.h>
+#include "msm_hip.h"
+
+#define NAPI_OK(call)                                                      \
+  do {                                                                     \
+    if ((call) != napi_ok) {                                               \
+      napi_throw_error(env, NULL, "N-API call failed: " #call);            \
+      return NULL;                                                         \
+    }                                                                      \
+  } while (0)
+
+static napi_value throw_msm(napi_env env, msm_ctx* ctx, int rc, const char* what) {
+  char buf[640];
+  snprintf(buf, sizeof buf, "%s: msm error %d: %s", what, rc, ctx ? msm_last_error(ctx) : "no context (no usable GPU? there is no CPU fallback)");
+  napi_throw_error(env, NULL, buf);
+  return NULL;
+}
+
+static msm_ctx* get_ctx(napi_env env, napi_value v) {
+  void* p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+    napi_throw_type_error(env, NULL, "expected a context handle from createContext()");
+    return NULL;
+  }
+  return (msm_ctx*)p;
+}
+
+static napi_value CreateContext(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  int32_t curve = 0, device = 0;
+  if (argc > 0) napi_get_value_int32(env, argv[0], &curve);
+  if (argc > 1) napi_get_value_int32(env, argv[1], &device);
+  msm_ctx* ctx = NULL;
+  int rc = msm_ctx_create(&ctx, curve, device);
+  if (rc != MSM_OK) return throw_msm(env, NULL, rc, "createContext");
+  napi_value out;
+  NAPI_OK(napi_create_external(env, ctx, NULL, NULL, &out));
+  return out;
+}
+
+static napi_value DestroyContext(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  msm_ctx* ctx = get_ctx(env, argv[0]);
+  if (ctx) msm_ctx_destroy(ctx);
+  return NULL;
+}
+
+static napi_value SetPoints(napi_env env, napi_callback_info info) {  // pointsFromBytes, src/parallel.ts:97-116
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  msm_ctx* ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  void* data;
+  size_t len;
+  NAPI_OK(napi_get_buffer_info(env, argv[1], &data, &len));
+  int32_t point_bytes = 96, check = 0;
+  if (argc > 2) napi_get_value_int32(env, argv[2], &point_bytes);
+  if (argc > 3) napi_get_value_int32(env, argv[3], &check);
+  if (point_bytes <= 0 || len % (size_t)point_bytes) {
+    napi_throw_range_error(env, NULL, "point buffer length is not a multiple of the point size");
+    return NULL;
+  }
+  int rc = msm_set_points(ctx, data, len / point_bytes, 0, check);
+  if (rc != MSM_OK) return throw_msm(env, ctx, rc, "setPoints");
+  napi_value n;
+  NAPI_OK(napi_create_uint32(env, (uint32_t)(len / point_bytes), &n));
+  return n;
+}
+
+static napi_value Msm(napi_env env, napi_callback_info info) {  // msm / msmUnsafe, src/msm-batched-affine.ts:69-340
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  msm_ctx* ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  void* data;
+  size_t len;
+  NAPI_OK(napi_get_buffer_info(env, argv[1], &data, &len));
+  if (len % 32) {
+    napi_throw_range_error(env, NULL, "scalar buffer length is not a multiple of 32");
+    return NULL;
+  }
+  msm_opts opts;
+  memset(&opts, 0, sizeof opts);
+  int32_t coord = 48;
+  if (argc > 2) napi_get_value_int32(env, argv[2], &opts.c);
+  if (argc > 3) napi_get_value_int32(env, argv[3], &coord);
+  msm_result res;
+  int rc = msm_run(ctx, data, len / 32, 0, &opts, &res);
+  if (rc != MSM_OK) return throw_msm(env, ctx, rc, "msm");
+  napi_value out, x, y, v, ph;
+  NAPI_OK(napi_create_object(env, &out));
+  NAPI_OK(napi_create_buffer_copy(env, (size_t)coord, res.x, NULL, &x));
+  NAPI_OK(napi_create_buffer_copy(env, (size_t)coord, res.y, NULL, &y));
+  NAPI_OK(napi_set_named_property(env, out, "x", x));
+  NAPI_OK(napi_set_named_property(env, out, "y", y));
+  NAPI_OK(napi_get_boolean(env, res.is_infinity != 0, &v));
+  NAPI_OK(napi_set_named_property(env, out, "isZero", v));
+  NAPI_OK(napi_create_int32(env, res.c, &v));
+  NAPI_OK(napi_set_named_property(env, out, "c", v));
+  NAPI_OK(napi_create_int32(env, res.K, &v));
+  NAPI_OK(napi_set_named_property(env, out, "K", v));
+  NAPI_OK(napi_create_array_with_length(env, MSM_N_PHASES, &ph));
+  for (uint32_t i = 0; i < MSM_N_PHASES; i++) {
+    NAPI_OK(napi_create_double(env, res.phase_ms[i], &v));
+    NAPI_OK(napi_set_element(env, ph, i, v));
+  }
+  NAPI_OK(napi_set_named_property(env, out, "phaseMs", ph));
+  return out;
+}
+
+static napi_value Plan(napi_env env, napi_callback_info info) {  // windowSize, src/msm-common.ts:8-41
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  msm_ctx* ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  uint32_t n = 0;
+  msm_opts opts;
+  memset(&opts, 0, sizeof opts);
+  napi_get_value_uint32(env, argv[1], &n);
+  if (argc > 2) napi_get_value_int32(env, argv[2], &opts.c);
+  int32_t c = 0, K = 0;
+  int rc = msm_plan(ctx, n, &opts, &c, &K);
+  if (rc != MSM_OK) return throw_msm(env, ctx, rc, "plan");
+  napi_value out, v;
+  NAPI_OK(napi_create_object(env, &out));
+  NAPI_OK(napi_create_int32(env, c, &v));
+  NAPI_OK(napi_set_named_property(env, out, "c", v));
+  NAPI_OK(napi_create_int32(env, K, &v));
+  NAPI_OK(napi_set_named_property(env, out, "K", v));
+  return out;
+}
+
+NAPI_MODULE_INIT() {
+  struct { const char* name; napi_callback fn; } fns[] = {
+      {"createContext", CreateContext}, {"destroyContext", DestroyContext}, {"setPoints", SetPoints}, {"msm", Msm}, {"plan", Plan}};
+  for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+    napi_value f;
+    if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+    if (napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) return NULL;
+  }
+  napi_value v;
+  napi_create_int32(env, MSM_CURVE_BLS12_377_G1, &v);
+  napi_set_named_property(env, exports, "CURVE_BLS12_377_G1", v);
+  napi_create_int32(env, MSM_CURVE_ED_ON_BLS12_377, &v);
+  napi_set_named_property(env, exports, "CURVE_ED_ON_BLS12_377", v);
+  return exports;
+}

@@ -327,3 +327,15 @@ def test_reference_shaped_api(gpu_ctx):
     r = compute_msm(O.points_to_bytes([P, P], 48), O.scalars_to_bytes([2, C.q - 1]), curve=cv)
     assert (r["x"], r["y"]) == P
     cv.context.close()
+
+
+def test_config1_inputs_2p14_on_gpu(gpu_ctx):
+    """The 2^14 plumbing configuration (BASELINE configs[0]) through the GPU path: same inputs as
+    tests/test_oracle_kat.py::test_config1_msm_basic_2p14_cpu_plumbing, same answer."""
+    base, ks = O.random_points_bls377("cfg1", 256)
+    n = 1 << 14
+    sc = O.prng_ints("cfg1/s", n, C.q)
+    gpu_ctx.set_points(O.points_to_bytes(base, 48) * (n // 256))
+    res, info = gpu_ctx.run(O.scalars_to_bytes(sc))
+    G = (C.gx, C.gy)
+    assert res.as_tuple() == O.aff_scale(sum(s * ks[i & 255] for i, s in enumerate(sc)) % C.q, G, P_MOD), info

@@ -1,0 +1,46 @@
+"""Node N-API shim + JS facade: builds, loads in the image's node, fails loudly
+without a GPU; on a GPU box it runs the reference's ZPrize self-tests and the golden vectors through JS."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE = shutil.which("node")
+
+
+@pytest.fixture(scope="module")
+def addon():
+    if NODE is None or not os.path.exists("/usr/include/node/node_api.h"):
+        pytest.skip("node / node_api.h not present")
+    subprocess.check_call(["make", "-C", ROOT, "-s", "all", "napi"])
+    return os.path.join(ROOT, "montgomery_amd", "msm_hip.node")
+
+
+def test_addon_loads_and_exports(addon):
+    out = subprocess.run([NODE, "-e", "const m=require('./js/montgomery-hip.js');console.log(Object.keys(m.hip).sort().join(','))"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    names = out.stdout.strip().split(",")
+    for n in ("createContext", "destroyContext", "setPoints", "msm", "plan"):
+        assert n in names
+
+
+def test_addon_fails_loudly_without_gpu(addon):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    code = ("const m=require('./js/montgomery-hip.js');"
+            "try{m.Weierstrass.create(m.bls12377Params);console.log('CREATED')}catch(e){console.log('THROWN '+e.message)}")
+    out = subprocess.run([NODE, "-e", code], cwd=ROOT, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.startswith("THROWN") and "msm error 5" in out.stdout
+
+
+@pytest.mark.gpu
+def test_js_facade_on_gpu(addon):
+    out = subprocess.run([NODE, "js/test-compute-msm.js"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ALL OK" in out.stdout

@@ -193,3 +193,19 @@ def test_c_oracle_n4096_known_logs(c_oracle):
     sc = O.prng_ints(d["seed_scalars"], d["n"], C.q)
     got, _ = c_oracle.msm_bls377(O.points_to_bytes(pts, 48), O.scalars_to_bytes(sc), 0)
     assert got == (H(d["result"][0]), H(d["result"][1]))
+
+
+def test_config1_msm_basic_2p14_cpu_plumbing(c_oracle):
+    """BASELINE configs[0]: 2^14 BLS12-377 G1 MSM via the msm-basic algorithm (`msmProjective`,
+    src/parallel.ts:69-87: full 253-bit scalars, no GLV, c = 13, K = 20) on the CPU, single thread --
+    the oracle's restatement against the known discrete logs and against the batched-affine C port."""
+    base, ks = O.random_points_bls377("cfg1", 256)
+    n = 1 << 14
+    sc = O.prng_ints("cfg1/s", n, C.q)
+    pts = [base[i & 255] for i in range(n)]
+    assert O.window_size_reference(377, 14) == 13
+    got = O.msm_basic_projective(sc, pts)
+    G = (C.gx, C.gy)
+    assert got == O.aff_scale(sum(s * ks[i & 255] for i, s in enumerate(sc)) % C.q, G, C.p)
+    ref, _ = c_oracle.msm_bls377(O.points_to_bytes(pts, 48), O.scalars_to_bytes(sc), 0)
+    assert ref == got
