@@ -56,7 +56,7 @@ struct msm_ctx {
   uint64_t n_points = 0;
 
   // workspace
-  DevBuf scal, dig, counts, cursor, tail_off, info, slots, block_hist, bufA, bufB, scratch, columns, partials, errflag, misc;
+  DevBuf scal, dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, bufA, bufB, scratch, columns, partials, errflag, misc;
   uint32_t* h_info = nullptr;      // pinned
   uint32_t* h_partials = nullptr;  // pinned, up to 64 windows x 36 words
   uint64_t ws_budget = 0;          // bytes the tree buffers of one window group may take
@@ -222,13 +222,41 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
     hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)ctx->block_hist.p,
                        (uint32_t*)ctx->counts.p, sortB, L, (uint32_t)kc);
   }
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, (const uint32_t*)ctx->counts.p, (uint32_t)nb, logG,
-                     (uint32_t*)ctx->cursor.p, (uint32_t*)ctx->tail_off.p, (uint32_t*)ctx->info.p);
-  HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->info.p, 64 * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  const uint64_t total_slots = ctx->h_info[0];
-  const uint32_t max_bucket = ctx->h_info[1];
-  const int RT = (int)ctx->h_info[2];
+  int RT = 0;
+  uint64_t total_slots = 0;
+  uint32_t max_bucket = 0;
+  if (lds_sort) {
+    // largest bucket -> number of tail rounds (first of two small read-backs), then the multi-block scan
+    HIPCHK(hipMemsetAsync(ctx->info.p, 0, 64 * 4, s));
+    hipLaunchKernelGGL(k_bucket_max, dim3((uint32_t)std::min<uint64_t>(1024, (nb + 255) / 256)), dim3(256), 0, s,
+                       (const uint32_t*)ctx->counts.p, (uint32_t)nb, (uint32_t*)ctx->info.p);
+    HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->info.p, 4 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    max_bucket = ctx->h_info[1];
+    uint32_t capmax = (max_bucket + (1u << logG) - 1) >> logG;
+    while ((1u << RT) < capmax) RT++;
+    const int nq = RT + 2;
+    const uint32_t nblocks = (uint32_t)((nb + PS_SPAN - 1) / PS_SPAN);
+    ctx->ensure(ctx->scan_partial, (size_t)nq * nblocks * 4);
+    hipLaunchKernelGGL(k_pscan_partial, dim3(nblocks), dim3(PS_BLOCK), 0, s, (const uint32_t*)ctx->counts.p, (uint32_t)nb, logG, nq,
+                       (uint32_t*)ctx->scan_partial.p, nblocks);
+    hipLaunchKernelGGL(k_pscan_top, dim3(1), dim3(SCAN_THREADS), 0, s, (uint32_t*)ctx->scan_partial.p, nblocks, nq,
+                       (uint32_t*)ctx->info.p);
+    hipLaunchKernelGGL(k_pscan_final, dim3(nblocks), dim3(PS_BLOCK), 0, s, (const uint32_t*)ctx->counts.p, (uint32_t)nb, logG, nq,
+                       (const uint32_t*)ctx->scan_partial.p, nblocks, (uint32_t*)ctx->cursor.p, (uint32_t*)ctx->tail_off.p,
+                       (const uint32_t*)ctx->info.p);
+    HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->info.p, 64 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    total_slots = ctx->h_info[0];
+  } else {
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, (const uint32_t*)ctx->counts.p, (uint32_t)nb, logG,
+                       (uint32_t*)ctx->cursor.p, (uint32_t*)ctx->tail_off.p, (uint32_t*)ctx->info.p);
+    HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->info.p, 64 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    total_slots = ctx->h_info[0];
+    max_bucket = ctx->h_info[1];
+    RT = (int)ctx->h_info[2];
+  }
   st.max_bucket = std::max<uint64_t>(st.max_bucket, max_bucket);
 
   // scatter
@@ -317,6 +345,12 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
       a.off_in = (const uint32_t*)ctx->tail_off.p + (uint64_t)(r - 1) * (nb + 1);
       a.off_out = (const uint32_t*)ctx->tail_off.p + (uint64_t)r * (nb + 1);
       a.nb = (uint32_t)nb;
+      if (n_out) {
+        ctx->ensure(ctx->desc, n_out * 4);
+        hipLaunchKernelGGL(k_tail_desc, dim3((uint32_t)((n_out + 255) / 256)), dim3(256), 0, s, (uint32_t*)ctx->desc.p, a.off_in,
+                           a.off_out, (uint32_t)nb, (uint32_t)n_out);
+        a.desc = (const uint32_t*)ctx->desc.p;
+      }
       if (te) hipLaunchKernelGGL(te::k_te_add<MODE_SEARCH>, dim3(g.grid), dim3(256), 0, s, a);
       else hipLaunchKernelGGL(k_batch_add<MODE_SEARCH>, dim3(g.grid), dim3(256), 0, s, a);
       st.n_pairs += n_out;
@@ -551,7 +585,7 @@ void msm_ctx_destroy(msm_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
-  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->dig, &ctx->counts, &ctx->cursor, &ctx->tail_off, &ctx->info, &ctx->slots, &ctx->block_hist,
+  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->dig, &ctx->counts, &ctx->cursor, &ctx->tail_off, &ctx->info, &ctx->slots, &ctx->block_hist, &ctx->scan_partial, &ctx->desc,
                     &ctx->bufA, &ctx->bufB, &ctx->scratch, &ctx->columns, &ctx->partials, &ctx->errflag, &ctx->misc})
     ctx->release(*b);
   if (ctx->h_info) hipHostFree(ctx->h_info);

@@ -302,6 +302,117 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(const uint32_t* counts, u
 }
 
 // ---------------------------------------------------------------------------------------------
+// Multi-block scan of the bucket sizes (replaces the single-workgroup k_scan on the LDS-sort path):
+//   quantity 0      : padded slot count  roundup(n, G)          -> cursor (slot offsets), total -> info[0]
+//   quantity 1 + r  : ceil(ceil(n / G) / 2^r), r = 0..RT          -> tail_off[r] (nb + 1 entries), totals -> info[3 + r]
+// k_pscan_partial sums each quantity per block of PS_BLOCK * PS_ITEMS buckets, k_pscan_top scans the
+// block sums (one workgroup), k_pscan_final rescans each block with its base.  k_bucket_max gives the
+// largest bucket (host needs RT before it can size this scan).
+// ---------------------------------------------------------------------------------------------
+
+constexpr int PS_BLOCK = 256;
+constexpr int PS_ITEMS = 16;
+constexpr int PS_SPAN = PS_BLOCK * PS_ITEMS;
+
+MSM_DEV uint32_t scan_quantity(uint32_t n, uint32_t logG, int q) {
+  const uint32_t cg = (n + ((1u << logG) - 1)) >> logG;
+  if (q == 0) return cg << logG;
+  const int r = q - 1;
+  return (cg + ((1u << r) - 1)) >> r;
+}
+
+__global__ void __launch_bounds__(256) k_bucket_max(const uint32_t* counts, uint32_t nb, uint32_t* info) {
+  __shared__ uint32_t lds_max;
+  if (threadIdx.x == 0) lds_max = 0;
+  __syncthreads();
+  uint32_t mx = 0;
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) mx = max(mx, counts[b]);
+  atomicMax(&lds_max, mx);
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(&info[1], lds_max);
+}
+
+__global__ void __launch_bounds__(PS_BLOCK) k_pscan_partial(const uint32_t* counts, uint32_t nb, uint32_t logG, int nq,
+                                                            uint32_t* partial, uint32_t nblocks) {
+  __shared__ uint32_t lds_wave[PS_BLOCK / 64];
+  const uint32_t b0 = blockIdx.x * PS_SPAN + threadIdx.x * PS_ITEMS;
+  uint32_t n[PS_ITEMS];
+#pragma unroll
+  for (int j = 0; j < PS_ITEMS; j++) n[j] = (b0 + j) < nb ? counts[b0 + j] : 0u;
+  for (int q = 0; q < nq; q++) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < PS_ITEMS; j++) sum += scan_quantity(n[j], logG, q);
+    uint32_t tot;
+    block_excl_scan(sum, lds_wave, tot);
+    if (threadIdx.x == 0) partial[(uint64_t)q * nblocks + blockIdx.x] = tot;
+  }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_pscan_top(uint32_t* partial, uint32_t nblocks, int nq, uint32_t* info) {
+  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
+  for (int q = 0; q < nq; q++) {
+    uint32_t* p = partial + (uint64_t)q * nblocks;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblocks; base += SCAN_THREADS) {
+      uint32_t i = base + threadIdx.x;
+      uint32_t v = i < nblocks ? p[i] : 0u;
+      uint32_t tot;
+      uint32_t ex = block_excl_scan(v, lds_wave, tot) + carry;
+      if (i < nblocks) p[i] = ex;
+      carry += tot;
+    }
+    if (threadIdx.x == 0) {
+      if (q == 0) info[0] = carry; else info[3 + (q - 1)] = carry;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(PS_BLOCK) k_pscan_final(const uint32_t* counts, uint32_t nb, uint32_t logG, int nq,
+                                                          const uint32_t* partial, uint32_t nblocks, uint32_t* cursor,
+                                                          uint32_t* tail_off, const uint32_t* info) {
+  __shared__ uint32_t lds_wave[PS_BLOCK / 64];
+  const uint32_t b0 = blockIdx.x * PS_SPAN + threadIdx.x * PS_ITEMS;
+  uint32_t n[PS_ITEMS];
+#pragma unroll
+  for (int j = 0; j < PS_ITEMS; j++) n[j] = (b0 + j) < nb ? counts[b0 + j] : 0u;
+  for (int q = 0; q < nq; q++) {
+    uint32_t v[PS_ITEMS], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PS_ITEMS; j++) { v[j] = scan_quantity(n[j], logG, q); sum += v[j]; }
+    uint32_t tot;
+    uint32_t ex = block_excl_scan(sum, lds_wave, tot) + partial[(uint64_t)q * nblocks + blockIdx.x];
+    uint32_t* out = q == 0 ? cursor : tail_off + (uint64_t)(q - 1) * (nb + 1);
+#pragma unroll
+    for (int j = 0; j < PS_ITEMS; j++) {
+      if (b0 + j < nb) out[b0 + j] = ex;
+      ex += v[j];
+    }
+    if (q > 0 && blockIdx.x == 0 && threadIdx.x == 0) out[nb] = info[3 + (q - 1)];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tail_desc: per tail round, the operand locations of every output element, found once by binary
+// search here (thousands of resident waves hide the dependent loads) instead of twice per pair inside
+// the latency-critical batch-add kernel.  desc[e] = (index of the first operand << 1) | second operand present.
+// ---------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_tail_desc(uint32_t* desc, const uint32_t* off_in, const uint32_t* off_out, uint32_t nb,
+                                                   uint32_t n_out) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_out) return;
+  uint32_t lo = 0, hi = nb;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (off_out[mid] <= e) lo = mid; else hi = mid;
+  }
+  uint32_t j = e - off_out[lo];
+  uint32_t ia = off_in[lo] + 2 * j;
+  desc[e] = (ia << 1) | ((ia + 1) < off_in[lo + 1] ? 1u : 0u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_scatter: digits -> bucket-ordered payload slots (order inside a bucket is arbitrary; the
 // bucket sum does not depend on it)
 // ---------------------------------------------------------------------------------------------
@@ -407,6 +518,7 @@ struct BatchArgs {
   const uint32_t* off_in;   // MODE_SEARCH: bucket offsets of the input / output round
   const uint32_t* off_out;
   uint32_t nb;
+  const uint32_t* desc;     // MODE_SEARCH: operand descriptors from k_tail_desc (replaces the search when set)
 };
 
 // One operand of a pair: where it lives and how to read it.
@@ -433,6 +545,11 @@ MSM_DEV void locate(const BatchArgs& a, uint64_t e, Side& A, Side& B) {
     sides_from_payload<MODE>(reinterpret_cast<const uint2*>(a.slots)[e], A, B);
   } else if (MODE == MODE_REGULAR) {
     A.idx = 2 * e; B.idx = 2 * e + 1;
+  } else if (a.desc) {
+    const uint32_t d = a.desc[e];
+    A.idx = d >> 1;
+    B.absent = (d & 1u) == 0;
+    B.idx = B.absent ? A.idx : A.idx + 1;
   } else {
     uint32_t lo = 0, hi = a.nb;
     const uint32_t e32 = (uint32_t)e;

@@ -264,6 +264,10 @@ __global__ void __launch_bounds__(256) k_te_add(BatchArgs a) {
       bool has_b = true;
       if (MODE == MODE_REGULAR) {
         ia = 2 * e; ib = 2 * e + 1;
+      } else if (a.desc) {
+        const uint32_t d = a.desc[e];
+        ia = d >> 1; ib = ia + 1;
+        has_b = (d & 1u) != 0;
       } else {
         uint32_t lo = 0, hi = a.nb;
         const uint32_t e32 = (uint32_t)e;
