@@ -56,7 +56,7 @@ struct msm_ctx {
   uint64_t n_points = 0;
 
   // workspace
-  DevBuf scal, dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, bufA, bufB, scratch, columns, partials, errflag, misc;
+  DevBuf scal, dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, columns2, rows_sum, bufA, bufB, scratch, columns, partials, errflag, misc;
   uint32_t* h_info = nullptr;      // pinned
   uint32_t* h_partials = nullptr;  // pinned, up to 64 windows x 36 words
   uint64_t ws_budget = 0;          // bytes the tree buffers of one window group may take
@@ -164,6 +164,25 @@ RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out) {
   uint64_t threads = (n_out + steps - 1) / steps;
   uint64_t grid = std::max<uint64_t>(1, (threads + 255) / 256);
   return RoundGeom{(uint32_t)steps, (uint32_t)grid, grid * 256};
+}
+
+void words_to_fe6(msm_host::Fe6& r, const uint32_t* w) {
+  for (int i = 0; i < 6; i++) r.v[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+}
+
+void fe6_to_bytes(uint8_t* out, const msm_host::Fe6& a) {
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(a.v[i] >> (8 * j));
+}
+
+// device-Montgomery packed partial (36 words) -> host projective point (host Montgomery form)
+msm_host::Proj6 partial_to_host(const msm_ctx* ctx, const uint32_t* w) {
+  msm_host::Proj6 P;
+  msm_host::Fe6 t;
+  words_to_fe6(t, w);      ctx->hc.F.mul(P.X, t, ctx->k_dev_to_host);
+  words_to_fe6(t, w + 12); ctx->hc.F.mul(P.Y, t, ctx->k_dev_to_host);
+  words_to_fe6(t, w + 24); ctx->hc.F.mul(P.Z, t, ctx->k_dev_to_host);
+  return P;
 }
 
 // Partition sums P_k for windows [k_lo, k_hi) -> ctx->h_partials[(k - k_lo) * 36 ...]
@@ -369,6 +388,10 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
   uint32_t TC = (uint32_t)std::max<uint64_t>(2, (nb + 65535) / 65536);
   TC = std::min<uint32_t>(TC, L);
   uint32_t nchunks = (L + TC - 1) / TC;
+  // bit-sliced weighting (Weierstrass path, enough chunks to matter, TC a power of two)
+  uint32_t nbits = 0;
+  while ((1u << nbits) < nchunks) nbits++;
+  const bool bit_sliced = !te && nchunks >= 64 && (TC & (TC - 1)) == 0;
   ctx->ensure(ctx->columns, (size_t)kc * nchunks * 4 * NL * 4);
   ctx->ensure(ctx->partials, (size_t)kc * 36 * 4);
   {
@@ -378,12 +401,72 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
                          off_fin, L, TC, nchunks, (uint32_t)kc);
       hipLaunchKernelGGL(te::k_te_window_sum, dim3(kc), dim3(te::TE_WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
                          (const uint32_t*)ctx->columns.p, nchunks);
+    } else if (bit_sliced) {
+      ctx->ensure(ctx->rows_sum, (size_t)kc * nchunks * 3 * NL * 4);
+      hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)ctx->columns.p,
+                         (uint32_t*)ctx->rows_sum.p, fin, fin_cap, off_fin, L, TC, nchunks, (uint32_t)kc);
+      const uint32_t per_block = 2 * WS_THREADS;
+      const uint32_t nblk = (nchunks + per_block - 1) / per_block;
+      ctx->ensure(ctx->columns2, (size_t)kc * (nbits + 1) * nblk * 3 * NL * 4);
+      ctx->ensure(ctx->partials, (size_t)kc * (nbits + 1) * 36 * 4);
+      hipLaunchKernelGGL(k_bit_tree, dim3(nblk, nbits + 1, kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->columns2.p,
+                         (const uint32_t*)ctx->rows_sum.p, (const uint32_t*)ctx->columns.p, nchunks, per_block, nbits, 1, 0);
+      hipLaunchKernelGGL(k_bit_tree, dim3(1, nbits + 1, kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
+                         (const uint32_t*)ctx->columns2.p, (const uint32_t*)nullptr, nblk, nblk, nbits, 0, 1);
     } else {
-      hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)ctx->columns.p, fin, fin_cap,
-                         off_fin, L, TC, nchunks, (uint32_t)kc);
-      hipLaunchKernelGGL(k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
-                         (const uint32_t*)ctx->columns.p, nchunks);
+      hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)ctx->columns.p, (uint32_t*)nullptr,
+                         fin, fin_cap, off_fin, L, TC, nchunks, (uint32_t)kc);
+      if (nchunks > 2 * WS_THREADS) {
+        // two-stage: blocks of 2 columns per lane, then one block per window over the block sums
+        const uint32_t per_block = 2 * WS_THREADS;
+        const uint32_t nblk = (nchunks + per_block - 1) / per_block;
+        ctx->ensure(ctx->columns2, (size_t)kc * nblk * 3 * NL * 4);
+        hipLaunchKernelGGL(k_column_tree, dim3(nblk, kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->columns2.p,
+                           (const uint32_t*)ctx->columns.p, nchunks, per_block);
+        hipLaunchKernelGGL(k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
+                           (const uint32_t*)ctx->columns2.p, nblk);
+      } else {
+        hipLaunchKernelGGL(k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
+                           (const uint32_t*)ctx->columns.p, nchunks);
+      }
     }
+  }
+  if (bit_sliced) {
+    // read the (nbits + 1) sums per window back and finish P_k = tri + TC * sum_b 2^b S_b on the host
+    HIPCHK(hipMemcpyAsync(ctx->h_partials, ctx->partials.p, (size_t)kc * (nbits + 1) * 36 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(ctx->ev[4], s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    const auto& C = ctx->hc;
+    for (int kk = 0; kk < kc; kk++) {
+      const uint32_t* base = ctx->h_partials + (size_t)kk * (nbits + 1) * 36;
+      msm_host::Proj6 acc = C.zero();
+      for (int b = (int)nbits - 1; b >= 0; b--) {
+        acc = C.dbl(acc);
+        acc = C.add(acc, partial_to_host(ctx, base + (size_t)b * 36));
+      }
+      for (uint32_t t = TC; t > 1; t >>= 1) acc = C.dbl(acc);   // TC is a power of two on this path
+      acc = C.add(acc, partial_to_host(ctx, base + (size_t)nbits * 36));
+      // back to the packed device-Montgomery form the rest of the pipeline carries (x 2^6: 2^384 -> 2^390)
+      msm_host::Fe6* co[3] = {&acc.X, &acc.Y, &acc.Z};
+      for (int j = 0; j < 3; j++) {
+        msm_host::Fe6 t = *co[j];
+        for (int d = 0; d < 6; d++) C.F.add(t, t, t);
+        msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
+        C.F.mul(t, t, one);
+        for (int q = 0; q < 6; q++) {
+          h_partials_out[(size_t)kk * 36 + 12 * j + 2 * q] = (uint32_t)t.v[q];
+          h_partials_out[(size_t)kk * 36 + 12 * j + 2 * q + 1] = (uint32_t)(t.v[q] >> 32);
+        }
+      }
+    }
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); st.ms_digits += ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2])); st.ms_sort += ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); st.ms_acc += ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[6])); st.ms_r1 += ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); st.ms_red += ms;
+    return;
   }
   HIPCHK(hipMemcpyAsync(h_partials_out, ctx->partials.p, (size_t)kc * part_words * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipEventRecord(ctx->ev[4], s));
@@ -404,25 +487,6 @@ int windows_per_group(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
                                  : (long double)n * (8 + 9 + 96 + 48 + 56) + (long double)pl.L * 4 * 40;
   int w = (int)std::max<long double>(1, (long double)ctx->ws_budget / per);
   return std::min(w, pl.K);
-}
-
-void words_to_fe6(msm_host::Fe6& r, const uint32_t* w) {
-  for (int i = 0; i < 6; i++) r.v[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
-}
-
-void fe6_to_bytes(uint8_t* out, const msm_host::Fe6& a) {
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(a.v[i] >> (8 * j));
-}
-
-// device-Montgomery packed partial (36 words) -> host projective point (host Montgomery form)
-msm_host::Proj6 partial_to_host(const msm_ctx* ctx, const uint32_t* w) {
-  msm_host::Proj6 P;
-  msm_host::Fe6 t;
-  words_to_fe6(t, w);      ctx->hc.F.mul(P.X, t, ctx->k_dev_to_host);
-  words_to_fe6(t, w + 12); ctx->hc.F.mul(P.Y, t, ctx->k_dev_to_host);
-  words_to_fe6(t, w + 24); ctx->hc.F.mul(P.Z, t, ctx->k_dev_to_host);
-  return P;
 }
 
 // S = sum_k 2^(ck) P_k, then affine (src/msm-batched-affine.ts:322-333, src/curve-projective.ts:335-349)
@@ -556,7 +620,7 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipHostMalloc((void**)&ctx->h_info, 64 * 4, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_partials, 128 * 36 * 4, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_partials, 128 * 20 * 36 * 4, hipHostMallocDefault));
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     // leave room for the resident points (144 B/point at 2^26 = 9.7 GB) and fragmentation
@@ -585,7 +649,7 @@ void msm_ctx_destroy(msm_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
-  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->dig, &ctx->counts, &ctx->cursor, &ctx->tail_off, &ctx->info, &ctx->slots, &ctx->block_hist, &ctx->scan_partial, &ctx->desc,
+  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->dig, &ctx->counts, &ctx->cursor, &ctx->tail_off, &ctx->info, &ctx->slots, &ctx->block_hist, &ctx->scan_partial, &ctx->desc, &ctx->columns2, &ctx->rows_sum,
                     &ctx->bufA, &ctx->bufB, &ctx->scratch, &ctx->columns, &ctx->partials, &ctx->errflag, &ctx->misc})
     ctx->release(*b);
   if (ctx->h_info) hipHostFree(ctx->h_info);

@@ -782,9 +782,12 @@ MSM_DEV void proj_load(Proj<F>& P, const uint32_t* src) {
   for (int l = 0; l < NL; l++) { P.X.l[l] = src[l]; P.Y.l[l] = src[NL + l]; P.Z.l[l] = src[2 * NL + l]; }
 }
 
-__global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, const uint4* fin, uint64_t fin_cap,
-                                                       const uint32_t* off_fin, uint32_t L, uint32_t TC,
-                                                       uint32_t nchunks, uint32_t k_cnt) {
+// rows != nullptr: "bit-sliced" mode -- the chunk's plain sum is written to rows[id] and its local triangle to
+// columns[id]; the weight (lstart - 1) = ch * TC is applied later through per-bit sums (k_bit_tree) instead of a
+// double-and-add chain in every lane.
+__global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, uint32_t* rows, const uint4* fin, uint64_t fin_cap,
+                                                       const uint32_t* off_fin, uint32_t L, uint32_t TC, uint32_t nchunks,
+                                                       uint32_t k_cnt) {
   uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= nchunks * k_cnt) return;
   uint32_t kk = id / nchunks, ch = id - kk * nchunks;
@@ -809,6 +812,11 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, const u
     }
     proj_add_mixed<F>(row, row, Q, qinf);
     proj_add<F>(tri, tri, row);
+  }
+  if (rows) {
+    proj_store(rows + (uint64_t)id * (3 * NL), row);
+    proj_store(columns + (uint64_t)id * (3 * NL), tri);
+    return;
   }
   uint32_t ls = lstart - 1;
   if (ls) {
@@ -879,6 +887,120 @@ __global__ void __launch_bounds__(WS_THREADS) k_window_sum(uint32_t* partials, c
     fe_pack<F>(w, acc.Z);
 #pragma unroll
     for (int j = 0; j < NW; j++) dst[24 + j] = w[j];
+  }
+}
+
+// first stage of the window sum when a window has many chunk columns: block (b, kk) tree-sums columns
+// [b * per_block, (b + 1) * per_block) of window kk into one raw projective point, so that no lane adds more
+// than a couple of columns serially (the sum of 8192 columns drops from 40 dependent additions to ~18)
+__global__ void __launch_bounds__(WS_THREADS) k_column_tree(uint32_t* out, const uint32_t* columns, uint32_t nchunks,
+                                                            uint32_t per_block) {
+  __shared__ uint32_t lds[3 * NL * WS_THREADS];
+  const uint32_t b = blockIdx.x, kk = blockIdx.y, tid = threadIdx.x, nblk = gridDim.x;
+  const uint32_t beg = b * per_block, end = min(beg + per_block, nchunks);
+  Proj<F> acc;
+  proj_set_zero<F>(acc);
+#pragma unroll 1
+  for (uint32_t j = beg + tid; j < end; j += WS_THREADS) {
+    Proj<F> Q;
+    proj_load(Q, columns + ((uint64_t)kk * nchunks + j) * (3 * NL));
+    proj_add<F>(acc, acc, Q);
+  }
+#pragma unroll 1
+  for (uint32_t s = WS_THREADS / 2; s >= 1; s >>= 1) {
+    if (tid >= s && tid < 2 * s) {
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        lds[(l)*WS_THREADS + tid] = acc.X.l[l];
+        lds[(NL + l) * WS_THREADS + tid] = acc.Y.l[l];
+        lds[(2 * NL + l) * WS_THREADS + tid] = acc.Z.l[l];
+      }
+    }
+    __syncthreads();
+    if (tid < s) {
+      Proj<F> Q;
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        Q.X.l[l] = lds[(l)*WS_THREADS + tid + s];
+        Q.Y.l[l] = lds[(NL + l) * WS_THREADS + tid + s];
+        Q.Z.l[l] = lds[(2 * NL + l) * WS_THREADS + tid + s];
+      }
+      proj_add<F>(acc, acc, Q);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) proj_store(out + ((uint64_t)kk * nblk + b) * (3 * NL), acc);
+}
+
+// Bit-sliced weighting of the chunk sums:  sum_ch (ch * TC) * row_ch = TC * sum_b 2^b * S_b  with
+// S_b = sum of row_ch over the chunks whose index has bit b set.  Block (blk, y, kk) tree-sums, for window kk,
+//   y <  nbits : the rows of its slice whose chunk index has bit y set,
+//   y == nbits : the local triangles (columns) of its slice, unmasked.
+// in_stride / masked select between the first stage (chunk arrays) and the second stage (block sums, unmasked).
+// The K * (nbits + 1) results go to the host, which applies the 2^b weights with nbits doublings per window --
+// one chain per window instead of one per lane (the reference applies the same weight by double-and-add per
+// chunk, src/msm-batched-affine.ts:574-580).
+__global__ void __launch_bounds__(WS_THREADS) k_bit_tree(uint32_t* out, const uint32_t* rows, const uint32_t* tris,
+                                                         uint32_t n_in, uint32_t per_block, uint32_t nbits, int masked,
+                                                         int pack_out) {
+  __shared__ uint32_t lds[3 * NL * WS_THREADS];
+  const uint32_t blk = blockIdx.x, y = blockIdx.y, kk = blockIdx.z, tid = threadIdx.x, nblk = gridDim.x;
+  const uint32_t beg = blk * per_block, end = min(beg + per_block, n_in);
+  // first stage: arrays are [kk][n_in]; second stage: [kk][y][n_in]
+  const uint64_t base = masked ? (uint64_t)kk * n_in : ((uint64_t)kk * (nbits + 1) + y) * n_in;
+  const uint32_t* src = (masked && y == nbits) ? tris : rows;
+  Proj<F> acc;
+  proj_set_zero<F>(acc);
+#pragma unroll 1
+  for (uint32_t j = beg + tid; j < end; j += WS_THREADS) {
+    if (masked && y < nbits && !((j >> y) & 1u)) continue;
+    Proj<F> Q;
+    proj_load(Q, src + (base + j) * (3 * NL));
+    proj_add<F>(acc, acc, Q);
+  }
+#pragma unroll 1
+  for (uint32_t s = WS_THREADS / 2; s >= 1; s >>= 1) {
+    if (tid >= s && tid < 2 * s) {
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        lds[(l)*WS_THREADS + tid] = acc.X.l[l];
+        lds[(NL + l) * WS_THREADS + tid] = acc.Y.l[l];
+        lds[(2 * NL + l) * WS_THREADS + tid] = acc.Z.l[l];
+      }
+    }
+    __syncthreads();
+    if (tid < s) {
+      Proj<F> Q;
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        Q.X.l[l] = lds[(l)*WS_THREADS + tid + s];
+        Q.Y.l[l] = lds[(NL + l) * WS_THREADS + tid + s];
+        Q.Z.l[l] = lds[(2 * NL + l) * WS_THREADS + tid + s];
+      }
+      proj_add<F>(acc, acc, Q);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const uint64_t o = ((uint64_t)kk * (nbits + 1) + y) * nblk + blk;
+    if (!pack_out) {
+      proj_store(out + o * (3 * NL), acc);
+    } else {
+      fe_reduce_2p<F>(acc.X);
+      fe_reduce_2p<F>(acc.Y);
+      fe_reduce_2p<F>(acc.Z);
+      uint32_t* dst = out + o * 36;
+      uint32_t w[NW];
+      fe_pack<F>(w, acc.X);
+#pragma unroll
+      for (int j = 0; j < NW; j++) dst[j] = w[j];
+      fe_pack<F>(w, acc.Y);
+#pragma unroll
+      for (int j = 0; j < NW; j++) dst[12 + j] = w[j];
+      fe_pack<F>(w, acc.Z);
+#pragma unroll
+      for (int j = 0; j < NW; j++) dst[24 + j] = w[j];
+    }
   }
 }
 

@@ -8,13 +8,15 @@ import sys, time, json
 sys.path.insert(0, %r)
 from montgomery_amd.api import MsmContext
 lg = int(sys.argv[1]); n = 1 << lg
+import os
+cc = int(os.environ.get('MSM_C', '0')) or None
 ctx = MsmContext()
 ctx.generate_points(n, seed=7)
 dev, _ = ctx.generate_scalars(n, seed=9)
-ctx.run_device(dev, n)
+ctx.run_device(dev, n, c=cc)
 best = None
 for i in range(4):
-    t = time.perf_counter(); r, info = ctx.run_device(dev, n); dt = time.perf_counter() - t
+    t = time.perf_counter(); r, info = ctx.run_device(dev, n, c=cc); dt = time.perf_counter() - t
     if best is None or dt < best[0]: best = (dt, info)
 print(json.dumps({"ms": best[0] * 1e3, "x": hex(r.x)[:18], "phase": {k: round(v, 2) for k, v in best[1]["phase_ms"].items()}, "c": best[1]["c"]}))
 ''' % ROOT
@@ -22,7 +24,7 @@ print(json.dumps({"ms": best[0] * 1e3, "x": hex(r.x)[:18], "phase": {k: round(v,
 def main():
     lg = sys.argv[1]
     libs = sys.argv[2:]
-    for rep in range(2):
+    for rep in range(int(os.environ.get('AB_REPS', '2'))):
         for lib in libs:
             env = dict(os.environ)
             if lib != "-":
