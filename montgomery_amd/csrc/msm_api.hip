@@ -56,7 +56,7 @@ struct msm_ctx {
   uint64_t n_points = 0;
 
   // workspace
-  DevBuf scal, dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, columns2, rows_sum, bufA, bufB, scratch, columns, partials, errflag, misc;
+  DevBuf scal, dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, columns2, rows_sum, bucket_proj, bufA, bufB, scratch, columns, partials, errflag, misc;
   uint32_t* h_info = nullptr;      // pinned
   uint32_t* h_partials = nullptr;  // pinned, up to 64 windows x 36 words
   uint64_t ws_budget = 0;          // bytes the tree buffers of one window group may take
@@ -199,10 +199,11 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
   const size_t elem_bytes = te ? 128 : 96;  // tree node: extended (X, Y, Z, T) x 32 B, or affine (x, y) x 48 B
   const int part_words = te ? 32 : 36;
 
-  // padding granule G = 2^g: about 1/16 of the mean bucket population
+  // padding granule G = 2^g: about 1/8 of the mean bucket population (pads cost G/2 slots per bucket; what is
+  // left after g regular rounds, ~8 elements per bucket, is finished without inversions by k_bucket_finish)
   uint64_t mean = std::max<uint64_t>(1, two_n / L);
   uint32_t logG = 1;
-  while (logG < 10 && (1ull << (logG + 1)) * 16 <= mean) logG++;
+  while (logG < 10 && (1ull << (logG + 1)) * 8 <= mean) logG++;
 
   ctx->ensure(ctx->dig, n_entries * 4);
   ctx->ensure(ctx->counts, nb * 4);
@@ -293,6 +294,15 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
   HIPCHK(hipEventRecord(ctx->ev[2], s));
 
   // accumulation tree
+  // Weierstrass: tail rounds run only until no bucket holds more than FINISH_MAX elements; k_bucket_finish ends it
+  const uint32_t FINISH_MAX = 32;
+  const bool use_finish = !te;
+  int r_stop = RT;
+  if (use_finish) {
+    uint32_t cap_elems = (max_bucket + (1u << logG) - 1) >> logG;   // largest bucket after the regular rounds
+    r_stop = 0;
+    while (r_stop < RT && ((cap_elems + (1u << r_stop) - 1) >> r_stop) > FINISH_MAX) r_stop++;
+  }
   // outputs alternate between two buffers: size each for the largest round it receives
   uint64_t capA = 1, capB = 1;
   {
@@ -303,7 +313,7 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
       (which ? capB : capA) = std::max<uint64_t>(which ? capB : capA, cnt);
       which ^= 1;
     }
-    for (int r = 1; r <= RT; r++) {
+    for (int r = 1; r <= r_stop; r++) {
       cnt = ctx->h_info[3 + r];
       (which ? capB : capA) = std::max<uint64_t>(which ? capB : capA, cnt);
       which ^= 1;
@@ -349,7 +359,7 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
       n_in = n_out;
       round++;
     }
-    for (int r = 1; r <= RT; r++) {
+    for (int r = 1; r <= r_stop; r++) {
       uint64_t n_out = ctx->h_info[3 + r];
       RoundGeom g = round_geom(ctx, n_out);
       if (!te) ctx->ensure(ctx->scratch, (size_t)g.steps * NL * g.T * 4);
@@ -378,9 +388,16 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
       cur ^= 1;
       round++;
     }
-    off_fin = (const uint32_t*)ctx->tail_off.p + (uint64_t)RT * (nb + 1);
+    off_fin = (const uint32_t*)ctx->tail_off.p + (uint64_t)r_stop * (nb + 1);
   }
   st.rounds = round;
+  const uint32_t* bucket_proj = nullptr;
+  if (use_finish && total_slots > 0) {
+    ctx->ensure(ctx->bucket_proj, nb * 3 * NL * 4);
+    hipLaunchKernelGGL(k_bucket_finish, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)ctx->bucket_proj.p, fin,
+                       fin_cap, off_fin, (uint32_t)nb);
+    bucket_proj = (const uint32_t*)ctx->bucket_proj.p;
+  }
   if (total_slots == 0) HIPCHK(hipEventRecord(ctx->ev[6], s));
   HIPCHK(hipEventRecord(ctx->ev[3], s));
 
@@ -404,7 +421,7 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
     } else if (bit_sliced) {
       ctx->ensure(ctx->rows_sum, (size_t)kc * nchunks * 3 * NL * 4);
       hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)ctx->columns.p,
-                         (uint32_t*)ctx->rows_sum.p, fin, fin_cap, off_fin, L, TC, nchunks, (uint32_t)kc);
+                         (uint32_t*)ctx->rows_sum.p, fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
       const uint32_t per_block = 2 * WS_THREADS;
       const uint32_t nblk = (nchunks + per_block - 1) / per_block;
       ctx->ensure(ctx->columns2, (size_t)kc * (nbits + 1) * nblk * 3 * NL * 4);
@@ -415,7 +432,7 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
                          (const uint32_t*)ctx->columns2.p, (const uint32_t*)nullptr, nblk, nblk, nbits, 0, 1);
     } else {
       hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)ctx->columns.p, (uint32_t*)nullptr,
-                         fin, fin_cap, off_fin, L, TC, nchunks, (uint32_t)kc);
+                         fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
       if (nchunks > 2 * WS_THREADS) {
         // two-stage: blocks of 2 columns per lane, then one block per window over the block sums
         const uint32_t per_block = 2 * WS_THREADS;
@@ -649,7 +666,7 @@ void msm_ctx_destroy(msm_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
-  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->dig, &ctx->counts, &ctx->cursor, &ctx->tail_off, &ctx->info, &ctx->slots, &ctx->block_hist, &ctx->scan_partial, &ctx->desc, &ctx->columns2, &ctx->rows_sum,
+  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->dig, &ctx->counts, &ctx->cursor, &ctx->tail_off, &ctx->info, &ctx->slots, &ctx->block_hist, &ctx->scan_partial, &ctx->desc, &ctx->columns2, &ctx->rows_sum, &ctx->bucket_proj,
                     &ctx->bufA, &ctx->bufB, &ctx->scratch, &ctx->columns, &ctx->partials, &ctx->errflag, &ctx->misc})
     ctx->release(*b);
   if (ctx->h_info) hipHostFree(ctx->h_info);

@@ -782,12 +782,41 @@ MSM_DEV void proj_load(Proj<F>& P, const uint32_t* src) {
   for (int l = 0; l < NL; l++) { P.X.l[l] = src[l]; P.Y.l[l] = src[NL + l]; P.Z.l[l] = src[2 * NL + l]; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_bucket_finish: once every bucket is down to a handful of elements the remaining tree rounds are pure
+// latency (one shared inversion per launch for a few additions per lane).  This kernel ends the accumulation
+// in one launch instead: one lane per bucket sums its remaining affine elements with mixed projective
+// additions -- no inversion at all -- and leaves the bucket sum in projective form for k_bucket_reduce.
+// ---------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_bucket_finish(uint32_t* bucket_proj, const uint4* in, uint64_t in_cap,
+                                                       const uint32_t* off, uint32_t nb) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const uint32_t o0 = off[b], o1 = off[b + 1];
+  Proj<F> acc;
+  proj_set_zero<F>(acc);
+#pragma unroll 1
+  for (uint32_t o = o0; o < o1; o++) {
+    Proj<F> Q;
+    uint32_t w[NW];
+    load_planes3(w, in, in_cap, 0, o);
+    bool qinf = w[NW - 1] == INF_WORD;
+    fe_unpack<F>(Q.X, w);
+    load_planes3(w, in, in_cap, 3, o);
+    fe_unpack<F>(Q.Y, w);
+    proj_add_mixed<F>(acc, acc, Q, qinf);
+  }
+  proj_store(bucket_proj + (uint64_t)b * (3 * NL), acc);
+}
+
 // rows != nullptr: "bit-sliced" mode -- the chunk's plain sum is written to rows[id] and its local triangle to
 // columns[id]; the weight (lstart - 1) = ch * TC is applied later through per-bit sums (k_bit_tree) instead of a
 // double-and-add chain in every lane.
+// bucket_proj != nullptr: bucket sums come from k_bucket_finish (projective, one per bucket) instead of the tree buffer
 __global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, uint32_t* rows, const uint4* fin, uint64_t fin_cap,
-                                                       const uint32_t* off_fin, uint32_t L, uint32_t TC, uint32_t nchunks,
-                                                       uint32_t k_cnt) {
+                                                       const uint32_t* off_fin, const uint32_t* bucket_proj, uint32_t L,
+                                                       uint32_t TC, uint32_t nchunks, uint32_t k_cnt) {
   uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= nchunks * k_cnt) return;
   uint32_t kk = id / nchunks, ch = id - kk * nchunks;
@@ -799,18 +828,23 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, uint32_
 #pragma unroll 1
   for (uint32_t l = lend; l >= lstart; l--) {
     uint64_t b = (uint64_t)kk * L + (l - 1);
-    uint32_t o0 = off_fin[b], o1 = off_fin[b + 1];
     Proj<F> Q;
-    bool qinf = true;
-    if (o1 > o0) {
-      uint32_t w[NW];
-      load_planes3(w, fin, fin_cap, 0, o0);
-      qinf = w[NW - 1] == INF_WORD;
-      fe_unpack<F>(Q.X, w);
-      load_planes3(w, fin, fin_cap, 3, o0);
-      fe_unpack<F>(Q.Y, w);
+    if (bucket_proj) {
+      proj_load(Q, bucket_proj + b * (3 * NL));
+      proj_add<F>(row, row, Q);
+    } else {
+      uint32_t o0 = off_fin[b], o1 = off_fin[b + 1];
+      bool qinf = true;
+      if (o1 > o0) {
+        uint32_t w[NW];
+        load_planes3(w, fin, fin_cap, 0, o0);
+        qinf = w[NW - 1] == INF_WORD;
+        fe_unpack<F>(Q.X, w);
+        load_planes3(w, fin, fin_cap, 3, o0);
+        fe_unpack<F>(Q.Y, w);
+      }
+      proj_add_mixed<F>(row, row, Q, qinf);
     }
-    proj_add_mixed<F>(row, row, Q, qinf);
     proj_add<F>(tri, tri, row);
   }
   if (rows) {
