@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--c", type=int, default=0)
     ap.add_argument("--cpu-log2n", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (functional check of the sharded path on one GPU)")
     ap.add_argument("--curve", choices=["bls12-377", "ed377"], default="bls12-377",
                     help="ed377 = BASELINE configs[3]: twisted Edwards msmBasic path (single GPU, use --log2n 20)")
     args = ap.parse_args()
@@ -134,8 +135,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if local_rank >= torch.cuda.device_count():   # several ranks on one GPU: only meaningful with --dist-backend gloo
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0 and world > 1:
@@ -167,7 +173,7 @@ def main():
             parts, box["info"] = ctx.window_sums(scal[i].data_ptr(), n, lo, hi, c=c, on_device=True)
             return parts
 
-        out = sharded_msm(my_window_sums, K, c, device=dev)
+        out = sharded_msm(my_window_sums, K, c, device=dev if args.dist_backend == "nccl" else "cpu")
         res = None
         if out is not None:
             xy = out[1]
@@ -191,7 +197,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
