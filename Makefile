@@ -3,7 +3,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := montgomery_amd/csrc
 LIB := montgomery_amd/libmsm_hip.so
-HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function -Wno-unused-variable \
+HIPFLAGS := -O3 -pthread -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function -Wno-unused-variable \
             -Iinclude -I$(CSRC)
 
 all: $(LIB)

@@ -11,7 +11,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace msm;
@@ -55,11 +57,25 @@ struct msm_ctx {
   DevBuf rows;
   uint64_t n_points = 0;
 
-  // workspace
-  DevBuf scal, dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, columns2, rows_sum, bucket_proj, bufA, bufB, scratch, columns, partials, errflag, misc;
+  // staging / misc buffers shared by all window groups
+  DevBuf scal, errflag, misc;
   uint32_t* h_info = nullptr;      // pinned
-  uint32_t* h_partials = nullptr;  // pinned, up to 64 windows x 36 words
-  uint64_t ws_budget = 0;          // bytes the tree buffers of one window group may take
+  uint64_t ws_budget = 0;          // bytes the per-group workspaces may take in total
+
+  // per-group workspace: two of them, each with its own stream, so that the memory-bound sort of one
+  // window group runs under the ALU-bound accumulation of the other
+  struct Workspace {
+    DevBuf dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, columns2, rows_sum, bucket_proj, bufA, bufB,
+        scratch, columns, partials;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8];
+    uint32_t* h_info = nullptr;   // pinned, 64 words
+    uint32_t* h_part = nullptr;   // pinned, window sums read-back
+    DevBuf* all[17] = {&dig, &counts, &cursor, &tail_off, &info, &slots, &block_hist, &scan_partial, &desc, &columns2, &rows_sum,
+                       &bucket_proj, &bufA, &bufB, &scratch, &columns, &partials};
+  };
+  static constexpr int N_WS = 2;
+  Workspace ws[N_WS];
 
   msm_host::Curve6 hc;
   msm_host::Fe6 k_dev_to_host;  // 2^378: device Montgomery (2^390) -> host Montgomery (2^384)
@@ -185,11 +201,11 @@ msm_host::Proj6 partial_to_host(const msm_ctx* ctx, const uint32_t* w) {
   return P;
 }
 
-// Partition sums P_k for windows [k_lo, k_hi) -> ctx->h_partials[(k - k_lo) * 36 ...]
+// Partition sums P_k for windows [k_lo, k_hi) -> w.h_part[(k - k_lo) * 36 ...]
 // scalars: device pointer, n x 8 words.
-void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const Plan& pl, int k_lo, int k_hi,
-                      uint32_t* h_partials_out, GroupStats& st) {
-  hipStream_t s = ctx->stream;
+void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars, uint64_t n, const Plan& pl, int k_lo,
+                      int k_hi, uint32_t* h_partials_out, GroupStats& st) {
+  hipStream_t s = w.stream;
   const int kc = k_hi - k_lo;
   const uint32_t L = pl.L;
   const uint64_t nb = (uint64_t)kc * L;
@@ -205,11 +221,11 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
   uint32_t logG = 1;
   while (logG < 10 && (1ull << (logG + 1)) * 8 <= mean) logG++;
 
-  ctx->ensure(ctx->dig, n_entries * 4);
-  ctx->ensure(ctx->counts, nb * 4);
-  ctx->ensure(ctx->cursor, nb * 4);
-  ctx->ensure(ctx->tail_off, (size_t)34 * (nb + 1) * 4);
-  ctx->ensure(ctx->info, 64 * 4);
+  ctx->ensure(w.dig, n_entries * 4);
+  ctx->ensure(w.counts, nb * 4);
+  ctx->ensure(w.cursor, nb * 4);
+  ctx->ensure(w.tail_off, (size_t)34 * (nb + 1) * 4);
+  ctx->ensure(w.info, 64 * 4);
 
   // sort path: LDS-privatised histogram/ranking when one window's counters fit the LDS
   const bool lds_sort = (size_t)L * 4 <= 128 * 1024;
@@ -220,78 +236,78 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
     uint64_t maxb = std::max<uint64_t>(1, two_n / 8192);
     sortB = (uint32_t)std::min<uint64_t>(want, maxb);
     chunk = (two_n + sortB - 1) / sortB;
-    ctx->ensure(ctx->block_hist, (size_t)kc * sortB * L * 4);
+    ctx->ensure(w.block_hist, (size_t)kc * sortB * L * 4);
   }
 
-  HIPCHK(hipEventRecord(ctx->ev[0], s));
-  if (!lds_sort) HIPCHK(hipMemsetAsync(ctx->counts.p, 0, nb * 4, s));
+  HIPCHK(hipEventRecord(w.ev[0], s));
+  if (!lds_sort) HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));
   {
     uint32_t grid = (uint32_t)((n + 255) / 256);
-    uint32_t* cnt = lds_sort ? (uint32_t*)nullptr : (uint32_t*)ctx->counts.p;
+    uint32_t* cnt = lds_sort ? (uint32_t*)nullptr : (uint32_t*)w.counts.p;
     if (te)
-      hipLaunchKernelGGL(te::k_te_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)ctx->dig.p, cnt, d_scalars, (uint32_t)n, pl.c,
+      hipLaunchKernelGGL(te::k_te_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, cnt, d_scalars, (uint32_t)n, pl.c,
                          pl.K, k_lo, kc);
     else
-      hipLaunchKernelGGL(k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)ctx->dig.p, cnt, d_scalars, (uint32_t)n, pl.c, pl.K,
+      hipLaunchKernelGGL(k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, cnt, d_scalars, (uint32_t)n, pl.c, pl.K,
                          k_lo, kc);
   }
-  HIPCHK(hipEventRecord(ctx->ev[1], s));
+  HIPCHK(hipEventRecord(w.ev[1], s));
   if (lds_sort) {
-    hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)ctx->block_hist.p,
-                       (const uint32_t*)ctx->dig.p, two_n, chunk, L);
-    hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)ctx->block_hist.p,
-                       (uint32_t*)ctx->counts.p, sortB, L, (uint32_t)kc);
+    hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.block_hist.p,
+                       (const uint32_t*)w.dig.p, two_n, chunk, L);
+    hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.block_hist.p,
+                       (uint32_t*)w.counts.p, sortB, L, (uint32_t)kc);
   }
   int RT = 0;
   uint64_t total_slots = 0;
   uint32_t max_bucket = 0;
   if (lds_sort) {
     // largest bucket -> number of tail rounds (first of two small read-backs), then the multi-block scan
-    HIPCHK(hipMemsetAsync(ctx->info.p, 0, 64 * 4, s));
+    HIPCHK(hipMemsetAsync(w.info.p, 0, 64 * 4, s));
     hipLaunchKernelGGL(k_bucket_max, dim3((uint32_t)std::min<uint64_t>(1024, (nb + 255) / 256)), dim3(256), 0, s,
-                       (const uint32_t*)ctx->counts.p, (uint32_t)nb, (uint32_t*)ctx->info.p);
-    HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->info.p, 4 * 4, hipMemcpyDeviceToHost, s));
+                       (const uint32_t*)w.counts.p, (uint32_t)nb, (uint32_t*)w.info.p);
+    HIPCHK(hipMemcpyAsync(w.h_info, w.info.p, 4 * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    max_bucket = ctx->h_info[1];
+    max_bucket = w.h_info[1];
     uint32_t capmax = (max_bucket + (1u << logG) - 1) >> logG;
     while ((1u << RT) < capmax) RT++;
     const int nq = RT + 2;
     const uint32_t nblocks = (uint32_t)((nb + PS_SPAN - 1) / PS_SPAN);
-    ctx->ensure(ctx->scan_partial, (size_t)nq * nblocks * 4);
-    hipLaunchKernelGGL(k_pscan_partial, dim3(nblocks), dim3(PS_BLOCK), 0, s, (const uint32_t*)ctx->counts.p, (uint32_t)nb, logG, nq,
-                       (uint32_t*)ctx->scan_partial.p, nblocks);
-    hipLaunchKernelGGL(k_pscan_top, dim3(1), dim3(SCAN_THREADS), 0, s, (uint32_t*)ctx->scan_partial.p, nblocks, nq,
-                       (uint32_t*)ctx->info.p);
-    hipLaunchKernelGGL(k_pscan_final, dim3(nblocks), dim3(PS_BLOCK), 0, s, (const uint32_t*)ctx->counts.p, (uint32_t)nb, logG, nq,
-                       (const uint32_t*)ctx->scan_partial.p, nblocks, (uint32_t*)ctx->cursor.p, (uint32_t*)ctx->tail_off.p,
-                       (const uint32_t*)ctx->info.p);
-    HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->info.p, 64 * 4, hipMemcpyDeviceToHost, s));
+    ctx->ensure(w.scan_partial, (size_t)nq * nblocks * 4);
+    hipLaunchKernelGGL(k_pscan_partial, dim3(nblocks), dim3(PS_BLOCK), 0, s, (const uint32_t*)w.counts.p, (uint32_t)nb, logG, nq,
+                       (uint32_t*)w.scan_partial.p, nblocks);
+    hipLaunchKernelGGL(k_pscan_top, dim3(1), dim3(SCAN_THREADS), 0, s, (uint32_t*)w.scan_partial.p, nblocks, nq,
+                       (uint32_t*)w.info.p);
+    hipLaunchKernelGGL(k_pscan_final, dim3(nblocks), dim3(PS_BLOCK), 0, s, (const uint32_t*)w.counts.p, (uint32_t)nb, logG, nq,
+                       (const uint32_t*)w.scan_partial.p, nblocks, (uint32_t*)w.cursor.p, (uint32_t*)w.tail_off.p,
+                       (const uint32_t*)w.info.p);
+    HIPCHK(hipMemcpyAsync(w.h_info, w.info.p, 64 * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    total_slots = ctx->h_info[0];
+    total_slots = w.h_info[0];
   } else {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, (const uint32_t*)ctx->counts.p, (uint32_t)nb, logG,
-                       (uint32_t*)ctx->cursor.p, (uint32_t*)ctx->tail_off.p, (uint32_t*)ctx->info.p);
-    HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->info.p, 64 * 4, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, (const uint32_t*)w.counts.p, (uint32_t)nb, logG,
+                       (uint32_t*)w.cursor.p, (uint32_t*)w.tail_off.p, (uint32_t*)w.info.p);
+    HIPCHK(hipMemcpyAsync(w.h_info, w.info.p, 64 * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    total_slots = ctx->h_info[0];
-    max_bucket = ctx->h_info[1];
-    RT = (int)ctx->h_info[2];
+    total_slots = w.h_info[0];
+    max_bucket = w.h_info[1];
+    RT = (int)w.h_info[2];
   }
   st.max_bucket = std::max<uint64_t>(st.max_bucket, max_bucket);
 
   // scatter
-  ctx->ensure(ctx->slots, std::max<uint64_t>(total_slots, 2) * 4);
-  HIPCHK(hipMemsetAsync(ctx->slots.p, 0xFF, std::max<uint64_t>(total_slots, 2) * 4, s));
+  ctx->ensure(w.slots, std::max<uint64_t>(total_slots, 2) * 4);
+  HIPCHK(hipMemsetAsync(w.slots.p, 0xFF, std::max<uint64_t>(total_slots, 2) * 4, s));
   if (lds_sort) {
-    hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)ctx->slots.p,
-                       (const uint32_t*)ctx->cursor.p, (const uint32_t*)ctx->block_hist.p, (const uint32_t*)ctx->dig.p, two_n,
+    hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.slots.p,
+                       (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n,
                        chunk, L);
   } else {
     uint64_t grid = (n_entries + 255) / 256;
-    hipLaunchKernelGGL(k_scatter, dim3((uint32_t)grid), dim3(256), 0, s, (uint32_t*)ctx->slots.p, (uint32_t*)ctx->cursor.p,
-                       (const uint32_t*)ctx->dig.p, two_n, n_entries, L);
+    hipLaunchKernelGGL(k_scatter, dim3((uint32_t)grid), dim3(256), 0, s, (uint32_t*)w.slots.p, (uint32_t*)w.cursor.p,
+                       (const uint32_t*)w.dig.p, two_n, n_entries, L);
   }
-  HIPCHK(hipEventRecord(ctx->ev[2], s));
+  HIPCHK(hipEventRecord(w.ev[2], s));
 
   // accumulation tree
   // Weierstrass: tail rounds run only until no bucket holds more than FINISH_MAX elements; k_bucket_finish ends it
@@ -314,40 +330,40 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
       which ^= 1;
     }
     for (int r = 1; r <= r_stop; r++) {
-      cnt = ctx->h_info[3 + r];
+      cnt = w.h_info[3 + r];
       (which ? capB : capA) = std::max<uint64_t>(which ? capB : capA, cnt);
       which ^= 1;
     }
   }
-  ctx->ensure(ctx->bufA, capA * elem_bytes);
-  ctx->ensure(ctx->bufB, capB * elem_bytes);
-  uint4* buf[2] = {(uint4*)ctx->bufA.p, (uint4*)ctx->bufB.p};
+  ctx->ensure(w.bufA, capA * elem_bytes);
+  ctx->ensure(w.bufB, capB * elem_bytes);
+  uint4* buf[2] = {(uint4*)w.bufA.p, (uint4*)w.bufB.p};
   uint64_t cap[2] = {capA, capB};
   int cur = 0;  // buffer that receives the next round's output
   uint64_t n_in = total_slots;
   int round = 0;
   const uint4* fin = buf[0];
   uint64_t fin_cap = cap[0];
-  const uint32_t* off_fin = (const uint32_t*)ctx->tail_off.p;
+  const uint32_t* off_fin = (const uint32_t*)w.tail_off.p;
   if (total_slots > 0) {
     for (uint32_t r = 1; r <= logG; r++) {
       uint64_t n_out = n_in / 2;
       RoundGeom g = round_geom(ctx, n_out);
-      if (!te) ctx->ensure(ctx->scratch, (size_t)g.steps * NL * g.T * 4);
+      if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * g.T * 4);
       BatchArgs a{};
       a.points = (const uint32_t*)ctx->rows.p;
-      a.slots = (const uint32_t*)ctx->slots.p;
+      a.slots = (const uint32_t*)w.slots.p;
       a.in = buf[cur ^ 1];
       a.in_cap = cap[cur ^ 1];
       a.out = buf[cur];
       a.out_cap = cap[cur];
-      a.scratch = (uint32_t*)ctx->scratch.p;
+      a.scratch = (uint32_t*)w.scratch.p;
       a.n_out = n_out;
       a.steps = g.steps;
       if (r == 1) {
         if (te) hipLaunchKernelGGL(te::k_te_add<MODE_GATHER>, dim3(g.grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(k_batch_add<MODE_GATHER>, dim3(g.grid), dim3(256), 0, s, a);
-        HIPCHK(hipEventRecord(ctx->ev[6], s));
+        HIPCHK(hipEventRecord(w.ev[6], s));
       } else {
         if (te) hipLaunchKernelGGL(te::k_te_add<MODE_REGULAR>, dim3(g.grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(k_batch_add<MODE_REGULAR>, dim3(g.grid), dim3(256), 0, s, a);
@@ -360,25 +376,25 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
       round++;
     }
     for (int r = 1; r <= r_stop; r++) {
-      uint64_t n_out = ctx->h_info[3 + r];
+      uint64_t n_out = w.h_info[3 + r];
       RoundGeom g = round_geom(ctx, n_out);
-      if (!te) ctx->ensure(ctx->scratch, (size_t)g.steps * NL * g.T * 4);
+      if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * g.T * 4);
       BatchArgs a{};
       a.in = buf[cur ^ 1];
       a.in_cap = cap[cur ^ 1];
       a.out = buf[cur];
       a.out_cap = cap[cur];
-      a.scratch = (uint32_t*)ctx->scratch.p;
+      a.scratch = (uint32_t*)w.scratch.p;
       a.n_out = n_out;
       a.steps = g.steps;
-      a.off_in = (const uint32_t*)ctx->tail_off.p + (uint64_t)(r - 1) * (nb + 1);
-      a.off_out = (const uint32_t*)ctx->tail_off.p + (uint64_t)r * (nb + 1);
+      a.off_in = (const uint32_t*)w.tail_off.p + (uint64_t)(r - 1) * (nb + 1);
+      a.off_out = (const uint32_t*)w.tail_off.p + (uint64_t)r * (nb + 1);
       a.nb = (uint32_t)nb;
       if (n_out) {
-        ctx->ensure(ctx->desc, n_out * 4);
-        hipLaunchKernelGGL(k_tail_desc, dim3((uint32_t)((n_out + 255) / 256)), dim3(256), 0, s, (uint32_t*)ctx->desc.p, a.off_in,
+        ctx->ensure(w.desc, n_out * 4);
+        hipLaunchKernelGGL(k_tail_desc, dim3((uint32_t)((n_out + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.desc.p, a.off_in,
                            a.off_out, (uint32_t)nb, (uint32_t)n_out);
-        a.desc = (const uint32_t*)ctx->desc.p;
+        a.desc = (const uint32_t*)w.desc.p;
       }
       if (te) hipLaunchKernelGGL(te::k_te_add<MODE_SEARCH>, dim3(g.grid), dim3(256), 0, s, a);
       else hipLaunchKernelGGL(k_batch_add<MODE_SEARCH>, dim3(g.grid), dim3(256), 0, s, a);
@@ -388,18 +404,18 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
       cur ^= 1;
       round++;
     }
-    off_fin = (const uint32_t*)ctx->tail_off.p + (uint64_t)r_stop * (nb + 1);
+    off_fin = (const uint32_t*)w.tail_off.p + (uint64_t)r_stop * (nb + 1);
   }
   st.rounds = round;
   const uint32_t* bucket_proj = nullptr;
   if (use_finish && total_slots > 0) {
-    ctx->ensure(ctx->bucket_proj, nb * 3 * NL * 4);
-    hipLaunchKernelGGL(k_bucket_finish, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)ctx->bucket_proj.p, fin,
+    ctx->ensure(w.bucket_proj, nb * 3 * NL * 4);
+    hipLaunchKernelGGL(k_bucket_finish, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.bucket_proj.p, fin,
                        fin_cap, off_fin, (uint32_t)nb);
-    bucket_proj = (const uint32_t*)ctx->bucket_proj.p;
+    bucket_proj = (const uint32_t*)w.bucket_proj.p;
   }
-  if (total_slots == 0) HIPCHK(hipEventRecord(ctx->ev[6], s));
-  HIPCHK(hipEventRecord(ctx->ev[3], s));
+  if (total_slots == 0) HIPCHK(hipEventRecord(w.ev[6], s));
+  HIPCHK(hipEventRecord(w.ev[3], s));
 
   // bucket reduction
   uint32_t TC = (uint32_t)std::max<uint64_t>(2, (nb + 65535) / 65536);
@@ -409,54 +425,54 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
   uint32_t nbits = 0;
   while ((1u << nbits) < nchunks) nbits++;
   const bool bit_sliced = !te && nchunks >= 64 && (TC & (TC - 1)) == 0;
-  ctx->ensure(ctx->columns, (size_t)kc * nchunks * 4 * NL * 4);
-  ctx->ensure(ctx->partials, (size_t)kc * 36 * 4);
+  ctx->ensure(w.columns, (size_t)kc * nchunks * 4 * NL * 4);
+  ctx->ensure(w.partials, (size_t)kc * 36 * 4);
   {
     uint32_t threads = nchunks * (uint32_t)kc;
     if (te) {
-      hipLaunchKernelGGL(te::k_te_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)ctx->columns.p, fin, fin_cap,
+      hipLaunchKernelGGL(te::k_te_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, fin, fin_cap,
                          off_fin, L, TC, nchunks, (uint32_t)kc);
-      hipLaunchKernelGGL(te::k_te_window_sum, dim3(kc), dim3(te::TE_WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
-                         (const uint32_t*)ctx->columns.p, nchunks);
+      hipLaunchKernelGGL(te::k_te_window_sum, dim3(kc), dim3(te::TE_WS_THREADS), 0, s, (uint32_t*)w.partials.p,
+                         (const uint32_t*)w.columns.p, nchunks);
     } else if (bit_sliced) {
-      ctx->ensure(ctx->rows_sum, (size_t)kc * nchunks * 3 * NL * 4);
-      hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)ctx->columns.p,
-                         (uint32_t*)ctx->rows_sum.p, fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
+      ctx->ensure(w.rows_sum, (size_t)kc * nchunks * 3 * NL * 4);
+      hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p,
+                         (uint32_t*)w.rows_sum.p, fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
       const uint32_t per_block = 2 * WS_THREADS;
       const uint32_t nblk = (nchunks + per_block - 1) / per_block;
-      ctx->ensure(ctx->columns2, (size_t)kc * (nbits + 1) * nblk * 3 * NL * 4);
-      ctx->ensure(ctx->partials, (size_t)kc * (nbits + 1) * 36 * 4);
-      hipLaunchKernelGGL(k_bit_tree, dim3(nblk, nbits + 1, kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->columns2.p,
-                         (const uint32_t*)ctx->rows_sum.p, (const uint32_t*)ctx->columns.p, nchunks, per_block, nbits, 1, 0);
-      hipLaunchKernelGGL(k_bit_tree, dim3(1, nbits + 1, kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
-                         (const uint32_t*)ctx->columns2.p, (const uint32_t*)nullptr, nblk, nblk, nbits, 0, 1);
+      ctx->ensure(w.columns2, (size_t)kc * (nbits + 1) * nblk * 3 * NL * 4);
+      ctx->ensure(w.partials, (size_t)kc * (nbits + 1) * 36 * 4);
+      hipLaunchKernelGGL(k_bit_tree, dim3(nblk, nbits + 1, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.columns2.p,
+                         (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, per_block, nbits, 1, 0);
+      hipLaunchKernelGGL(k_bit_tree, dim3(1, nbits + 1, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
+                         (const uint32_t*)w.columns2.p, (const uint32_t*)nullptr, nblk, nblk, nbits, 0, 1);
     } else {
-      hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)ctx->columns.p, (uint32_t*)nullptr,
+      hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, (uint32_t*)nullptr,
                          fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
       if (nchunks > 2 * WS_THREADS) {
         // two-stage: blocks of 2 columns per lane, then one block per window over the block sums
         const uint32_t per_block = 2 * WS_THREADS;
         const uint32_t nblk = (nchunks + per_block - 1) / per_block;
-        ctx->ensure(ctx->columns2, (size_t)kc * nblk * 3 * NL * 4);
-        hipLaunchKernelGGL(k_column_tree, dim3(nblk, kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->columns2.p,
-                           (const uint32_t*)ctx->columns.p, nchunks, per_block);
-        hipLaunchKernelGGL(k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
-                           (const uint32_t*)ctx->columns2.p, nblk);
+        ctx->ensure(w.columns2, (size_t)kc * nblk * 3 * NL * 4);
+        hipLaunchKernelGGL(k_column_tree, dim3(nblk, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.columns2.p,
+                           (const uint32_t*)w.columns.p, nchunks, per_block);
+        hipLaunchKernelGGL(k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
+                           (const uint32_t*)w.columns2.p, nblk);
       } else {
-        hipLaunchKernelGGL(k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)ctx->partials.p,
-                           (const uint32_t*)ctx->columns.p, nchunks);
+        hipLaunchKernelGGL(k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
+                           (const uint32_t*)w.columns.p, nchunks);
       }
     }
   }
   if (bit_sliced) {
     // read the (nbits + 1) sums per window back and finish P_k = tri + TC * sum_b 2^b S_b on the host
-    HIPCHK(hipMemcpyAsync(ctx->h_partials, ctx->partials.p, (size_t)kc * (nbits + 1) * 36 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipEventRecord(ctx->ev[4], s));
+    HIPCHK(hipMemcpyAsync(w.h_part, w.partials.p, (size_t)kc * (nbits + 1) * 36 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(w.ev[4], s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     const auto& C = ctx->hc;
     for (int kk = 0; kk < kc; kk++) {
-      const uint32_t* base = ctx->h_partials + (size_t)kk * (nbits + 1) * 36;
+      const uint32_t* base = w.h_part + (size_t)kk * (nbits + 1) * 36;
       msm_host::Proj6 acc = C.zero();
       for (int b = (int)nbits - 1; b >= 0; b--) {
         acc = C.dbl(acc);
@@ -478,23 +494,24 @@ void run_window_group(msm_ctx* ctx, const uint32_t* d_scalars, uint64_t n, const
       }
     }
     float ms;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); st.ms_digits += ms;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2])); st.ms_sort += ms;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); st.ms_acc += ms;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[6])); st.ms_r1 += ms;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); st.ms_red += ms;
+    HIPCHK(hipEventElapsedTime(&ms, w.ev[0], w.ev[1])); st.ms_digits += ms;
+    HIPCHK(hipEventElapsedTime(&ms, w.ev[1], w.ev[2])); st.ms_sort += ms;
+    HIPCHK(hipEventElapsedTime(&ms, w.ev[2], w.ev[3])); st.ms_acc += ms;
+    HIPCHK(hipEventElapsedTime(&ms, w.ev[2], w.ev[6])); st.ms_r1 += ms;
+    HIPCHK(hipEventElapsedTime(&ms, w.ev[3], w.ev[4])); st.ms_red += ms;
     return;
   }
-  HIPCHK(hipMemcpyAsync(h_partials_out, ctx->partials.p, (size_t)kc * part_words * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipEventRecord(ctx->ev[4], s));
+  HIPCHK(hipMemcpyAsync(w.h_part, w.partials.p, (size_t)kc * part_words * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(w.ev[4], s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
+  memcpy(h_partials_out, w.h_part, (size_t)kc * part_words * 4);
   float ms;
-  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); st.ms_digits += ms;
-  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2])); st.ms_sort += ms;
-  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); st.ms_acc += ms;
-  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[6])); st.ms_r1 += ms;
-  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); st.ms_red += ms;
+  HIPCHK(hipEventElapsedTime(&ms, w.ev[0], w.ev[1])); st.ms_digits += ms;
+  HIPCHK(hipEventElapsedTime(&ms, w.ev[1], w.ev[2])); st.ms_sort += ms;
+  HIPCHK(hipEventElapsedTime(&ms, w.ev[2], w.ev[3])); st.ms_acc += ms;
+  HIPCHK(hipEventElapsedTime(&ms, w.ev[2], w.ev[6])); st.ms_r1 += ms;
+  HIPCHK(hipEventElapsedTime(&ms, w.ev[3], w.ev[4])); st.ms_red += ms;
 }
 
 // how many windows fit one group under the workspace budget
@@ -502,7 +519,7 @@ int windows_per_group(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
   // per window: digits 8n, slots ~8n(+pad), bufA ~ n*96, bufB ~ n*48, scratch ~ n*52
   long double per = ctx->is_te() ? (long double)n * (4 + 5 + 64 + 32) + (long double)pl.L * 4 * 40
                                  : (long double)n * (8 + 9 + 96 + 48 + 56) + (long double)pl.L * 4 * 40;
-  int w = (int)std::max<long double>(1, (long double)ctx->ws_budget / per);
+  int w = (int)std::max<long double>(1, (long double)ctx->ws_budget / msm_ctx::N_WS / per);
   return std::min(w, pl.K);
 }
 
@@ -583,11 +600,53 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   GroupStats st;
   const int pw = ctx->is_te() ? 32 : 36;
   words.assign((size_t)(k_hi - k_lo) * pw, 0);
+  // window groups: as large as the workspace budget allows; for big inputs two of them, so that the two
+  // workspaces/streams overlap one group's sort and bucket reduction with the other's accumulation
   int wpg = std::min(windows_per_group(ctx, n, pl), 128);
-  for (int k = k_lo; k < k_hi; k += wpg) {
-    int ke = std::min(k_hi, k + wpg);
-    run_window_group(ctx, d_scal, n, pl, k, ke, ctx->h_partials, st);
-    memcpy(&words[(size_t)(k - k_lo) * pw], ctx->h_partials, (size_t)(ke - k) * pw * 4);
+  const int nwin = k_hi - k_lo;
+  // measured on MI355X: two groups win ~7 % at 2^26 (198 vs 213 ms); below ~2^23 the fixed per-group latencies
+  // (read-backs, bucket reduction depth) cost more than the overlap returns
+  int want_groups = (nwin >= 2 && n >= (1ull << 23)) ? 2 : 1;
+  if (const char* e = getenv("MSM_GROUPS")) want_groups = std::max(1, atoi(e));
+  wpg = std::max(1, std::min(wpg, (nwin + want_groups - 1) / want_groups));
+  std::vector<std::pair<int, int>> groups;
+  for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg)});
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // staged scalars are in place before the group streams start
+  std::atomic<int> next{0};
+  GroupStats sts[msm_ctx::N_WS];
+  HipFail fails[msm_ctx::N_WS];
+  bool failed[msm_ctx::N_WS] = {false, false};
+  auto worker = [&](int slot) {
+    try {
+      HIPCHK(hipSetDevice(ctx->device));
+      for (;;) {
+        int gi = next.fetch_add(1);
+        if (gi >= (int)groups.size()) break;
+        const int ka = groups[gi].first, kb = groups[gi].second;
+        std::vector<uint32_t> part((size_t)(kb - ka) * pw);
+        run_window_group(ctx, ctx->ws[slot], d_scal, n, pl, ka, kb, part.data(), sts[slot]);
+        memcpy(&words[(size_t)(ka - k_lo) * pw], part.data(), part.size() * 4);
+      }
+    } catch (const HipFail& f) {
+      fails[slot] = f;
+      failed[slot] = true;
+    }
+  };
+  const int nthreads = std::min<int>(msm_ctx::N_WS, (int)groups.size());
+  if (nthreads <= 1) {
+    worker(0);
+  } else {
+    std::thread t1(worker, 1);
+    worker(0);
+    t1.join();
+  }
+  for (int i = 0; i < msm_ctx::N_WS; i++) {
+    if (failed[i]) throw fails[i];
+    st.n_pairs += sts[i].n_pairs;
+    st.max_bucket = std::max(st.max_bucket, sts[i].max_bucket);
+    st.rounds = std::max(st.rounds, sts[i].rounds);
+    st.ms_digits += sts[i].ms_digits; st.ms_sort += sts[i].ms_sort; st.ms_acc += sts[i].ms_acc;
+    st.ms_red += sts[i].ms_red; st.ms_r1 += sts[i].ms_r1;
   }
   HIPCHK(hipEventRecord(ctx->ev[10], ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -637,7 +696,12 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipHostMalloc((void**)&ctx->h_info, 64 * 4, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_partials, 128 * 20 * 36 * 4, hipHostMallocDefault));
+    for (auto& w : ctx->ws) {
+      HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+      for (auto& e : w.ev) HIPCHK(hipEventCreate(&e));
+      HIPCHK(hipHostMalloc((void**)&w.h_info, 64 * 4, hipHostMallocDefault));
+      HIPCHK(hipHostMalloc((void**)&w.h_part, 128 * 20 * 36 * 4, hipHostMallocDefault));
+    }
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     // leave room for the resident points (144 B/point at 2^26 = 9.7 GB) and fragmentation
@@ -666,11 +730,16 @@ void msm_ctx_destroy(msm_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
-  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->dig, &ctx->counts, &ctx->cursor, &ctx->tail_off, &ctx->info, &ctx->slots, &ctx->block_hist, &ctx->scan_partial, &ctx->desc, &ctx->columns2, &ctx->rows_sum, &ctx->bucket_proj,
-                    &ctx->bufA, &ctx->bufB, &ctx->scratch, &ctx->columns, &ctx->partials, &ctx->errflag, &ctx->misc})
-    ctx->release(*b);
+  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->errflag, &ctx->misc}) ctx->release(*b);
+  for (auto& w : ctx->ws) {
+    if (w.stream) hipStreamSynchronize(w.stream);
+    for (DevBuf* b : w.all) ctx->release(*b);
+    if (w.h_info) hipHostFree(w.h_info);
+    if (w.h_part) hipHostFree(w.h_part);
+    for (auto& e : w.ev) hipEventDestroy(e);
+    if (w.stream) hipStreamDestroy(w.stream);
+  }
   if (ctx->h_info) hipHostFree(ctx->h_info);
-  if (ctx->h_partials) hipHostFree(ctx->h_partials);
   for (auto& e : ctx->ev) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
