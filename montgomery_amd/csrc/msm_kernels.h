@@ -25,6 +25,7 @@
 #pragma once
 #include "curve.h"
 #include "glv.h"
+#include "packed.h"
 
 namespace msm {
 
@@ -566,37 +567,36 @@ MSM_DEV void locate(const BatchArgs& a, uint64_t e, Side& A, Side& B) {
   }
 }
 
-// raw (packed) coordinate loads; the unpack happens where the value is consumed so that the loads
-// of the NEXT pair can be in flight while the current one is being computed
+// raw (packed) coordinate loads: operands stay in the packed word form (packed.h) and only the values that feed
+// multiplications are unpacked; the loads of the NEXT pair are in flight while the current one is computed
 template <int MODE>
-MSM_DEV void load_x_raw(const BatchArgs& a, const Side& s, uint32_t (&w)[NW]) {
-  if (MODE == MODE_GATHER) load_words12(w, a.points + s.idx + s.xoff);
-  else load_planes3(w, a.in, a.in_cap, 0, s.idx);
+MSM_DEV void load_x_raw(const BatchArgs& a, const Side& s, Pk& w) {
+  if (MODE == MODE_GATHER) load_words12(w.w, a.points + s.idx + s.xoff);
+  else load_planes3(w.w, a.in, a.in_cap, 0, s.idx);
 }
 template <int MODE>
-MSM_DEV void load_y_raw(const BatchArgs& a, const Side& s, uint32_t (&w)[NW]) {
-  if (MODE == MODE_GATHER) load_words12(w, a.points + s.idx + s.xoff + ROW_Y);
-  else load_planes3(w, a.in, a.in_cap, 3, s.idx);
+MSM_DEV void load_y_raw(const BatchArgs& a, const Side& s, Pk& w) {
+  if (MODE == MODE_GATHER) load_words12(w.w, a.points + s.idx + s.xoff + ROW_Y);
+  else load_planes3(w.w, a.in, a.in_cap, 3, s.idx);
 }
 
+// gather mode: apply the sign bit of the payload, y -> p - y (0 stays 0)
 template <int MODE>
-MSM_DEV void finish_y(const Side& s, const uint32_t (&w)[NW], Fe<F>& y) {
-  fe_unpack<F>(y, w);
-  if (MODE == MODE_GATHER && s.neg && !fe_is_zero_canonical<F>(y)) {
-    Fe<F> z;
-    fe_set_zero<F>(z);
-    fe_sub_p<F>(y, z, y);  // p - y, canonical because 0 < y < p
-  }
+MSM_DEV void finish_y(const Side& s, Pk& y) {
+  if (MODE != MODE_GATHER) return;
+  Pk pp, t;
+  pk_set_p_masked<F>(pp, 0xFFFFFFFFu);
+  pk_sub(t, pp, y);
+  const bool flip = s.neg && !pk_is_zero(y);
+#pragma unroll
+  for (int i = 0; i < NW; i++) y.w[i] = flip ? t.w[i] : y.w[i];
 }
 
 enum : int { KIND_ADD = 0, KIND_DOUBLE = 1, KIND_COPY_A = 2, KIND_COPY_B = 3, KIND_ZERO = 4 };
 
-MSM_DEV void store_point(uint4* out, uint64_t cap, uint64_t e, const Fe<F>& x, const Fe<F>& y) {
-  uint32_t w[NW];
-  fe_pack<F>(w, x);
-  store_planes3(out, cap, 0, e, w);
-  fe_pack<F>(w, y);
-  store_planes3(out, cap, 3, e, w);
+MSM_DEV void store_point_pk(uint4* out, uint64_t cap, uint64_t e, const Pk& x, const Pk& y) {
+  store_planes3(out, cap, 0, e, x.w);
+  store_planes3(out, cap, 3, e, y.w);
 }
 
 MSM_DEV void store_identity(uint4* out, uint64_t cap, uint64_t e) {
@@ -613,7 +613,7 @@ MSM_DEV void store_identity(uint4* out, uint64_t cap, uint64_t e) {
 template <int MODE>
 struct PairFetch {
   Side A, B;
-  uint32_t ax[NW], bx[NW];
+  Pk ax, bx;
 };
 
 template <int MODE>
@@ -621,7 +621,7 @@ MSM_DEV void copy_fetch(PairFetch<MODE>& d, const PairFetch<MODE>& s) {  // elem
   d.A.idx = s.A.idx; d.A.xoff = s.A.xoff; d.A.neg = s.A.neg; d.A.absent = s.A.absent;
   d.B.idx = s.B.idx; d.B.xoff = s.B.xoff; d.B.neg = s.B.neg; d.B.absent = s.B.absent;
 #pragma unroll
-  for (int j = 0; j < NW; j++) { d.ax[j] = s.ax[j]; d.bx[j] = s.bx[j]; }
+  for (int j = 0; j < NW; j++) { d.ax.w[j] = s.ax.w[j]; d.bx.w[j] = s.bx.w[j]; }
 }
 
 template <int MODE>
@@ -631,31 +631,32 @@ MSM_DEV void fetch_pair_x(const BatchArgs& a, uint64_t e, PairFetch<MODE>& pf) {
   load_x_raw<MODE>(a, pf.B, pf.bx);
 }
 
-// classification + denominator from the x coordinates (y only for the rare equal-x case)
+// classification + denominator from the packed x coordinates (y only for the rare equal-x case).
+// den comes back in limb form, ready for the multiplier.
 template <int MODE>
-MSM_DEV int classify(const BatchArgs& a, const PairFetch<MODE>& pf, Fe<F>& x1, Fe<F>& x2, bool& inf1, bool& inf2,
-                     Fe<F>& den) {
-  fe_unpack<F>(x1, pf.ax);
-  fe_unpack<F>(x2, pf.bx);
-  inf1 = pf.A.absent || pf.ax[NW - 1] == INF_WORD;
-  inf2 = pf.B.absent || pf.bx[NW - 1] == INF_WORD;
+MSM_DEV int classify(const BatchArgs& a, const PairFetch<MODE>& pf, bool& inf1, bool& inf2, Fe<F>& den) {
+  inf1 = pf.A.absent || pf.ax.w[NW - 1] == INF_WORD;
+  inf2 = pf.B.absent || pf.bx.w[NW - 1] == INF_WORD;
   fe_set_one<F>(den);
   if (inf2) return KIND_COPY_A;
   if (inf1) return KIND_COPY_B;
-  if (fe_equal(x1, x2)) {
-    uint32_t w[NW];
-    Fe<F> y1, y2;
-    load_y_raw<MODE>(a, pf.A, w);
-    finish_y<MODE>(pf.A, w, y1);
-    load_y_raw<MODE>(a, pf.B, w);
-    finish_y<MODE>(pf.B, w, y2);
-    if (fe_equal(y1, y2) && !fe_is_zero_canonical<F>(y1)) {
-      fe_add<F>(den, y1, y1);
+  Pk dx;
+  pk_sub_mod<F>(dx, pf.bx, pf.ax);          // x2 - x1 mod p, canonical
+  if (pk_is_zero(dx)) {
+    Pk y1, y2;
+    load_y_raw<MODE>(a, pf.A, y1);
+    finish_y<MODE>(pf.A, y1);
+    load_y_raw<MODE>(a, pf.B, y2);
+    finish_y<MODE>(pf.B, y2);
+    if (pk_equal(y1, y2) && !pk_is_zero(y1)) {
+      Fe<F> yl;
+      pk_unpack<F>(yl, y1);
+      fe_add<F>(den, yl, yl);
       return KIND_DOUBLE;
     }
     return KIND_ZERO;
   }
-  fe_sub_p<F>(den, x2, x1);
+  pk_unpack<F>(den, dx);
   return KIND_ADD;
 }
 
@@ -679,9 +680,9 @@ __global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
       PairFetch<MODE> cur;
       copy_fetch<MODE>(cur, nxt);
       if (i + 1 < my_steps) fetch_pair_x<MODE>(a, (uint64_t)(i + 1) * T + t, nxt);   // in flight during the multiply
-      Fe<F> x1, x2, den;
+      Fe<F> den;
       bool inf1, inf2;
-      classify<MODE>(a, cur, x1, x2, inf1, inf2, den);
+      classify<MODE>(a, cur, inf1, inf2, den);
       uint32_t* sp = a.scratch + ((uint64_t)i * NL) * T + t;
 #pragma unroll
       for (int l = 0; l < NL; l++) sp[(uint64_t)l * T] = acc.l[l];
@@ -712,9 +713,9 @@ __global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
 #pragma unroll
       for (int l = 0; l < NL; l++) pre.l[l] = npre[l];
       // this pair's y coordinates: issued now, consumed after two multiplications
-      uint32_t ay[NW], by[NW];
-      load_y_raw<MODE>(a, cur.A, ay);
-      load_y_raw<MODE>(a, cur.B, by);
+      Pk y1, y2;
+      load_y_raw<MODE>(a, cur.A, y1);
+      load_y_raw<MODE>(a, cur.B, y2);
       // next pair's x coordinates and prefix product: in flight during this pair's arithmetic
       if (i > 0) {
         fetch_pair_x<MODE>(a, (uint64_t)(i - 1) * T + t, nxt);
@@ -722,56 +723,60 @@ __global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
 #pragma unroll
         for (int l = 0; l < NL; l++) npre[l] = sp[(uint64_t)l * T];
       }
-      Fe<F> x1, x2, den, d;
+      Fe<F> den, d;
       bool inf1, inf2;
-      int kind = classify<MODE>(a, cur, x1, x2, inf1, inf2, den);
+      int kind = classify<MODE>(a, cur, inf1, inf2, den);
       fe_mul<F>(d, inv, pre);     // 1 / den_i
       fe_mul<F>(inv, inv, den);   // strip den_i from the running inverse
 
-      Fe<F> y1, y2;
-      finish_y<MODE>(cur.A, ay, y1);
-      finish_y<MODE>(cur.B, by, y2);
+      finish_y<MODE>(cur.A, y1);
+      finish_y<MODE>(cur.B, y2);
       if (kind == KIND_ZERO || (kind == KIND_COPY_A && inf1)) {
         store_identity(a.out, a.out_cap, e);
         continue;
       }
       if (kind == KIND_COPY_A) {
-        store_point(a.out, a.out_cap, e, x1, y1);
+        store_point_pk(a.out, a.out_cap, e, cur.ax, y1);
         continue;
       }
       if (kind == KIND_COPY_B) {
-        store_point(a.out, a.out_cap, e, x2, y2);
+        store_point_pk(a.out, a.out_cap, e, cur.bx, y2);
         continue;
       }
-      Fe<F> num, m, mm, x3, y3, tt;
+      Fe<F> num, m, mm, tt, y3l;
       if (kind == KIND_DOUBLE) {
-        fe_sqr<F>(tt, x1);
+        Fe<F> x1l;
+        pk_unpack<F>(x1l, cur.ax);
+        fe_sqr<F>(tt, x1l);
         fe_add<F>(num, tt, tt);
         fe_add<F>(num, num, tt);   // 3 x^2
       } else {
-        fe_sub_p<F>(num, y2, y1);
+        Pk dy;
+        pk_sub_mod<F>(dy, y2, y1);
+        pk_unpack<F>(num, dy);
       }
       fe_mul<F>(m, num, d);
       fe_sqr<F>(mm, m);
-      fe_sub_p<F>(x3, mm, x1);
-      fe_sub_p<F>(x3, x3, x2);
-      fe_reduce_4p<F>(x3);
-      fe_sub_p<F>(tt, x1, x3);
-      fe_mul<F>(y3, m, tt);
-      fe_sub_p<F>(y3, y3, y1);
-      fe_reduce_4p<F>(y3);
-      store_point(a.out, a.out_cap, e, x3, y3);
+      // x3 = m^2 - x1 - x2, on words: m^2 < p + eps, every step stays in [0, p + eps), one final conditional subtraction
+      Pk x3, tw, y3;
+      pk_pack<F>(x3, mm);
+      pk_sub_mod<F>(x3, x3, cur.ax);
+      pk_sub_mod<F>(x3, x3, cur.bx);
+      pk_cond_sub_p<F>(x3);
+      pk_sub_mod<F>(tw, cur.ax, x3);   // x1 - x3
+      pk_unpack<F>(tt, tw);
+      fe_mul<F>(y3l, m, tt);
+      pk_pack<F>(y3, y3l);
+      pk_sub_mod<F>(y3, y3, y1);
+      pk_cond_sub_p<F>(y3);
+      store_point_pk(a.out, a.out_cap, e, x3, y3);
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_bucket_reduce: per chunk of TC buckets of one window, triangle + (lstart-1)*row in projective
+// projective points in raw limb form (3 x 13 words) between the reduction kernels
 // ---------------------------------------------------------------------------------------------
-
-struct ProjOut {
-  uint32_t w[3 * NL];
-};
 
 MSM_DEV void proj_store(uint32_t* dst, const Proj<F>& P) {
 #pragma unroll
