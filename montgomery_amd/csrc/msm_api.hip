@@ -66,13 +66,13 @@ struct msm_ctx {
   // window group runs under the ALU-bound accumulation of the other
   struct Workspace {
     DevBuf dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, columns2, rows_sum, bucket_proj, bufA, bufB,
-        scratch, columns, partials;
+        scratch, columns, partials, part, dig2, idx2, block_hist2, blk_tab;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8];
     uint32_t* h_info = nullptr;   // pinned, 64 words
     uint32_t* h_part = nullptr;   // pinned, window sums read-back
-    DevBuf* all[17] = {&dig, &counts, &cursor, &tail_off, &info, &slots, &block_hist, &scan_partial, &desc, &columns2, &rows_sum,
-                       &bucket_proj, &bufA, &bufB, &scratch, &columns, &partials};
+    DevBuf* all[22] = {&dig, &counts, &cursor, &tail_off, &info, &slots, &block_hist, &scan_partial, &desc, &columns2, &rows_sum,
+                       &bucket_proj, &bufA, &bufB, &scratch, &columns, &partials, &part, &dig2, &idx2, &block_hist2, &blk_tab};
   };
   static constexpr int N_WS = 2;
   Workspace ws[N_WS];
@@ -227,17 +227,30 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   ctx->ensure(w.tail_off, (size_t)34 * (nb + 1) * 4);
   ctx->ensure(w.info, 64 * 4);
 
-  // sort path: LDS-privatised histogram/ranking when one window's counters fit the LDS
-  const bool lds_sort = (size_t)L * 4 <= 128 * 1024;
+  // sort path: LDS-privatised histogram/ranking.  One level when a window's counters fit the LDS (c <= 16), two
+  // levels (coarse bins of 2^15 buckets, then the same LDS sort per bin) up to c = 24; global atomics otherwise.
+  const bool one_level = (size_t)L * 4 <= 128 * 1024;
+  const bool two_level = !one_level && pl.c <= 24;
+  const bool lds_sort = one_level || two_level;
+  const uint32_t shift = two_level ? (uint32_t)(pl.c - 1 - 15) : 0;   // low bits kept for the second level
+  const uint32_t Hn = 1u << shift;                                    // coarse bins per window
+  const uint32_t L2 = two_level ? 32768u : L;                         // buckets per (virtual) window
+  const uint32_t V = (uint32_t)kc * Hn;                               // virtual windows
   uint32_t sortB = 1;
   uint64_t chunk = two_n;
   if (lds_sort) {
-    uint64_t want = std::max<uint64_t>(1, (2ull * ctx->n_cu + kc - 1) / kc);
+    // big inputs: finer slices also keep the round-1 gathers of neighbouring lanes inside one Infinity-Cache-sized
+    // range of point rows (measured: 193 -> 183 ms at 2^26); small inputs: fewer, larger blocks (less fixed cost)
+    uint64_t mult = two_n >= (1ull << 24) ? 8 : 2;
+    if (const char* e = getenv("MSM_SORTB_MULT")) mult = std::max(1, atoi(e));
+    uint64_t want = std::max<uint64_t>(1, (mult * ctx->n_cu + kc - 1) / kc);
     uint64_t maxb = std::max<uint64_t>(1, two_n / 8192);
     sortB = (uint32_t)std::min<uint64_t>(want, maxb);
     chunk = (two_n + sortB - 1) / sortB;
-    ctx->ensure(w.block_hist, (size_t)kc * sortB * L * 4);
+    ctx->ensure(w.block_hist, (size_t)kc * sortB * (two_level ? Hn : L) * 4);
   }
+  uint64_t chunk2 = 0;      // second level: entries per block, number of active blocks
+  uint32_t n_active2 = 0;
 
   HIPCHK(hipEventRecord(w.ev[0], s));
   if (!lds_sort) HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));
@@ -252,11 +265,60 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
                          k_lo, kc);
   }
   HIPCHK(hipEventRecord(w.ev[1], s));
-  if (lds_sort) {
+  if (one_level) {
     hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.block_hist.p,
-                       (const uint32_t*)w.dig.p, two_n, chunk, L);
+                       (const uint32_t*)w.dig.p, two_n, chunk, L, 0u, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.block_hist.p,
-                       (uint32_t*)w.counts.p, sortB, L, (uint32_t)kc);
+                       (uint32_t*)w.counts.p, sortB, L, (uint32_t)kc, (const uint32_t*)nullptr);
+  } else if (two_level) {
+    // level 1: coarse histogram -> partition offsets (host scan of V counters) -> partitioned (digit, entry) arrays
+    ctx->ensure(w.part, (size_t)(2 * V + 2) * 4);
+    uint32_t* d_cnt = (uint32_t*)w.part.p;            // V coarse counts
+    uint32_t* d_part = (uint32_t*)w.part.p + V;       // V + 1 partition starts
+    hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)Hn * 4, s, (uint32_t*)w.block_hist.p,
+                       (const uint32_t*)w.dig.p, two_n, chunk, Hn, 15u, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_colscan, dim3((V + 255) / 256), dim3(256), 0, s, (uint32_t*)w.block_hist.p, d_cnt, sortB, Hn,
+                       (uint32_t)kc, (const uint32_t*)nullptr);
+    std::vector<uint32_t> h_cnt(V), h_part(V + 1);
+    HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)V * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    // partition starts, and the table of active (partition, block) pairs of the second level: partitions differ a lot
+    // in size (the top window has few, heavy coarse bins), so blocks are enumerated, not laid out on a 2-D grid
+    chunk2 = 1ull << 20;
+    uint64_t run = 0;
+    std::vector<uint32_t> h_tab, h_rows(V + 1);
+    uint32_t nrows = 0;
+    for (uint32_t v = 0; v < V; v++) {
+      h_part[v] = (uint32_t)run;
+      run += h_cnt[v];
+      h_rows[v] = nrows;
+      uint32_t bv = (uint32_t)((h_cnt[v] + chunk2 - 1) / chunk2);
+      for (uint32_t b = 0; b < bv; b++) { h_tab.push_back(v); h_tab.push_back(b); h_tab.push_back(nrows); }
+      nrows += bv;
+    }
+    h_part[V] = (uint32_t)run;
+    h_rows[V] = nrows;
+    n_active2 = nrows;
+    ctx->ensure(w.blk_tab, (size_t)(h_tab.size() + V + 2) * 4 + 16);
+    uint32_t* d_tab = (uint32_t*)w.blk_tab.p;
+    uint32_t* d_rows = d_tab + h_tab.size();
+    HIPCHK(hipMemcpyAsync(d_part, h_part.data(), (size_t)(V + 1) * 4, hipMemcpyHostToDevice, s));
+    if (!h_tab.empty()) HIPCHK(hipMemcpyAsync(d_tab, h_tab.data(), h_tab.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_rows, h_rows.data(), (size_t)(V + 1) * 4, hipMemcpyHostToDevice, s));
+    ctx->ensure(w.dig2, std::max<uint64_t>(run, 1) * 4);
+    ctx->ensure(w.idx2, std::max<uint64_t>(run, 1) * 4);
+    hipLaunchKernelGGL(k_scatter_coarse, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)Hn * 4, s, (uint32_t*)w.dig2.p,
+                       (uint32_t*)w.idx2.p, (const uint32_t*)d_part, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p,
+                       two_n, chunk, Hn, 15u);
+    // level 2: LDS sort of every coarse bin (a "virtual window" of 2^15 buckets)
+    ctx->ensure(w.block_hist2, (size_t)std::max<uint32_t>(nrows, 1) * L2 * 4);
+    HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));
+    if (nrows)
+      hipLaunchKernelGGL(k_hist, dim3(nrows), dim3(SORT_THREADS), (size_t)L2 * 4, s, (uint32_t*)w.block_hist2.p,
+                         (const uint32_t*)w.dig2.p, (uint64_t)0, chunk2, L2, 0u, (const uint32_t*)d_part, (const uint32_t*)d_tab);
+    hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.block_hist2.p,
+                       (uint32_t*)w.counts.p, 0u, L2, V, (const uint32_t*)d_rows);
+    HIPCHK(hipStreamSynchronize(s));   // host tables must outlive their copies
   }
   int RT = 0;
   uint64_t total_slots = 0;
@@ -298,10 +360,15 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   // scatter
   ctx->ensure(w.slots, std::max<uint64_t>(total_slots, 2) * 4);
   HIPCHK(hipMemsetAsync(w.slots.p, 0xFF, std::max<uint64_t>(total_slots, 2) * 4, s));
-  if (lds_sort) {
+  if (one_level) {
     hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.slots.p,
                        (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n,
-                       chunk, L);
+                       chunk, L, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+  } else if (two_level) {
+    if (n_active2)
+      hipLaunchKernelGGL(k_scatter_lds, dim3(n_active2), dim3(SORT_THREADS), (size_t)L2 * 4, s, (uint32_t*)w.slots.p,
+                         (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist2.p, (const uint32_t*)w.dig2.p, (uint64_t)0,
+                         chunk2, L2, (const uint32_t*)w.part.p + V, (const uint32_t*)w.idx2.p, (const uint32_t*)w.blk_tab.p);
   } else {
     uint64_t grid = (n_entries + 255) / 256;
     hipLaunchKernelGGL(k_scatter, dim3((uint32_t)grid), dim3(256), 0, s, (uint32_t*)w.slots.p, (uint32_t*)w.cursor.p,
@@ -315,9 +382,13 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   const bool use_finish = !te;
   int r_stop = RT;
   if (use_finish) {
+    // a tail round is worth its launch + inversion latency (~0.25 ms) only while it still has a few million pairs;
+    // below that, and once no bucket holds more than FINISH_MAX elements, k_bucket_finish takes over
     uint32_t cap_elems = (max_bucket + (1u << logG) - 1) >> logG;   // largest bucket after the regular rounds
     r_stop = 0;
-    while (r_stop < RT && ((cap_elems + (1u << r_stop) - 1) >> r_stop) > FINISH_MAX) r_stop++;
+    while (r_stop < RT &&
+           (((cap_elems + (1u << r_stop) - 1) >> r_stop) > FINISH_MAX || w.h_info[3 + r_stop + 1] >= (1u << 21)))
+      r_stop++;
   }
   // outputs alternate between two buffers: size each for the largest round it receives
   uint64_t capA = 1, capB = 1;
@@ -418,7 +489,9 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   HIPCHK(hipEventRecord(w.ev[3], s));
 
   // bucket reduction
-  uint32_t TC = (uint32_t)std::max<uint64_t>(2, (nb + 65535) / 65536);
+  // buckets per lane: enough lanes to fill the chip, but never more than 16 buckets deep (2 additions each)
+  uint32_t TC = 2;
+  while (TC < 16 && nb / TC > 65536) TC *= 2;
   TC = std::min<uint32_t>(TC, L);
   uint32_t nchunks = (L + TC - 1) / TC;
   // bit-sliced weighting (Weierstrass path, enough chunks to matter, TC a power of two)

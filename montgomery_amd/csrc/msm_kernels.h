@@ -444,29 +444,55 @@ __global__ void __launch_bounds__(256) k_scatter(uint32_t* slots, uint32_t* curs
 
 constexpr int SORT_THREADS = 1024;
 
+// part_start == nullptr: window kk owns digits dig[kk * two_n ..) and block b the slice [b * chunk, (b+1) * chunk).
+// part_start != nullptr (second level of the two-level sort): "window" kk is the partition
+// [part_start[kk], part_start[kk + 1]) of a flat digit array.  bin = (l - 1) >> shift (shift > 0: coarse level).
+// blk_tab != nullptr (with part_start): 1-D grid over the ACTIVE (partition, block) pairs listed in blk_tab as
+// (kk, b, first histogram row of kk); partitions differ 50x in size, idle blocks would dominate otherwise.
 __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, const uint32_t* dig, uint64_t two_n,
-                                                       uint64_t chunk, uint32_t L) {
+                                                       uint64_t chunk, uint32_t L, uint32_t shift,
+                                                       const uint32_t* part_start, const uint32_t* blk_tab) {
   extern __shared__ uint32_t lds_hist[];
-  const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
+  uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
+  uint64_t hist_row = (uint64_t)kk * B + b;
+  if (blk_tab) {
+    kk = blk_tab[3 * blockIdx.x];
+    b = blk_tab[3 * blockIdx.x + 1];
+    hist_row = (uint64_t)blk_tab[3 * blockIdx.x + 2] + b;
+  }
   for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) lds_hist[l] = 0;
   __syncthreads();
-  const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
-  const uint32_t* d = dig + (uint64_t)kk * two_n;
+  uint64_t beg, end;
+  const uint32_t* d;
+  if (part_start) {
+    beg = (uint64_t)part_start[kk] + (uint64_t)b * chunk;
+    end = min(beg + chunk, (uint64_t)part_start[kk + 1]);
+    d = dig;
+  } else {
+    beg = (uint64_t)b * chunk;
+    end = min(beg + chunk, two_n);
+    d = dig + (uint64_t)kk * two_n;
+  }
   for (uint64_t j = beg + threadIdx.x; j < end; j += SORT_THREADS) {
     uint32_t l = d[j] & 0x7FFFFFFFu;
-    if (l) atomicAdd(&lds_hist[l - 1], 1u);
+    if (l) atomicAdd(&lds_hist[(l - 1) >> shift], 1u);
   }
   __syncthreads();
-  uint32_t* out = block_hist + ((uint64_t)kk * B + b) * L;
+  uint32_t* out = block_hist + hist_row * L;
   for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) out[l] = lds_hist[l];
 }
 
+// row_tab != nullptr: partition kk owns histogram rows [row_tab[kk], row_tab[kk + 1]) (variable block counts)
 __global__ void __launch_bounds__(256) k_colscan(uint32_t* block_hist, uint32_t* counts, uint32_t B, uint32_t L,
-                                                 uint32_t k_cnt) {
+                                                 uint32_t k_cnt, const uint32_t* row_tab) {
   uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= (uint64_t)k_cnt * L) return;
   uint32_t kk = (uint32_t)(id / L), l = (uint32_t)(id - (uint64_t)kk * L);
   uint32_t* p = block_hist + (uint64_t)kk * B * L + l;
+  if (row_tab) {
+    p = block_hist + (uint64_t)row_tab[kk] * L + l;
+    B = row_tab[kk + 1] - row_tab[kk];
+  }
   uint32_t run = 0;
   for (uint32_t b = 0; b < B; b++) {
     uint32_t v = p[(uint64_t)b * L];
@@ -478,21 +504,66 @@ __global__ void __launch_bounds__(256) k_colscan(uint32_t* block_hist, uint32_t*
 
 __global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(uint32_t* slots, const uint32_t* cursor,
                                                               const uint32_t* block_hist, const uint32_t* dig,
-                                                              uint64_t two_n, uint64_t chunk, uint32_t L) {
+                                                              uint64_t two_n, uint64_t chunk, uint32_t L,
+                                                              const uint32_t* part_start, const uint32_t* idx,
+                                                              const uint32_t* blk_tab) {
   extern __shared__ uint32_t lds_pos[];
-  const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
-  const uint32_t* base = block_hist + ((uint64_t)kk * B + b) * L;
+  uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
+  uint64_t hist_row = (uint64_t)kk * B + b;
+  if (blk_tab) {
+    kk = blk_tab[3 * blockIdx.x];
+    b = blk_tab[3 * blockIdx.x + 1];
+    hist_row = (uint64_t)blk_tab[3 * blockIdx.x + 2] + b;
+  }
+  const uint32_t* base = block_hist + hist_row * L;
   const uint32_t* cur = cursor + (uint64_t)kk * L;
   for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) lds_pos[l] = cur[l] + base[l];
   __syncthreads();
-  const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
-  const uint32_t* d = dig + (uint64_t)kk * two_n;
+  uint64_t beg, end;
+  const uint32_t* d;
+  if (part_start) {
+    beg = (uint64_t)part_start[kk] + (uint64_t)b * chunk;
+    end = min(beg + chunk, (uint64_t)part_start[kk + 1]);
+    d = dig;
+  } else {
+    beg = (uint64_t)b * chunk;
+    end = min(beg + chunk, two_n);
+    d = dig + (uint64_t)kk * two_n;
+  }
   for (uint64_t j = beg + threadIdx.x; j < end; j += SORT_THREADS) {
     uint32_t v = d[j];
     uint32_t l = v & 0x7FFFFFFFu;
     if (l) {
       uint32_t pos = atomicAdd(&lds_pos[l - 1], 1u);
-      slots[pos] = ((uint32_t)j << 1) | (v >> 31);
+      uint32_t entry = idx ? idx[j] : (uint32_t)j;
+      slots[pos] = (entry << 1) | (v >> 31);
+    }
+  }
+}
+
+// First level of the two-level sort (windows with more than 2^15 buckets, c > 16): entries of window kk are
+// partitioned by the high bits of their bucket index into Hn = L >> 15 coarse bins (k_hist with shift = 15 and
+// k_colscan provide the offsets); the entry keeps its low 15 bits (+1, so 0 still means "no entry"), its sign and
+// its entry index in two flat arrays.  Every block writes Hn sequential streams, which the L2 can merge -- the
+// direct scatter over 2^21 buckets could not.  The second level is the ordinary LDS sort per coarse bin.
+__global__ void __launch_bounds__(SORT_THREADS) k_scatter_coarse(uint32_t* dig2, uint32_t* idx2, const uint32_t* part_start,
+                                                                 const uint32_t* block_hist, const uint32_t* dig,
+                                                                 uint64_t two_n, uint64_t chunk, uint32_t Hn, uint32_t shift) {
+  extern __shared__ uint32_t lds_pos[];
+  const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
+  const uint32_t* base = block_hist + ((uint64_t)kk * B + b) * Hn;
+  for (uint32_t h = threadIdx.x; h < Hn; h += SORT_THREADS) lds_pos[h] = part_start[kk * Hn + h] + base[h];
+  __syncthreads();
+  const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
+  const uint32_t* d = dig + (uint64_t)kk * two_n;
+  const uint32_t lo_mask = (1u << shift) - 1;
+  for (uint64_t j = beg + threadIdx.x; j < end; j += SORT_THREADS) {
+    uint32_t v = d[j];
+    uint32_t l = v & 0x7FFFFFFFu;
+    if (l) {
+      uint32_t pos = atomicAdd(&lds_pos[(l - 1) >> shift], 1u);
+      dig2[pos] = (((l - 1) & lo_mask) + 1) | (v & 0x80000000u);
+      idx2[pos] = (uint32_t)j;
     }
   }
 }
