@@ -48,7 +48,9 @@ typedef struct msm_opts {
   int32_t c;            /* window size in bits, 0 = pick from N (windowSize, src/msm-common.ts:8-41, retuned) */
   int32_t unsafe;       /* accepted for API parity with msmUnsafe; the GPU path always handles edge cases */
   int32_t k_lo, k_hi;   /* window shard [k_lo, k_hi) for msm_window_sums; 0,0 = all windows */
-  int32_t reserved[4];
+  int32_t serial;       /* != 0: run the window groups one after the other on one stream (no overlap): phase_ms then
+                           hold exclusive kernel times -- used for roofline measurements */
+  int32_t reserved[3];
 } msm_opts;
 
 #define MSM_N_PHASES 8

@@ -29,7 +29,8 @@ EXPORTS = (
 
 
 class MsmOpts(C.Structure):
-    _fields_ = [("c", C.c_int32), ("unsafe", C.c_int32), ("k_lo", C.c_int32), ("k_hi", C.c_int32), ("reserved", C.c_int32 * 4)]
+    _fields_ = [("c", C.c_int32), ("unsafe", C.c_int32), ("k_lo", C.c_int32), ("k_hi", C.c_int32), ("serial", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 class MsmResult(C.Structure):

@@ -197,11 +197,11 @@ class MsmContext:
         buf = (C.c_uint8 * max(len(scalars), 1)).from_buffer_copy(bytes(scalars) or b"\0")
         return self._run(buf, n, 0, c, unsafe)
 
-    def run_device(self, dev_ptr: int, n: int, c: Optional[int] = None, unsafe: bool = False) -> Tuple[AffineResult, Dict]:
-        return self._run(C.c_void_p(dev_ptr), n, 1, c, unsafe)
+    def run_device(self, dev_ptr: int, n: int, c: Optional[int] = None, unsafe: bool = False, serial: bool = False) -> Tuple[AffineResult, Dict]:
+        return self._run(C.c_void_p(dev_ptr), n, 1, c, unsafe, serial)
 
-    def _run(self, ptr, n: int, on_device: int, c: Optional[int], unsafe: bool) -> Tuple[AffineResult, Dict]:
-        opts = MsmOpts(c=c or 0, unsafe=int(unsafe))
+    def _run(self, ptr, n: int, on_device: int, c: Optional[int], unsafe: bool, serial: bool = False) -> Tuple[AffineResult, Dict]:
+        opts = MsmOpts(c=c or 0, unsafe=int(unsafe), serial=int(serial))
         res = MsmResult()
         self._check(self._lib.msm_run(self._h, ptr, n, on_device, C.byref(opts), C.byref(res)))
         nb = self.coord_bytes

@@ -705,7 +705,7 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       failed[slot] = true;
     }
   };
-  const int nthreads = std::min<int>(msm_ctx::N_WS, (int)groups.size());
+  const int nthreads = (opts && opts->serial) ? 1 : std::min<int>(msm_ctx::N_WS, (int)groups.size());
   if (nthreads <= 1) {
     worker(0);
   } else {
@@ -740,7 +740,6 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     stats->c = pl.c;
     stats->K = pl.K;
   }
-  (void)opts;
   return MSM_OK;
 }
 
