@@ -339,3 +339,41 @@ def test_config1_inputs_2p14_on_gpu(gpu_ctx):
     res, info = gpu_ctx.run(O.scalars_to_bytes(sc))
     G = (C.gx, C.gy)
     assert res.as_tuple() == O.aff_scale(sum(s * ks[i & 255] for i, s in enumerate(sc)) % C.q, G, P_MOD), info
+
+
+def test_large_windows_two_level_sort_and_fallbacks(gpu_ctx):
+    """Window sizes beyond the one-level LDS sort: c = 17..24 take the two-level sort (coarse bins + per-bin LDS
+    sort); every path must give the same group element (known discrete logs at 2^16)."""
+    n = 1 << 16
+    a = O.scalars_from_bytes(gpu_ctx.generate_points(n, seed=41, want_scalars=True))
+    dev, sb = gpu_ctx.generate_scalars(n, seed=42, to_host=True)
+    s = O.scalars_from_bytes(sb)
+    G = (C.gx, C.gy)
+    exp = O.aff_scale(sum(x * y for x, y in zip(a, s)) % C.q, G, P_MOD)
+    for c in (16, 17, 19, 22, 24):
+        res, info = gpu_ctx.run_device(dev, n, c=c)
+        assert res.as_tuple() == exp, (c, info)
+        assert info["c"] == c and info["K"] == -(-127 // c)
+    # serialised window groups (used for exclusive roofline timing) give the same answer
+    res, _ = gpu_ctx.run_device(dev, n, serial=True)
+    assert res.as_tuple() == exp
+
+
+def test_skewed_buckets_tail_rounds(gpu_ctx, c_oracle):
+    """Heavily skewed digit distributions (few distinct scalars, tiny scalars) force deep trees, tail rounds with
+    operand descriptors and the finish kernel on very uneven buckets."""
+    pts, _ = O.random_points_bls377("gpu/skew", 512)
+    n = 4096
+    P = [pts[i % 512] for i in range(n)]
+    pb = O.points_to_bytes(P, 48)
+    for name, sc in (
+        ("two_values", [(12345 if i % 3 else C.q - 77) for i in range(n)]),
+        ("tiny", [i % 7 for i in range(n)]),
+        ("one_hot_window", [(i % 5 + 1) << 48 for i in range(n)]),
+    ):
+        sb = O.scalars_to_bytes(sc)
+        ref, _ = c_oracle.msm_bls377(pb, sb, 0)
+        gpu_ctx.set_points(pb)
+        for c in (None, 5, 16):
+            res, info = gpu_ctx.run(sb, c=c)
+            assert res.as_tuple() == ref, (name, c, info)
