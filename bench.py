@@ -28,7 +28,11 @@ PAIR_ALGO_BYTES = 288
 # 32x32->64 multiply-adds of one pair addition: 5 multiplications (325 each) + 1 squaring (247), 13 x 30-bit limbs
 PAIR_MADS = 5 * 325 + 247
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-INT_MAD_PEAK = 30.3e12         # v_mad_u64_u32 lane-ops/s measured on MI355X by tools/ubench_int.hip (profiles/ubench_int_r01.txt)
+INT_MAD_PEAK = 30.3e12         # v_mad_u64_u32 lane-ops/s measured on MI355X by tools/ubench_int.hip (profiles/r01_ubench_int.txt)
+# HBM bytes per pair addition of the regular tree rounds from the PMC passes committed in profiles/r01_pmc_2p24.json
+# (separate --pmc FETCH_SIZE / WRITE_SIZE runs at 2^24): FETCH_SIZE 169 B x 2 (gfx950 halves wide coalesced reads)
+# + WRITE_SIZE 147 B.  Round 1 (random 64-byte-sector gathers) reads 381 B uncorrected + writes 148 B per pair.
+PAIR_TRAFFIC_BYTES_PMC = 2 * 169 + 147
 
 
 def cpu_baseline(ctx, log2n_sample, seed):
@@ -250,7 +254,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pairs / launches * PAIR_TRAFFIC_BYTES_PMC,
+                "traffic_note": "bytes per launch = pair additions per launch x 485 B/pair from the committed PMC passes "
+                                "(profiles/r01_pmc_2p24.json, regular rounds); not collected inside this run",
+                "algorithmic_bytes_per_launch": pairs / launches * PAIR_ALGO_BYTES,
                 "algorithmic_bytes_per_pair_add": PAIR_ALGO_BYTES,
                 "pair_adds_per_step": pairs / max(len(infos), 1),
                 "avg_launch_ms": acc_ms / launches,
