@@ -217,9 +217,12 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
 
   // padding granule G = 2^g: about 1/8 of the mean bucket population (pads cost G/2 slots per bucket; what is
   // left after g regular rounds, ~8 elements per bucket, is finished without inversions by k_bucket_finish)
+  // Big buckets (>= 1024 entries) take G = mean / 16: half the pads (1/32 instead of 1/16 of all slots are identity
+  // pairs that occupy a lane for nothing) for twice the k_bucket_finish work, which is negligible there.
   uint64_t mean = std::max<uint64_t>(1, two_n / L);
+  const uint64_t per_bucket_left = mean >= 1024 ? 16 : 8;
   uint32_t logG = 1;
-  while (logG < 10 && (1ull << (logG + 1)) * 8 <= mean) logG++;
+  while (logG < 10 && (1ull << (logG + 1)) * per_bucket_left <= mean) logG++;
 
   ctx->ensure(w.dig, n_entries * 4);
   ctx->ensure(w.counts, nb * 4);
