@@ -173,8 +173,10 @@ struct RoundGeom {
 };
 
 RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out) {
-  const uint64_t target = (uint64_t)ctx->n_cu * 4 * 2 * 64;  // two waves per SIMD
-  const uint32_t max_steps = 512;
+  uint64_t target = (uint64_t)ctx->n_cu * 4 * 2 * 64;  // two waves per SIMD
+  uint32_t max_steps = 512;
+  if (const char* e = getenv("MSM_MAX_STEPS")) max_steps = (uint32_t)std::max(1, atoi(e));       // tuning knobs
+  if (const char* e = getenv("MSM_TARGET_WAVES")) target = (uint64_t)ctx->n_cu * 4 * 64 * std::max(1, atoi(e));
   uint64_t steps = (n_out + target - 1) / target;
   steps = std::max<uint64_t>(1, std::min<uint64_t>(steps, max_steps));
   uint64_t threads = (n_out + steps - 1) / steps;
