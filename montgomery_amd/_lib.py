@@ -24,7 +24,7 @@ OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_INV, OP_TO_MONT, OP_FROM_MONT = range(7)
 EXPORTS = (
     "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_set_points", "msm_run", "msm_window_sums",
     "msm_combine", "msm_plan", "msm_generate_points", "msm_generate_scalars", "msm_get_points", "msm_test_fp",
-    "msm_test_glv", "msm_test_batch_add",
+    "msm_test_glv", "msm_test_batch_add", "msm_test_batch_inverse",
 )
 
 
@@ -82,6 +82,7 @@ def load() -> C.CDLL:
     lib.msm_test_fp.argtypes = [vp, C.c_int, vp, vp, vp, u64]
     lib.msm_test_glv.argtypes = [vp, vp, vp, u64]
     lib.msm_test_batch_add.argtypes = [vp, vp, vp, vp, u64]
+    lib.msm_test_batch_inverse.argtypes = [vp, vp, vp, u64, C.c_uint32]
     for name in EXPORTS:
         if name not in ("msm_ctx_destroy", "msm_last_error"):
             getattr(lib, name).restype = C.c_int

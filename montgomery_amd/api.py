@@ -256,6 +256,13 @@ class MsmContext:
                         bool(int.from_bytes(r[32:36], "little")), bool(int.from_bytes(r[36:40], "little"))))
         return res
 
+    def test_batch_inverse(self, xs: BytesLike, per_lane: int = 7) -> bytes:
+        n = len(xs) // self.coord_bytes
+        bx = (C.c_uint8 * len(xs)).from_buffer_copy(bytes(xs))
+        out = (C.c_uint8 * len(xs))()
+        self._check(self._lib.msm_test_batch_inverse(self._h, bx, out, n, per_lane))
+        return bytes(out)
+
     def test_batch_add(self, g: BytesLike, h: BytesLike) -> bytes:
         n = len(g) // (2 * self.coord_bytes)
         bg = (C.c_uint8 * len(g)).from_buffer_copy(bytes(g))

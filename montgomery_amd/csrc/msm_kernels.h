@@ -1153,6 +1153,33 @@ __global__ void __launch_bounds__(256) k_test_fp(uint32_t* out, const uint32_t* 
   fe_store<F>(out + (uint64_t)i * NW, r);
 }
 
+// `batchInverse` (src/wasm/inverse.ts:220-271, JS twin src/curve-affine.ts:692-727): Montgomery's trick over a
+// contiguous array; lane t inverts elements [t * per_lane, (t + 1) * per_lane) with ONE fe_inv.
+// Operands and results are canonical Montgomery-form words; zeros are not allowed (as in the reference).
+__global__ void __launch_bounds__(256) k_test_batch_inverse(uint32_t* out, const uint32_t* xs, uint32_t n, uint32_t per_lane) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t beg = (uint64_t)t * per_lane, end = min(beg + per_lane, (uint64_t)n);
+  if (beg >= end) return;
+  Fe<F> acc, x;
+  fe_set_one<F>(acc);
+  for (uint64_t i = beg; i < end; i++) {            // out[i] temporarily holds the prefix product before x_i
+    fe_reduce_2p<F>(acc);
+    fe_store<F>(out + i * NW, acc);
+    fe_load<F>(x, xs + i * NW);
+    fe_mul<F>(acc, acc, x);
+  }
+  Fe<F> inv, pre, r;
+  fe_inv<F>(inv, acc);
+  for (uint64_t i = end; i-- > beg;) {
+    fe_load<F>(pre, out + i * NW);
+    fe_load<F>(x, xs + i * NW);
+    fe_mul<F>(r, inv, pre);
+    fe_mul<F>(inv, inv, x);
+    fe_reduce_2p<F>(r);
+    fe_store<F>(out + i * NW, r);
+  }
+}
+
 // out: n x 10 words: |s0| (4), |s1| (4), neg0, neg1
 __global__ void __launch_bounds__(256) k_test_glv(uint32_t* out, const uint32_t* scalars, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

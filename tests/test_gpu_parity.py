@@ -109,6 +109,17 @@ def test_fp_golden(gpu_ctx):
         assert [fb(out, i) for i in range(len(cases))] == [H(c[key]) for c in cases], key
 
 
+def test_batch_inverse(gpu_ctx):
+    """`batchInverse` vs single inverses for several batch lengths (src/field.test.ts:152-211)."""
+    from montgomery_amd import _lib
+
+    vals = [v for v in field_inputs() if v][:203]
+    mont = gpu_ctx.test_fp(_lib.OP_TO_MONT, b"".join(tb(v) for v in vals))
+    for per_lane in (1, 2, 7, 100, 1000):
+        out = gpu_ctx.test_fp(_lib.OP_FROM_MONT, gpu_ctx.test_batch_inverse(mont, per_lane))
+        assert all(fb(out, i) == pow(v, -1, P_MOD) for i, v in enumerate(vals)), per_lane
+
+
 # ---- GLV decomposition (src/glv/glv-test.ts:92-125) ------------------------------------------------
 
 
