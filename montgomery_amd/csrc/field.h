@@ -201,8 +201,8 @@ MSM_DEV void fe_select(Fe<C>& r, bool c, const Fe<C>& a, const Fe<C>& b) {  // r
 template <class C>
 MSM_DEV void fe_mul(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) {
   constexpr int N = C::NL;
-  static_assert(C::MU == LMASK, "modulus must be 1 mod 2^30");
-  static_assert(C::P[0] == 1, "modulus must be 1 mod 2^30");
+  // fast path: p == 1 mod 2^30 (BLS12-377 base and scalar fields): m = -t0, and m * P[0] = m needs no multiply
+  constexpr bool UNIT = (C::MU == LMASK) && (C::P[0] == 1);
   uint64_t t[N];
 #pragma unroll
   for (int j = 0; j < N; j++) t[j] = 0;
@@ -210,10 +210,16 @@ MSM_DEV void fe_mul(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) {
   for (int i = 0; i < N; i++) {
 #pragma unroll
     for (int j = 0; j < N; j++) t[j] += (uint64_t)a.l[i] * b.l[j];
-    uint32_t lo = (uint32_t)t[0] & LMASK;
-    uint32_t m = (0u - lo) & LMASK;
-    // t[0] + m*P[0] = t[0] + m is a multiple of 2^30
-    uint64_t carry = (t[0] + m) >> LB;
+    uint64_t carry;
+    uint32_t m;
+    if (UNIT) {
+      uint32_t lo = (uint32_t)t[0] & LMASK;
+      m = (0u - lo) & LMASK;
+      carry = (t[0] + m) >> LB;   // t[0] + m*P[0] = t[0] + m is a multiple of 2^30
+    } else {
+      m = ((uint32_t)t[0] * C::MU) & LMASK;
+      carry = (t[0] + (uint64_t)m * C::P[0]) >> LB;
+    }
 #pragma unroll
     for (int j = 1; j < N; j++) t[j] += (uint64_t)m * C::P[j];
     t[1] += carry;
@@ -262,11 +268,19 @@ MSM_DEV void fe_sqr(Fe<C>& r, const Fe<C>& a) {
     t[j] &= LMASK;
   }
   // reduction: N rows of m_i * p
+  constexpr bool UNIT = (C::MU == LMASK) && (C::P[0] == 1);
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    uint32_t lo = (uint32_t)t[i] & LMASK;
-    uint32_t m = (0u - lo) & LMASK;
-    uint64_t carry = (t[i] + m) >> LB;
+    uint32_t m;
+    uint64_t carry;
+    if (UNIT) {
+      uint32_t lo = (uint32_t)t[i] & LMASK;
+      m = (0u - lo) & LMASK;
+      carry = (t[i] + m) >> LB;
+    } else {
+      m = ((uint32_t)t[i] * C::MU) & LMASK;
+      carry = (t[i] + (uint64_t)m * C::P[0]) >> LB;
+    }
 #pragma unroll
     for (int j = 1; j < N; j++) t[i + j] += (uint64_t)m * C::P[j];
     t[i + 1] += carry;
@@ -342,7 +356,7 @@ MSM_DEV void fe_update_fg(int32_t (&f)[N], int32_t (&g)[N], const DivstepMatrix&
   g[N - 1] = (int32_t)cg;
 }
 
-// (d, e) <- (u d + v e, q d + r e) / 2^30 mod p, kept in (-2p, p); p == 1 mod 2^30 so p^-1 mod 2^30 = 1
+// (d, e) <- (u d + v e, q d + r e) / 2^30 mod p, kept in (-2p, p)
 template <class C>
 MSM_DEV void fe_update_de(int32_t (&d)[C::NL], int32_t (&e)[C::NL], const DivstepMatrix& t) {
   constexpr int N = C::NL;
@@ -351,8 +365,9 @@ MSM_DEV void fe_update_de(int32_t (&d)[C::NL], int32_t (&e)[C::NL], const Divste
   int32_t me = (t.q & sd) + (t.r & se);
   int64_t cd = (int64_t)t.u * d[0] + (int64_t)t.v * e[0];
   int64_t ce = (int64_t)t.q * d[0] + (int64_t)t.r * e[0];
-  md -= (int32_t)(((uint32_t)cd + (uint32_t)md) & LMASK);
-  me -= (int32_t)(((uint32_t)ce + (uint32_t)me) & LMASK);
+  // make the low 30 bits vanish: md, me += -(p^-1 (c + p m)) mod 2^30  (p^-1 mod 2^30 = 1 for the BLS12-377 fields)
+  md -= (int32_t)((C::PINV30 * (uint32_t)cd + (uint32_t)md) & LMASK);
+  me -= (int32_t)((C::PINV30 * (uint32_t)ce + (uint32_t)me) & LMASK);
   cd += (int64_t)C::P[0] * md;
   ce += (int64_t)C::P[0] * me;
   cd >>= LB; ce >>= LB;

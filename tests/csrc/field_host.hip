@@ -36,10 +36,11 @@ static void op(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
 }
 
 extern "C" {
-// field 0 = Fp377 (12 words), 1 = Fp253 (8 words); operands are canonical Montgomery-form words
+// field 0 = Fp377 (12 words), 1 = Fp253 (8 words), 2 = Fp381 (12 words); operands are canonical Montgomery-form words
 void host_fp_op(int field, int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
   if (field == 0) op<Fp377>(which, a, b, out);
-  else op<Fp253>(which, a, b, out);
+  else if (field == 1) op<Fp253>(which, a, b, out);
+  else op<Fp381>(which, a, b, out);
 }
 void host_glv(const uint32_t* s8, uint32_t* out10) {
   uint32_t s[8];

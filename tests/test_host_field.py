@@ -14,6 +14,7 @@ LIB = os.path.join(ROOT, "tests", "csrc", "libfield_host.so")
 FIELDS = {
     0: (O.BLS12_377.p, 12, 13),   # modulus, packed words, 30-bit limbs
     1: (O.ED_ON_BLS12_377.p, 8, 9),
+    2: (0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 12, 13),  # BLS12-381: p != 1 mod 2^30
 }
 
 
@@ -35,7 +36,7 @@ def fp_op(lib, field, which, a, b=0):
     return sum(int(w) << (32 * i) for i, w in enumerate(out))
 
 
-@pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("field", [0, 1, 2])
 def test_mul_sqr_add_sub(lib, field):
     p, _, nl = FIELDS[field]
     R = 1 << (30 * nl)
@@ -49,7 +50,7 @@ def test_mul_sqr_add_sub(lib, field):
         assert fp_op(lib, field, 3, a, b) == (a - b) % p
 
 
-@pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("field", [0, 1, 2])
 def test_inverse_divsteps_and_fermat(lib, field):
     """fe_inv (division steps) == fe_inv_fermat == a^-1 R^2 for Montgomery-form input a R."""
     p, _, nl = FIELDS[field]
