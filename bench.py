@@ -125,8 +125,9 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (functional check of the sharded path on one GPU)")
-    ap.add_argument("--curve", choices=["bls12-377", "ed377"], default="bls12-377",
-                    help="ed377 = BASELINE configs[3]: twisted Edwards msmBasic path (single GPU, use --log2n 20)")
+    ap.add_argument("--curve", choices=["bls12-377", "bls12-381", "ed377"], default="bls12-377",
+                    help="ed377 = BASELINE configs[3]: twisted Edwards msmBasic path (single GPU, use --log2n 20); "
+                         "bls12-381 = the same batched-affine path over the BLS12-381 G1 constants (no CPU baseline leg)")
     args = ap.parse_args()
 
     import torch
@@ -157,7 +158,10 @@ def main():
     n = 1 << args.log2n
     if args.curve == "ed377":
         return bench_ed377(args, torch)
-    ctx = MsmContext(device=local_rank)
+    from montgomery_amd import _lib as _abi
+
+    is381 = args.curve == "bls12-381"
+    ctx = MsmContext(_abi.CURVE_BLS12_381_G1 if is381 else _abi.CURVE_BLS12_377_G1, device=local_rank)
     ctx.generate_points(n, seed=20261002)   # identical on every rank
     c, K = ctx.plan(n, args.c or None)
     shards = window_shards(K, world)
@@ -226,7 +230,7 @@ def main():
                 "phase_ms": xi["phase_ms"],
             }
         out = {
-            "metric": "BLS12-377 G1 MSM throughput",
+            "metric": f"{'BLS12-381' if is381 else 'BLS12-377'} G1 MSM throughput",
             "value": n * args.steps / dt,
             "unit": "points/s",
             "n_gpus": world,
@@ -239,7 +243,7 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"bls12-377-g1-msm-2^{args.log2n}",
+                "workload": f"{args.curve}-g1-msm-2^{args.log2n}",
                 "log2_n": args.log2n,
                 "window_bits": c,
                 "windows": K,
@@ -276,7 +280,7 @@ def main():
             "phase_ms": phase,
             "result_is_infinity": bool(last.isZero) if last is not None else None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not is381:
             out["cpu_baseline"] = cpu_baseline(ctx, min(args.cpu_log2n, args.log2n), seed=777)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -37,7 +37,8 @@ enum {
 
 enum {
   MSM_CURVE_BLS12_377_G1 = 0,     /* Weierstrass + GLV, batched-affine path: src/msm-batched-affine.ts */
-  MSM_CURVE_ED_ON_BLS12_377 = 1   /* twisted Edwards, generic path: src/msm-basic.ts */
+  MSM_CURVE_ED_ON_BLS12_377 = 1,  /* twisted Edwards, generic path: src/msm-basic.ts */
+  MSM_CURVE_BLS12_381_G1 = 2      /* Weierstrass + GLV, batched-affine path; src/concrete/bls12-381.params.ts */
 };
 
 typedef struct msm_ctx msm_ctx;

@@ -15,6 +15,11 @@ const bls12377Params = {
   modulus: BigInt("0x01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001"),
   order: BigInt("0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001"),
 };
+const bls12381Params = {
+  label: "bls12-381",
+  modulus: BigInt("0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab"),
+  order: BigInt("0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001"),
+};
 const edOnBls12377Params = {
   label: "ed-on-bls12-377",
   modulus: BigInt("0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001"),
@@ -60,7 +65,13 @@ function createCurve(params, curveId, coordBytes, device) {
   return { params, Parallel, close() { hip.destroyContext(ctx); } };
 }
 
-const Weierstrass = { create(params, device) { return createCurve(params, hip.CURVE_BLS12_377_G1, 48, device); } };
+const weierstrassIds = { "bls12-377": hip.CURVE_BLS12_377_G1, "bls12-381": hip.CURVE_BLS12_381_G1 };
+const Weierstrass = {
+  create(params, device) {
+    if (!(params.label in weierstrassIds)) throw new Error(`curve ${params.label} has no device constants`);
+    return createCurve(params, weierstrassIds[params.label], 48, device);
+  },
+};
 const TwistedEdwards = { create(params, device) { return createCurve(params, hip.CURVE_ED_ON_BLS12_377, 32, device); } };
 
 // compute_msm(points: {x, y, isZero}[] | Buffer, scalars: bigint[] | Buffer) -> {x, y}
@@ -81,4 +92,4 @@ async function compute_msm(curve, coordBytes, inputPoints, inputScalars) {
   return { x: result.x, y: result.y, isZero: result.isZero };
 }
 
-module.exports = { hip, Weierstrass, TwistedEdwards, bls12377Params, edOnBls12377Params, compute_msm, leBytesToBigint, bigintToLeBytes };
+module.exports = { hip, Weierstrass, TwistedEdwards, bls12377Params, bls12381Params, edOnBls12377Params, compute_msm, leBytesToBigint, bigintToLeBytes };

@@ -59,6 +59,27 @@ BLS12_377_PARAMS = WeierstrassParams(
 )
 
 
+BLS12_381_PARAMS = WeierstrassParams(  # src/concrete/bls12-381.params.ts:6-55
+    label="bls12-381",
+    modulus=0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB,
+    order=0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+    cofactor=0x396C8C005555E1568C00AAAB0000AAAB,
+    a=0,
+    b=4,
+    generator=(
+        0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+        0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1,
+    ),
+    endomorphism=(
+        0xD201000000010000 ** 2 - 1,
+        0x1A0111EA397FE699EC02408663D4DE85AA0D857D89759AD4897D29650FB85F9B409427EB4F49FFFD8BFD00000000AAAC,
+    ),
+)
+
+# curves with device constants (montgomery_amd/csrc/constants_gen.h), by label
+_WEIERSTRASS_CURVE_IDS = {"bls12-377": _lib.CURVE_BLS12_377_G1, "bls12-381": _lib.CURVE_BLS12_381_G1}
+
+
 @dataclass(frozen=True)
 class TwistedEdwardsParams:
     """src/concrete/ed-on-bls12-377.params.ts:5-31"""
@@ -125,7 +146,7 @@ class MsmContext:
         self.curve = curve
         self.device = device
         self.n_points = 0
-        self.coord_bytes = 48 if curve == _lib.CURVE_BLS12_377_G1 else 32
+        self.coord_bytes = 32 if curve == _lib.CURVE_ED_ON_BLS12_377 else 48
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -360,10 +381,11 @@ class Weierstrass:
     """Curve module as `Weierstraß.create(params)` returns it (src/parallel.ts:147-160), MSM path only."""
 
     def __init__(self, params: WeierstrassParams, device: int = 0):
-        if params.label != "bls12-377":
-            raise MsmError(_lib.MSM_ERR_ARG, f"curve {params.label!r} has no device constants (only bls12-377 G1)")
+        if params.label not in _WEIERSTRASS_CURVE_IDS:
+            raise MsmError(_lib.MSM_ERR_ARG, f"curve {params.label!r} has no device constants "
+                                             f"(have {sorted(_WEIERSTRASS_CURVE_IDS)})")
         self.params = params
-        self.context = MsmContext(_lib.CURVE_BLS12_377_G1, device)
+        self.context = MsmContext(_WEIERSTRASS_CURVE_IDS[params.label], device)
         self.Parallel = _Parallel(self.context, params)
 
     @classmethod
@@ -408,6 +430,7 @@ class _LazyCurve:
 
 
 BLS12377 = _LazyCurve(BLS12_377_PARAMS)
+BLS12381 = _LazyCurve(BLS12_381_PARAMS)  # src/concrete/bls12-381.ts
 
 
 def compute_msm_ed(inputPoints, inputScalars, curve: Optional[TwistedEdwards] = None) -> Dict[str, int]:

@@ -79,8 +79,8 @@ struct GlvHalf {
 };
 
 // s (8 words, < q) -> s0 + s1 * lambda, as sign + magnitude each
+template <class G>
 MSM_DEV void glv_decompose(GlvHalf& h0, GlvHalf& h1, const uint32_t (&s)[8]) {
-  using G = GlvBls377;
   // s_hi = s >> k  (k = 116): 253 - 116 = 137 bits -> 5 words
   uint32_t shi[5];
   bn_shr<5, 8>(shi, s, G::K_SHIFT);

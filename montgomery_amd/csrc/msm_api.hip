@@ -45,6 +45,23 @@ inline uint32_t ceil_log2_u64(uint64_t n) {
 
 }  // namespace
 
+// host-side view of the per-curve constants (constants_gen.h)
+struct CurveInfo {
+  const uint32_t* pw;   // base field modulus, 12 words
+  const uint32_t* q;    // scalar field order, 8 words
+  const uint32_t* gx;   // generator (Weierstrass curves), 12 words each
+  const uint32_t* gy;
+  int glv_max_bits;     // Scalar.maxBits after decomposition, src/wasm/glv.ts:216-226
+  int q_bits;           // bit length of q
+};
+
+inline const CurveInfo& curve_info(int curve) {
+  static const CurveInfo bls377 = {msm::Fp377::PW, msm::GlvBls377::Q, msm::Fp377::GXW, msm::Fp377::GYW, msm::GlvBls377::MAX_BITS, 253};
+  static const CurveInfo bls381 = {msm::Fp381::PW, msm::GlvBls381::Q, msm::Fp381::GXW, msm::Fp381::GYW, msm::GlvBls381::MAX_BITS, 255};
+  static const CurveInfo ed377 = {msm::Fp253::PW, msm::FRED_Q, nullptr, nullptr, 251, 251};
+  return curve == MSM_CURVE_BLS12_381_G1 ? bls381 : curve == MSM_CURVE_ED_ON_BLS12_377 ? ed377 : bls377;
+}
+
 struct msm_ctx {
   int curve = 0;
   int device = 0;
@@ -99,6 +116,18 @@ struct msm_ctx {
   }
 };
 
+// curve dispatch for the templated Weierstrass kernels
+#define W_LAUNCH(ctx, KERNEL, ...)                                                         \
+  do {                                                                                     \
+    if ((ctx)->curve == MSM_CURVE_BLS12_381_G1) hipLaunchKernelGGL((KERNEL<msm::CvBls381>), __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<msm::CvBls377>), __VA_ARGS__);                          \
+  } while (0)
+#define W_LAUNCH_MODE(ctx, KERNEL, MODE, ...)                                              \
+  do {                                                                                     \
+    if ((ctx)->curve == MSM_CURVE_BLS12_381_G1) hipLaunchKernelGGL((KERNEL<msm::CvBls381, MODE>), __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<msm::CvBls377, MODE>), __VA_ARGS__);                    \
+  } while (0)
+
 #include "msm_gen.h"
 
 namespace {
@@ -120,7 +149,7 @@ int fail_hip(msm_ctx* ctx, const HipFail& f) {
 // GPU-tuned window size (the reference's table, src/msm-common.ts:25-41, was tuned for 16 CPU
 // threads and copies points; here the trade is 2N*K pair additions against K*2^(c-1) buckets to
 // reduce, with histogram/scatter counters that must stay cache friendly).
-int pick_window(bool te, uint64_t n) {
+int pick_window(bool te, uint64_t n, int glv_max_bits) {
   // candidates whose top window is not degenerate (bits left for the last digit close to c):
   //   Weierstrass + GLV, b + 1 = 127: c = 16 (K = 8, 15 bits), 13 (K = 10, 10 bits), 10, 8, 5, 4
   //   twisted Edwards, b + 1 = 252:   c = 16 (K = 16, 12 bits), 14 (K = 18), 12 (K = 21), 9, 7, 6, 4 (exact)
@@ -128,7 +157,7 @@ int pick_window(bool te, uint64_t n) {
   // additions on poorly filled lanes).  c <= 16 keeps one window's counters inside the 160 KB LDS for the sort.
   static const int cand_w[] = {4, 5, 8, 10, 13, 16};
   static const int cand_te[] = {4, 6, 7, 9, 12, 14, 16};
-  const int b1 = te ? 252 : GlvBls377::MAX_BITS + 1;
+  const int b1 = te ? 252 : glv_max_bits + 1;
   const double entries = te ? (double)n : 2.0 * (double)n;
   int best = 4;
   double best_cost = 1e300;
@@ -148,10 +177,11 @@ struct Plan {
 
 int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
   const bool te = ctx && ctx->is_te();
-  int c = (opts && opts->c > 0) ? opts->c : pick_window(te, n);
+  const int glv_bits = curve_info(ctx ? ctx->curve : MSM_CURVE_BLS12_377_G1).glv_max_bits;
+  int c = (opts && opts->c > 0) ? opts->c : pick_window(te, n, glv_bits);
   if (c < 2 || c > 24) return MSM_ERR_ARG;
   // b = Scalar.maxBits (126 after GLV, src/wasm/glv.ts:216-226) or Scalar.sizeInBits (251, src/msm-basic.ts:56)
-  const int b = te ? 251 : GlvBls377::MAX_BITS;
+  const int b = te ? 251 : glv_bits;
   pl.c = c;
   pl.K = (b + 1 + c - 1) / c;  // K = ceil((b + 1) / c), src/msm-batched-affine.ts:90, src/msm-basic.ts:59
   pl.L_log = c - 1;
@@ -266,7 +296,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       hipLaunchKernelGGL(te::k_te_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, cnt, d_scalars, (uint32_t)n, pl.c,
                          pl.K, k_lo, kc);
     else
-      hipLaunchKernelGGL(k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, cnt, d_scalars, (uint32_t)n, pl.c, pl.K,
+      W_LAUNCH(ctx, k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, cnt, d_scalars, (uint32_t)n, pl.c, pl.K,
                          k_lo, kc);
   }
   HIPCHK(hipEventRecord(w.ev[1], s));
@@ -438,11 +468,11 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       a.steps = g.steps;
       if (r == 1) {
         if (te) hipLaunchKernelGGL(te::k_te_add<MODE_GATHER>, dim3(g.grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(k_batch_add<MODE_GATHER>, dim3(g.grid), dim3(256), 0, s, a);
+        else W_LAUNCH_MODE(ctx, k_batch_add, MODE_GATHER, dim3(g.grid), dim3(256), 0, s, a);
         HIPCHK(hipEventRecord(w.ev[6], s));
       } else {
         if (te) hipLaunchKernelGGL(te::k_te_add<MODE_REGULAR>, dim3(g.grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(k_batch_add<MODE_REGULAR>, dim3(g.grid), dim3(256), 0, s, a);
+        else W_LAUNCH_MODE(ctx, k_batch_add, MODE_REGULAR, dim3(g.grid), dim3(256), 0, s, a);
       }
       st.n_pairs += n_out;
       fin = buf[cur];
@@ -473,7 +503,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
         a.desc = (const uint32_t*)w.desc.p;
       }
       if (te) hipLaunchKernelGGL(te::k_te_add<MODE_SEARCH>, dim3(g.grid), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL(k_batch_add<MODE_SEARCH>, dim3(g.grid), dim3(256), 0, s, a);
+      else W_LAUNCH_MODE(ctx, k_batch_add, MODE_SEARCH, dim3(g.grid), dim3(256), 0, s, a);
       st.n_pairs += n_out;
       fin = buf[cur];
       fin_cap = cap[cur];
@@ -486,7 +516,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   const uint32_t* bucket_proj = nullptr;
   if (use_finish && total_slots > 0) {
     ctx->ensure(w.bucket_proj, nb * 3 * NL * 4);
-    hipLaunchKernelGGL(k_bucket_finish, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.bucket_proj.p, fin,
+    W_LAUNCH(ctx, k_bucket_finish, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.bucket_proj.p, fin,
                        fin_cap, off_fin, (uint32_t)nb);
     bucket_proj = (const uint32_t*)w.bucket_proj.p;
   }
@@ -514,30 +544,30 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
                          (const uint32_t*)w.columns.p, nchunks);
     } else if (bit_sliced) {
       ctx->ensure(w.rows_sum, (size_t)kc * nchunks * 3 * NL * 4);
-      hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p,
+      W_LAUNCH(ctx, k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p,
                          (uint32_t*)w.rows_sum.p, fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
       const uint32_t per_block = 2 * WS_THREADS;
       const uint32_t nblk = (nchunks + per_block - 1) / per_block;
       ctx->ensure(w.columns2, (size_t)kc * (nbits + 1) * nblk * 3 * NL * 4);
       ctx->ensure(w.partials, (size_t)kc * (nbits + 1) * 36 * 4);
-      hipLaunchKernelGGL(k_bit_tree, dim3(nblk, nbits + 1, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.columns2.p,
+      W_LAUNCH(ctx, k_bit_tree, dim3(nblk, nbits + 1, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.columns2.p,
                          (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, per_block, nbits, 1, 0);
-      hipLaunchKernelGGL(k_bit_tree, dim3(1, nbits + 1, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
+      W_LAUNCH(ctx, k_bit_tree, dim3(1, nbits + 1, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
                          (const uint32_t*)w.columns2.p, (const uint32_t*)nullptr, nblk, nblk, nbits, 0, 1);
     } else {
-      hipLaunchKernelGGL(k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, (uint32_t*)nullptr,
+      W_LAUNCH(ctx, k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, (uint32_t*)nullptr,
                          fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
       if (nchunks > 2 * WS_THREADS) {
         // two-stage: blocks of 2 columns per lane, then one block per window over the block sums
         const uint32_t per_block = 2 * WS_THREADS;
         const uint32_t nblk = (nchunks + per_block - 1) / per_block;
         ctx->ensure(w.columns2, (size_t)kc * nblk * 3 * NL * 4);
-        hipLaunchKernelGGL(k_column_tree, dim3(nblk, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.columns2.p,
+        W_LAUNCH(ctx, k_column_tree, dim3(nblk, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.columns2.p,
                            (const uint32_t*)w.columns.p, nchunks, per_block);
-        hipLaunchKernelGGL(k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
+        W_LAUNCH(ctx, k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
                            (const uint32_t*)w.columns2.p, nblk);
       } else {
-        hipLaunchKernelGGL(k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
+        W_LAUNCH(ctx, k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
                            (const uint32_t*)w.columns.p, nchunks);
       }
     }
@@ -759,7 +789,7 @@ extern "C" {
 int msm_ctx_create(msm_ctx** out, int curve, int device) {
   if (!out) return MSM_ERR_ARG;
   *out = nullptr;
-  if (curve != MSM_CURVE_BLS12_377_G1 && curve != MSM_CURVE_ED_ON_BLS12_377) return MSM_ERR_ARG;
+  if (curve != MSM_CURVE_BLS12_377_G1 && curve != MSM_CURVE_ED_ON_BLS12_377 && curve != MSM_CURVE_BLS12_381_G1) return MSM_ERR_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MSM_ERR_NO_DEVICE;
   msm_ctx* ctx = new msm_ctx();
@@ -791,7 +821,7 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     delete ctx;
     return MSM_ERR_HIP;
   }
-  ctx->hc.F.init(Fp377::PW);
+  ctx->hc.F.init(curve == MSM_CURVE_BLS12_381_G1 ? Fp381::PW : Fp377::PW);
   ctx->k_dev_to_host = ctx->hc.F.pow2(378);
   {
     uint32_t pw[12] = {0};
@@ -847,7 +877,7 @@ int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, 
         hipLaunchKernelGGL(te::k_te_points_from_wire, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p, d_wire,
                            n, check_curve, (uint32_t*)ctx->errflag.p);
       else
-        hipLaunchKernelGGL(k_points_from_wire, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p, d_wire, n,
+        W_LAUNCH(ctx, k_points_from_wire, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p, d_wire, n,
                            check_curve, (uint32_t*)ctx->errflag.p);
     }
     HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->errflag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -875,7 +905,7 @@ int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_ou
 int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, uint8_t* partials_out,
                     msm_result* stats) {
   if (!ctx || !partials_out || (!scalars && n)) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: null argument");
-  if (ctx->curve != MSM_CURVE_BLS12_377_G1) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: curve not supported yet");
+  if (ctx->is_te()) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: curve not supported yet");
   if (n > ctx->n_points) return fail(ctx, MSM_ERR_NO_POINTS, "msm_window_sums: %llu scalars but %llu resident points",
                                      (unsigned long long)n, (unsigned long long)ctx->n_points);
   Plan pl;
@@ -1043,7 +1073,7 @@ int msm_test_fp(msm_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_
       hipLaunchKernelGGL(te::k_te_test_fp, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)(d + 2 * n * nb),
                          (const uint32_t*)d, (const uint32_t*)(d + n * nb), (uint32_t)n, op);
     else
-      hipLaunchKernelGGL(k_test_fp, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)(d + 2 * n * nb),
+      W_LAUNCH(ctx, k_test_fp, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)(d + 2 * n * nb),
                          (const uint32_t*)d, (const uint32_t*)(d + n * nb), (uint32_t)n, op);
     HIPCHK(hipMemcpyAsync(out, d + 2 * n * nb, n * nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1063,7 +1093,7 @@ int msm_test_batch_inverse(msm_ctx* ctx, const uint8_t* xs, uint8_t* out, uint64
     uint8_t* d = (uint8_t*)ctx->misc.p;
     HIPCHK(hipMemcpyAsync(d, xs, n * 48, hipMemcpyHostToDevice, ctx->stream));
     uint64_t lanes = (n + per_lane - 1) / per_lane;
-    hipLaunchKernelGGL(k_test_batch_inverse, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, ctx->stream,
+    W_LAUNCH(ctx, k_test_batch_inverse, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, ctx->stream,
                        (uint32_t*)(d + n * 48), (const uint32_t*)d, (uint32_t)n, per_lane);
     HIPCHK(hipMemcpyAsync(out, d + n * 48, n * 48, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1082,7 +1112,7 @@ int msm_test_glv(msm_ctx* ctx, const uint8_t* scalars, uint8_t* out, uint64_t n)
     ctx->ensure(ctx->misc, n * 72 + 64);
     uint8_t* d = (uint8_t*)ctx->misc.p;
     HIPCHK(hipMemcpyAsync(d, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_test_glv, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)(d + n * 32),
+    W_LAUNCH(ctx, k_test_glv, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)(d + n * 32),
                        (const uint32_t*)d, (uint32_t)n);
     HIPCHK(hipMemcpyAsync(out, d + n * 32, n * 40, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1095,7 +1125,7 @@ int msm_test_glv(msm_ctx* ctx, const uint8_t* scalars, uint8_t* out, uint64_t n)
 
 int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t* out, uint64_t n) {
   if (!ctx || !g || !h || !out || n == 0) return fail(ctx, MSM_ERR_ARG, "msm_test_batch_add: bad argument");
-  if (ctx->curve != MSM_CURVE_BLS12_377_G1) return fail(ctx, MSM_ERR_ARG, "msm_test_batch_add: curve not supported yet");
+  if (ctx->is_te()) return fail(ctx, MSM_ERR_ARG, "msm_test_batch_add: curve not supported yet");
   try {
     HIPCHK(hipSetDevice(ctx->device));
     // rows for 2n points: pair e = (row 2e, row 2e + 1), gathered through identity payload slots
@@ -1115,7 +1145,7 @@ int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t
     HIPCHK(hipMemcpyAsync(wire.p, inter.data(), 2 * n * 96, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(slots.p, sl.data(), 2 * n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_points_from_wire, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)rows.p,
+    W_LAUNCH(ctx, k_points_from_wire, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)rows.p,
                        (const uint32_t*)wire.p, 2 * n, 0, (uint32_t*)ctx->errflag.p);
     RoundGeom gm = round_geom(ctx, n);
     gm.steps = (uint32_t)std::min<uint64_t>(n, 3);  // exercise the shared inversion with a few pairs per lane
@@ -1131,7 +1161,7 @@ int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t
     a.scratch = (uint32_t*)scr.p;
     a.n_out = n;
     a.steps = gm.steps;
-    hipLaunchKernelGGL(k_batch_add<MODE_GATHER>, dim3(gm.grid), dim3(256), 0, ctx->stream, a);
+    W_LAUNCH_MODE(ctx, k_batch_add, MODE_GATHER, dim3(gm.grid), dim3(256), 0, ctx->stream, a);
     std::vector<uint32_t> planes(n * 24);
     HIPCHK(hipMemcpyAsync(planes.data(), outb.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1160,7 +1190,7 @@ int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t
 
 int msm_generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
   if (!ctx) return MSM_ERR_ARG;
-  if (ctx->curve != MSM_CURVE_BLS12_377_G1) return fail(ctx, MSM_ERR_ARG, "msm_generate_points: curve not supported yet");
+  if (ctx->is_te()) return fail(ctx, MSM_ERR_ARG, "msm_generate_points: curve not supported yet");
   try {
     HIPCHK(hipSetDevice(ctx->device));
     return msm_gen::generate_points(ctx, n, seed, a_out);

@@ -32,22 +32,35 @@ __host__ __device__ inline bool ge_q(const uint64_t* s, const uint64_t* q) {
   return true;
 }
 
-__host__ __device__ inline void draw_scalar(uint64_t* s, uint64_t seed, uint64_t i, const uint64_t* q) {
+__host__ __device__ inline void draw_scalar(uint64_t* s, uint64_t seed, uint64_t i, const uint64_t* q, int q_bits) {
   for (uint64_t attempt = 0; attempt < 256; attempt++) {
     for (int j = 0; j < 4; j++) s[j] = mix64(seed ^ 0x5ca1ab1e00000000ull, (i * 256 + attempt) * 4 + j);
-    s[3] &= (1ull << 61) - 1;  // 253 bits
+    s[3] &= (1ull << (q_bits - 192)) - 1;  // mask to the bit length of q, then reject
     if (!ge_q(s, q)) return;
   }
   s[0] = 1; s[1] = s[2] = s[3] = 0;
 }
 
-__global__ void __launch_bounds__(256) k_gen_scalars(uint64_t* out, uint64_t n, uint64_t seed) {
+struct Q256 {
+  uint64_t v[4];
+  int bits;
+};
+
+inline Q256 scalar_order(const msm_ctx* ctx) {
+  const CurveInfo& ci = curve_info(ctx->curve);
+  Q256 q;
+  for (int j = 0; j < 4; j++) q.v[j] = (uint64_t)ci.q[2 * j] | ((uint64_t)ci.q[2 * j + 1] << 32);
+  q.bits = ci.q_bits;
+  return q;
+}
+
+__global__ void __launch_bounds__(256) k_gen_scalars(uint64_t* out, uint64_t n, uint64_t seed, Q256 qq) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t q[4], s[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) q[j] = (uint64_t)msm::GlvBls377::Q[2 * j] | ((uint64_t)msm::GlvBls377::Q[2 * j + 1] << 32);
-  draw_scalar(s, seed, i, q);
+  for (int j = 0; j < 4; j++) q[j] = qq.v[j];
+  draw_scalar(s, seed, i, q, qq.bits);
 #pragma unroll
   for (int j = 0; j < 4; j++) out[i * 4 + j] = s[j];
 }
@@ -60,7 +73,8 @@ inline int generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void** dev_
     dst = ctx->scal.p;
   }
   if (n) {
-    hipLaunchKernelGGL(k_gen_scalars, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint64_t*)dst, n, seed);
+    hipLaunchKernelGGL(k_gen_scalars, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint64_t*)dst, n, seed,
+                       scalar_order(ctx));
     if (host_out) HIPCHK(hipMemcpyAsync(host_out, dst, n * 32, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -76,8 +90,10 @@ __host__ __device__ inline uint32_t table_index(uint64_t seed, uint64_t i, int j
 }
 
 // tables: N_BASIS * TBL point rows (x, y used); rows_out: n point rows
+template <class CV>
 __global__ void __launch_bounds__(256) k_gen_points(uint32_t* rows_out, const uint32_t* tables, uint64_t n, uint64_t seed) {
   using namespace msm;
+  using F = typename CV::F;
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Proj<F> acc;
@@ -136,15 +152,16 @@ inline int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_o
   using namespace msm_host;
   if (n >= (1ull << 30)) return MSM_ERR_ARG;
   const Curve6& C = ctx->hc;
-  uint64_t q[4];
-  for (int j = 0; j < 4; j++) q[j] = (uint64_t)msm::GlvBls377::Q[2 * j] | ((uint64_t)msm::GlvBls377::Q[2 * j + 1] << 32);
+  const CurveInfo& ci = curve_info(ctx->curve);
+  const Q256 qq = scalar_order(ctx);
+  const uint64_t* q = qq.v;
   // generator in host Montgomery form
   Proj6 G;
   {
     Fe6 t;
-    for (int i = 0; i < 6; i++) t.v[i] = (uint64_t)msm::Fp377::GXW[2 * i] | ((uint64_t)msm::Fp377::GXW[2 * i + 1] << 32);
+    for (int i = 0; i < 6; i++) t.v[i] = (uint64_t)ci.gx[2 * i] | ((uint64_t)ci.gx[2 * i + 1] << 32);
     C.F.mul(G.X, t, ctx->k_dev_to_host);
-    for (int i = 0; i < 6; i++) t.v[i] = (uint64_t)msm::Fp377::GYW[2 * i] | ((uint64_t)msm::Fp377::GYW[2 * i + 1] << 32);
+    for (int i = 0; i < 6; i++) t.v[i] = (uint64_t)ci.gy[2 * i] | ((uint64_t)ci.gy[2 * i + 1] << 32);
     C.F.mul(G.Y, t, ctx->k_dev_to_host);
     G.Z = C.F.one;
   }
@@ -153,7 +170,7 @@ inline int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_o
   Fe6 one_plain = {{1, 0, 0, 0, 0, 0}};
   for (int j = 0; j < N_BASIS; j++) {
     U256 b;
-    draw_scalar(b.v, seed ^ 0xba5e5ull, (uint64_t)j, q);
+    draw_scalar(b.v, seed ^ 0xba5e5ull, (uint64_t)j, q, qq.bits);
     // B = b * G (MSB-first double and add)
     Proj6 B = C.zero();
     for (int bit = 255; bit >= 0; bit--) {
@@ -189,12 +206,12 @@ inline int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_o
   ctx->ensure(d_tbl, (size_t)N_BASIS * TBL * msm::ROW_WORDS * 4);
   HIPCHK(hipMemcpyAsync(d_wire.p, wire.data(), wire.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
-  hipLaunchKernelGGL(msm::k_points_from_wire, dim3((N_BASIS * TBL + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t*)d_tbl.p,
+  W_LAUNCH(ctx, msm::k_points_from_wire, dim3((N_BASIS * TBL + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t*)d_tbl.p,
                      (const uint32_t*)d_wire.p, (uint64_t)N_BASIS * TBL, 1, (uint32_t*)ctx->errflag.p);
   ctx->n_points = 0;
   ctx->ensure(ctx->rows, std::max<uint64_t>(n, 1) * msm::ROW_WORDS * 4);
   if (n)
-    hipLaunchKernelGGL(k_gen_points, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p,
+    W_LAUNCH(ctx, k_gen_points, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p,
                        (const uint32_t*)d_tbl.p, n, seed);
   HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->errflag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -1,4 +1,5 @@
-// HIP kernels of the batched-affine Pippenger MSM for BLS12-377 G1 on gfx950.
+// HIP kernels of the batched-affine Pippenger MSM for short Weierstrass curves y^2 = x^3 + b with a
+// GLV endomorphism (BLS12-377 G1, BLS12-381 G1) on gfx950.
 //
 // Phase map (reference: src/msm-batched-affine.ts:69-340):
 //   k_points_from_wire   pointsFromBytes + toMontgomery + endomorphism      src/parallel.ts:97-116, src/wasm/curve.ts:90-103
@@ -29,9 +30,14 @@
 
 namespace msm {
 
-using F = Fp377;
-constexpr int NL = F::NL;
-constexpr int NW = F::NW;
+// curve configurations: every curve-dependent kernel is a template over one of these.  Both base
+// fields use 13 x 30-bit limbs in registers and 12 x 32-bit words in memory, so all buffer layouts
+// and the curve-independent sort / scan kernels are shared.
+struct CvBls377 { using F = Fp377; using G = GlvBls377; };   // src/concrete/bls12-377.params.ts
+struct CvBls381 { using F = Fp381; using G = GlvBls381; };   // src/concrete/bls12-381.params.ts
+constexpr int NL = 13;
+constexpr int NW = 12;
+static_assert(Fp377::NL == NL && Fp377::NW == NW && Fp381::NL == NL && Fp381::NW == NW, "shared layouts");
 constexpr int ROW_WORDS = 64;   // 256 B per point
 constexpr int ROW_HALF = 32;    // word offset of the endomorphism image (second 128-byte line)
 constexpr int ROW_Y = 12;       // word offset of y inside a line
@@ -65,6 +71,7 @@ MSM_DEV void store_planes3(uint4* base, uint64_t cap, int first_plane, uint64_t 
     base[(uint64_t)(first_plane + j) * cap + e] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
 
+template <class F>
 MSM_DEV bool words_ge_p(const uint32_t (&w)[NW]) {  // w >= p ?
   bool gt = false, lt = false;
 #pragma unroll
@@ -77,6 +84,7 @@ MSM_DEV bool words_ge_p(const uint32_t (&w)[NW]) {  // w >= p ?
   return !lt;
 }
 
+template <class F>
 MSM_DEV bool fe_equal(const Fe<F>& a, const Fe<F>& b) {
   uint32_t o = 0;
 #pragma unroll
@@ -84,6 +92,7 @@ MSM_DEV bool fe_equal(const Fe<F>& a, const Fe<F>& b) {
   return o == 0;
 }
 
+template <class F>
 MSM_DEV void store_row(uint32_t* row, const Fe<F>& x, const Fe<F>& y, const Fe<F>& bx) {
   fe_store<F>(row, x);
   fe_store<F>(row + ROW_Y, y);
@@ -107,8 +116,10 @@ MSM_DEV void store_row_identity(uint32_t* row) {
 // k_points_from_wire: N x (x || y), 48-byte little-endian canonical integers -> point rows
 // ---------------------------------------------------------------------------------------------
 
+template <class CV>
 __global__ void __launch_bounds__(256) k_points_from_wire(uint32_t* rows, const uint32_t* wire, uint64_t n,
                                                           int check_curve, uint32_t* err) {
+  using F = typename CV::F;
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t xw[NW], yw[NW];
@@ -122,7 +133,7 @@ __global__ void __launch_bounds__(256) k_points_from_wire(uint32_t* rows, const 
     store_row_identity(row);
     return;
   }
-  if (words_ge_p(xw) || words_ge_p(yw)) atomicOr(err, 1u);
+  if (words_ge_p<F>(xw) || words_ge_p<F>(yw)) atomicOr(err, 1u);
   Fe<F> x, y, r2, beta, bx;
   fe_unpack<F>(x, xw);
   fe_unpack<F>(y, yw);
@@ -166,8 +177,10 @@ MSM_DEV bool words8_ge(const uint32_t (&a)[8], const uint32_t* q) {
 }
 
 // windows [k_lo, k_lo + k_cnt) of K_total are emitted (window groups / multi-GPU window shards)
+template <class CV>
 __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts, const uint32_t* scalars, uint32_t n,
                                                 int c, int k_total, int k_lo, int k_cnt) {
+  using F = typename CV::F;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -178,12 +191,12 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts,
   }
   uint32_t q[8];
 #pragma unroll
-  for (int j = 0; j < 8; j++) q[j] = GlvBls377::Q[j];
+  for (int j = 0; j < 8; j++) q[j] = CV::G::Q[j];
   // inputs are specified < q (src/curve-random.ts:151-194); larger values are reduced, not rejected
   for (int it = 0; it < 16 && words8_ge(s, q); it++) bn_addsub<8, 8>(s, q, true);
 
   GlvHalf h[2];
-  glv_decompose(h[0], h[1], s);
+  glv_decompose<typename CV::G>(h[0], h[1], s);
   const uint32_t L = 1u << (c - 1);
   const uint64_t two_n = 2ull * n;
 #pragma unroll
@@ -652,7 +665,7 @@ MSM_DEV void load_y_raw(const BatchArgs& a, const Side& s, Pk& w) {
 }
 
 // gather mode: apply the sign bit of the payload, y -> p - y (0 stays 0)
-template <int MODE>
+template <class F, int MODE>
 MSM_DEV void finish_y(const Side& s, Pk& y) {
   if (MODE != MODE_GATHER) return;
   Pk pp, t;
@@ -704,7 +717,7 @@ MSM_DEV void fetch_pair_x(const BatchArgs& a, uint64_t e, PairFetch<MODE>& pf) {
 
 // classification + denominator from the packed x coordinates (y only for the rare equal-x case).
 // den comes back in limb form, ready for the multiplier.
-template <int MODE>
+template <class F, int MODE>
 MSM_DEV int classify(const BatchArgs& a, const PairFetch<MODE>& pf, bool& inf1, bool& inf2, Fe<F>& den) {
   inf1 = pf.A.absent || pf.ax.w[NW - 1] == INF_WORD;
   inf2 = pf.B.absent || pf.bx.w[NW - 1] == INF_WORD;
@@ -716,9 +729,9 @@ MSM_DEV int classify(const BatchArgs& a, const PairFetch<MODE>& pf, bool& inf1, 
   if (pk_is_zero(dx)) {
     Pk y1, y2;
     load_y_raw<MODE>(a, pf.A, y1);
-    finish_y<MODE>(pf.A, y1);
+    finish_y<F, MODE>(pf.A, y1);
     load_y_raw<MODE>(a, pf.B, y2);
-    finish_y<MODE>(pf.B, y2);
+    finish_y<F, MODE>(pf.B, y2);
     if (pk_equal(y1, y2) && !pk_is_zero(y1)) {
       Fe<F> yl;
       pk_unpack<F>(yl, y1);
@@ -731,8 +744,9 @@ MSM_DEV int classify(const BatchArgs& a, const PairFetch<MODE>& pf, bool& inf1, 
   return KIND_ADD;
 }
 
-template <int MODE>
+template <class CV, int MODE>
 __global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
+  using F = typename CV::F;
   const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.n_out) return;   // whole lane idle (steps * T >= n_out, lane t owns e = t, t + T, ...)
@@ -753,7 +767,7 @@ __global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
       if (i + 1 < my_steps) fetch_pair_x<MODE>(a, (uint64_t)(i + 1) * T + t, nxt);   // in flight during the multiply
       Fe<F> den;
       bool inf1, inf2;
-      classify<MODE>(a, cur, inf1, inf2, den);
+      classify<F, MODE>(a, cur, inf1, inf2, den);
       uint32_t* sp = a.scratch + ((uint64_t)i * NL) * T + t;
 #pragma unroll
       for (int l = 0; l < NL; l++) sp[(uint64_t)l * T] = acc.l[l];
@@ -796,12 +810,12 @@ __global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
       }
       Fe<F> den, d;
       bool inf1, inf2;
-      int kind = classify<MODE>(a, cur, inf1, inf2, den);
+      int kind = classify<F, MODE>(a, cur, inf1, inf2, den);
       fe_mul<F>(d, inv, pre);     // 1 / den_i
       fe_mul<F>(inv, inv, den);   // strip den_i from the running inverse
 
-      finish_y<MODE>(cur.A, y1);
-      finish_y<MODE>(cur.B, y2);
+      finish_y<F, MODE>(cur.A, y1);
+      finish_y<F, MODE>(cur.B, y2);
       if (kind == KIND_ZERO || (kind == KIND_COPY_A && inf1)) {
         store_identity(a.out, a.out_cap, e);
         continue;
@@ -849,10 +863,12 @@ __global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
 // projective points in raw limb form (3 x 13 words) between the reduction kernels
 // ---------------------------------------------------------------------------------------------
 
+template <class F>
 MSM_DEV void proj_store(uint32_t* dst, const Proj<F>& P) {
 #pragma unroll
   for (int l = 0; l < NL; l++) { dst[l] = P.X.l[l]; dst[NL + l] = P.Y.l[l]; dst[2 * NL + l] = P.Z.l[l]; }
 }
+template <class F>
 MSM_DEV void proj_load(Proj<F>& P, const uint32_t* src) {
 #pragma unroll
   for (int l = 0; l < NL; l++) { P.X.l[l] = src[l]; P.Y.l[l] = src[NL + l]; P.Z.l[l] = src[2 * NL + l]; }
@@ -865,8 +881,10 @@ MSM_DEV void proj_load(Proj<F>& P, const uint32_t* src) {
 // additions -- no inversion at all -- and leaves the bucket sum in projective form for k_bucket_reduce.
 // ---------------------------------------------------------------------------------------------
 
+template <class CV>
 __global__ void __launch_bounds__(256) k_bucket_finish(uint32_t* bucket_proj, const uint4* in, uint64_t in_cap,
                                                        const uint32_t* off, uint32_t nb) {
+  using F = typename CV::F;
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   const uint32_t o0 = off[b], o1 = off[b + 1];
@@ -890,9 +908,11 @@ __global__ void __launch_bounds__(256) k_bucket_finish(uint32_t* bucket_proj, co
 // columns[id]; the weight (lstart - 1) = ch * TC is applied later through per-bit sums (k_bit_tree) instead of a
 // double-and-add chain in every lane.
 // bucket_proj != nullptr: bucket sums come from k_bucket_finish (projective, one per bucket) instead of the tree buffer
+template <class CV>
 __global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, uint32_t* rows, const uint4* fin, uint64_t fin_cap,
                                                        const uint32_t* off_fin, const uint32_t* bucket_proj, uint32_t L,
                                                        uint32_t TC, uint32_t nchunks, uint32_t k_cnt) {
+  using F = typename CV::F;
   uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= nchunks * k_cnt) return;
   uint32_t kk = id / nchunks, ch = id - kk * nchunks;
@@ -948,7 +968,9 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, uint32_
 
 constexpr int WS_THREADS = 256;
 
+template <class CV>
 __global__ void __launch_bounds__(WS_THREADS) k_window_sum(uint32_t* partials, const uint32_t* columns, uint32_t nchunks) {
+  using F = typename CV::F;
   __shared__ uint32_t lds[3 * NL * WS_THREADS];
   const uint32_t kk = blockIdx.x, tid = threadIdx.x;
   Proj<F> acc;
@@ -1003,8 +1025,10 @@ __global__ void __launch_bounds__(WS_THREADS) k_window_sum(uint32_t* partials, c
 // first stage of the window sum when a window has many chunk columns: block (b, kk) tree-sums columns
 // [b * per_block, (b + 1) * per_block) of window kk into one raw projective point, so that no lane adds more
 // than a couple of columns serially (the sum of 8192 columns drops from 40 dependent additions to ~18)
+template <class CV>
 __global__ void __launch_bounds__(WS_THREADS) k_column_tree(uint32_t* out, const uint32_t* columns, uint32_t nchunks,
                                                             uint32_t per_block) {
+  using F = typename CV::F;
   __shared__ uint32_t lds[3 * NL * WS_THREADS];
   const uint32_t b = blockIdx.x, kk = blockIdx.y, tid = threadIdx.x, nblk = gridDim.x;
   const uint32_t beg = b * per_block, end = min(beg + per_block, nchunks);
@@ -1050,9 +1074,11 @@ __global__ void __launch_bounds__(WS_THREADS) k_column_tree(uint32_t* out, const
 // The K * (nbits + 1) results go to the host, which applies the 2^b weights with nbits doublings per window --
 // one chain per window instead of one per lane (the reference applies the same weight by double-and-add per
 // chunk, src/msm-batched-affine.ts:574-580).
+template <class CV>
 __global__ void __launch_bounds__(WS_THREADS) k_bit_tree(uint32_t* out, const uint32_t* rows, const uint32_t* tris,
                                                          uint32_t n_in, uint32_t per_block, uint32_t nbits, int masked,
                                                          int pack_out) {
+  using F = typename CV::F;
   __shared__ uint32_t lds[3 * NL * WS_THREADS];
   const uint32_t blk = blockIdx.x, y = blockIdx.y, kk = blockIdx.z, tid = threadIdx.x, nblk = gridDim.x;
   const uint32_t beg = blk * per_block, end = min(beg + per_block, n_in);
@@ -1122,7 +1148,9 @@ __global__ void __launch_bounds__(WS_THREADS) k_bit_tree(uint32_t* out, const ui
 enum : int { OP_MUL = 0, OP_SQR = 1, OP_ADD = 2, OP_SUB = 3, OP_INV = 4, OP_TO_MONT = 5, OP_FROM_MONT = 6 };
 
 // a, b, out: n x 12 packed words; values are canonical Montgomery form unless the op says otherwise
+template <class CV>
 __global__ void __launch_bounds__(256) k_test_fp(uint32_t* out, const uint32_t* a, const uint32_t* b, uint32_t n, int op) {
+  using F = typename CV::F;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fe<F> x, y, r;
@@ -1156,7 +1184,9 @@ __global__ void __launch_bounds__(256) k_test_fp(uint32_t* out, const uint32_t* 
 // `batchInverse` (src/wasm/inverse.ts:220-271, JS twin src/curve-affine.ts:692-727): Montgomery's trick over a
 // contiguous array; lane t inverts elements [t * per_lane, (t + 1) * per_lane) with ONE fe_inv.
 // Operands and results are canonical Montgomery-form words; zeros are not allowed (as in the reference).
+template <class CV>
 __global__ void __launch_bounds__(256) k_test_batch_inverse(uint32_t* out, const uint32_t* xs, uint32_t n, uint32_t per_lane) {
+  using F = typename CV::F;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t beg = (uint64_t)t * per_lane, end = min(beg + per_lane, (uint64_t)n);
   if (beg >= end) return;
@@ -1181,14 +1211,16 @@ __global__ void __launch_bounds__(256) k_test_batch_inverse(uint32_t* out, const
 }
 
 // out: n x 10 words: |s0| (4), |s1| (4), neg0, neg1
+template <class CV>
 __global__ void __launch_bounds__(256) k_test_glv(uint32_t* out, const uint32_t* scalars, uint32_t n) {
+  using F = typename CV::F;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) s[j] = scalars[(uint64_t)i * 8 + j];
   GlvHalf h0, h1;
-  glv_decompose(h0, h1, s);
+  glv_decompose<typename CV::G>(h0, h1, s);
   uint32_t* o = out + (uint64_t)i * 10;
 #pragma unroll
   for (int j = 0; j < 4; j++) { o[j] = h0.mag[j]; o[4 + j] = h1.mag[j]; }

@@ -66,6 +66,19 @@ BLS12_377 = WeierstrassParams(
     n_bytes=48,
 )
 
+BLS12_381 = WeierstrassParams(  # src/concrete/bls12-381.params.ts:6-55 (lambda2 = z^2 - 1, beta2)
+    label="bls12-381",
+    p=0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB,
+    q=0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+    h=0x396C8C005555E1568C00AAAB0000AAAB,
+    b=4,
+    gx=0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+    gy=0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1,
+    lam=0xD201000000010000 ** 2 - 1,
+    beta=0x1A0111EA397FE699EC02408663D4DE85AA0D857D89759AD4897D29650FB85F9B409427EB4F49FFFD8BFD00000000AAAC,
+    n_bytes=48,
+)
+
 ED_ON_BLS12_377 = TwistedEdwardsParams(
     label="ed-on-bls12-377",
     p=0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001,

@@ -42,11 +42,13 @@ void host_fp_op(int field, int which, const uint32_t* a, const uint32_t* b, uint
   else if (field == 1) op<Fp253>(which, a, b, out);
   else op<Fp381>(which, a, b, out);
 }
-void host_glv(const uint32_t* s8, uint32_t* out10) {
+// curve 0 = BLS12-377 lattice, 2 = BLS12-381 lattice
+void host_glv(int curve, const uint32_t* s8, uint32_t* out10) {
   uint32_t s[8];
   for (int i = 0; i < 8; i++) s[i] = s8[i];
   GlvHalf h0, h1;
-  glv_decompose(h0, h1, s);
+  if (curve == 2) glv_decompose<GlvBls381>(h0, h1, s);
+  else glv_decompose<GlvBls377>(h0, h1, s);
   for (int i = 0; i < 4; i++) { out10[i] = h0.mag[i]; out10[4 + i] = h1.mag[i]; }
   out10[8] = h0.neg; out10[9] = h1.neg;
 }

@@ -23,7 +23,7 @@ def lib():
     subprocess.check_call(["make", "-C", ROOT, "-s", "hosttest"])
     lib = C.CDLL(LIB)
     lib.host_fp_op.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.host_glv.argtypes = [C.c_void_p, C.c_void_p]
+    lib.host_glv.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
     return lib
 
 
@@ -67,13 +67,14 @@ def test_inverse_divsteps_and_fermat(lib, field):
     assert fp_op(lib, field, 4, 0) == 0
 
 
-def test_glv_decompose_host_build(lib):
-    Cc = O.BLS12_377
+@pytest.mark.parametrize("curve", [0, 2])
+def test_glv_decompose_host_build(lib, curve):
+    Cc = O.BLS12_381 if curve == 2 else O.BLS12_377
     g = O.glv_params(Cc.q, Cc.lam)
     for s in O.prng_ints("host/glv", 3000, Cc.q) + [0, 1, Cc.q - 1, Cc.lam, Cc.lam + 1]:
         S = (C.c_uint32 * 8)(*[(s >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
         out = (C.c_uint32 * 10)()
-        lib.host_glv(S, out)
+        lib.host_glv(curve, S, out)
         a0 = sum(int(out[i]) << (32 * i) for i in range(4))
         a1 = sum(int(out[4 + i]) << (32 * i) for i in range(4))
         assert (a0, a1, bool(out[8]), bool(out[9])) == O.glv_decompose(s, g)

@@ -209,3 +209,52 @@ def test_config1_msm_basic_2p14_cpu_plumbing(c_oracle):
     assert got == O.aff_scale(sum(s * ks[i & 255] for i, s in enumerate(sc)) % C.q, G, C.p)
     ref, _ = c_oracle.msm_bls377(O.points_to_bytes(pts, 48), O.scalars_to_bytes(sc), 0)
     assert ref == got
+
+
+# ---- BLS12-381 G1 (src/concrete/bls12-381.params.ts; covered by the reference in src/msm.test.ts:31) ----
+
+
+def test_bls12_381_params_glv_and_msm_identities():
+    B = O.BLS12_381
+    G = (B.gx, B.gy)
+    assert O.aff_is_on_curve(G, B) and O.aff_scale(B.q, G, B.p) is None
+    # (beta x, y) = lambda (x, y): src/concrete/bls12-381.params.ts:11-31 (the lambda2 / beta2 pair)
+    assert pow(B.lam, 3, B.q) == 1 and pow(B.beta, 3, B.p) == 1
+    assert O.aff_scale(B.lam, G, B.p) == (B.beta * B.gx % B.p, B.gy)
+    g = O.glv_params(B.q, B.lam)
+    assert (g.n, g.n0, g.m, g.k, g.max_bits) == (9, 5, 145, 116, 127)
+    assert g.v00 * g.v11 - g.v10 * g.v01 == B.q
+    for s in O.prng_ints("kat/glv381", 2000, B.q) + [0, 1, B.q - 1]:
+        a0, a1, n0, n1 = O.glv_decompose(s, g)
+        s0, s1 = (-a0 if n0 else a0), (-a1 if n1 else a1)
+        assert (s0 + s1 * B.lam - s) % B.q == 0 and max(a0, a1) < (1 << g.max_bits)
+    pts, ks = O.random_points_bls377("kat/381", 40, B)
+    sc = O.prng_ints("kat/381/s", 40, B.q)
+    spec = O.msm_naive_affine(sc, pts, B)
+    assert spec == O.aff_scale(sum(a * b for a, b in zip(sc, ks)) % B.q, G, B.p)
+    for c, safe, chunks in ((None, True, 1), (4, False, 3), (7, True, 2)):
+        assert O.msm_batched_affine(sc, pts, B, c=c, safe=safe, n_chunks=chunks) == spec
+    assert O.msm_basic_projective(sc, pts, B, c=6) == spec
+
+
+def test_golden_bls12_381():
+    B = O.BLS12_381
+    d = load("bls381.json")
+    p = H(d["modulus"])
+    assert p == B.p and H(d["q"]) == B.q and d["max_bits"] == 127
+    for c in d["fp"]:
+        a, b = H(c["a"]), H(c["b"])
+        assert a * b % p == H(c["mul"]) and (a + b) % p == H(c["add"]) and (a - b) % p == H(c["sub"]) and a * a % p == H(c["sqr"])
+        if c["inv"]:
+            assert H(c["inv"]) * a % p == 1
+    g = O.glv_params(B.q, B.lam)
+    assert [hex(g.v00), hex(g.v01), str(g.v10), hex(g.v11)] == d["v"] and str(g.m0) == d["m0"] and str(g.m1) == d["m1"]
+    for c in d["glv"]:
+        assert O.glv_decompose(H(c["s"]), g) == (H(c["s0"]), H(c["s1"]), c["neg0"], c["neg1"])
+    for c in d["msm"]:
+        if c["n"] > 128:
+            continue
+        sc = O.scalars_from_bytes(bytes.fromhex(c["scalars"]))
+        pts = [None if P == (0, 0) else P for P in O.points_from_bytes(bytes.fromhex(c["points"]), 48)]
+        exp = None if c["result"] is None else (H(c["result"][0]), H(c["result"][1]))
+        assert O.msm_batched_affine(sc, pts, B, c=c["c"]) == exp, c["name"]
