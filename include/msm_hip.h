@@ -38,7 +38,10 @@ enum {
 enum {
   MSM_CURVE_BLS12_377_G1 = 0,     /* Weierstrass + GLV, batched-affine path: src/msm-batched-affine.ts */
   MSM_CURVE_ED_ON_BLS12_377 = 1,  /* twisted Edwards, generic path: src/msm-basic.ts */
-  MSM_CURVE_BLS12_381_G1 = 2      /* Weierstrass + GLV, batched-affine path; src/concrete/bls12-381.params.ts */
+  MSM_CURVE_BLS12_381_G1 = 2,     /* Weierstrass + GLV, batched-affine path; src/concrete/bls12-381.params.ts */
+  MSM_CURVE_PALLAS = 3            /* same path, src/concrete/pasta.params.ts.  Runs in the 381-bit-wide code path:
+                                   * every coordinate at this ABI is a 48-byte little-endian integer (upper 16
+                                   * bytes zero); the facades translate the reference's 32-byte Pallas wire form */
 };
 
 typedef struct msm_ctx msm_ctx;

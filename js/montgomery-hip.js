@@ -20,6 +20,11 @@ const bls12381Params = {
   modulus: BigInt("0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab"),
   order: BigInt("0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001"),
 };
+const pallasParams = {
+  label: "pallas",
+  modulus: BigInt("0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001"),
+  order: BigInt("0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001"),
+};
 const edOnBls12377Params = {
   label: "ed-on-bls12-377",
   modulus: BigInt("0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001"),
@@ -37,14 +42,20 @@ function bigintToLeBytes(x, n) {
   return out;
 }
 
-function createCurve(params, curveId, coordBytes, device) {
+function createCurve(params, curveId, coordBytes, device, wireBytes) {
+  wireBytes = wireBytes || coordBytes;   // the reference's packed coordinate size; Pallas: 32 on the wire, 48 at the C ABI
   const ctx = hip.createContext(curveId, device || 0);
   const pointBytes = 2 * coordBytes;
   const Parallel = {
     getPointer(size) { return { size, n: 0 }; },
     getScalarPointer(size) { return { size, bytes: null, n: 0 }; },
     async pointsFromBytes(pointPtr, input, n) {
-      const b = Buffer.from(input.buffer, input.byteOffset, n * pointBytes);
+      let b = Buffer.from(input.buffer, input.byteOffset, n * 2 * wireBytes);
+      if (wireBytes !== coordBytes) {
+        const padded = Buffer.alloc(n * pointBytes);
+        for (let i = 0; i < 2 * n; i++) b.copy(padded, i * coordBytes, i * wireBytes, (i + 1) * wireBytes);
+        b = padded;
+      }
       pointPtr.n = hip.setPoints(ctx, b, pointBytes, 0);
     },
     async scalarsFromBytes(scalarPtr, input, n) {
@@ -58,6 +69,9 @@ function createCurve(params, curveId, coordBytes, device) {
       const log = verboseTiming ? [[{ n: Math.ceil(Math.log2(Math.max(N, 1))), K: r.K, c: r.c }], [`msm total... ${r.phaseMs[0].toFixed(3)}ms`]] : [];
       return { result, log };
     },
+    msmProjective(scalarPtr, pointPtr, N, options) {
+      return Parallel.msm(scalarPtr, pointPtr, N, false, options);   // src/parallel.ts:69-87: same group element
+    },
     msmUnsafe(scalarPtr, pointPtr, N, verboseTiming, options) {
       return Parallel.msm(scalarPtr, pointPtr, N, verboseTiming, options);   // the GPU kernels always handle the edge cases
     },
@@ -65,11 +79,11 @@ function createCurve(params, curveId, coordBytes, device) {
   return { params, Parallel, close() { hip.destroyContext(ctx); } };
 }
 
-const weierstrassIds = { "bls12-377": hip.CURVE_BLS12_377_G1, "bls12-381": hip.CURVE_BLS12_381_G1 };
+const weierstrassIds = { "bls12-377": hip.CURVE_BLS12_377_G1, "bls12-381": hip.CURVE_BLS12_381_G1, "pallas": hip.CURVE_PALLAS };
 const Weierstrass = {
   create(params, device) {
     if (!(params.label in weierstrassIds)) throw new Error(`curve ${params.label} has no device constants`);
-    return createCurve(params, weierstrassIds[params.label], 48, device);
+    return createCurve(params, weierstrassIds[params.label], 48, device, params.label === "pallas" ? 32 : 48);
   },
 };
 const TwistedEdwards = { create(params, device) { return createCurve(params, hip.CURVE_ED_ON_BLS12_377, 32, device); } };
@@ -92,4 +106,4 @@ async function compute_msm(curve, coordBytes, inputPoints, inputScalars) {
   return { x: result.x, y: result.y, isZero: result.isZero };
 }
 
-module.exports = { hip, Weierstrass, TwistedEdwards, bls12377Params, bls12381Params, edOnBls12377Params, compute_msm, leBytesToBigint, bigintToLeBytes };
+module.exports = { hip, Weierstrass, TwistedEdwards, bls12377Params, bls12381Params, pallasParams, edOnBls12377Params, compute_msm, leBytesToBigint, bigintToLeBytes };

@@ -16,6 +16,7 @@ MSM_OK, MSM_ERR_ARG, MSM_ERR_HIP, MSM_ERR_POINT, MSM_ERR_NO_POINTS, MSM_ERR_NO_D
 CURVE_BLS12_377_G1 = 0
 CURVE_ED_ON_BLS12_377 = 1
 CURVE_BLS12_381_G1 = 2
+CURVE_PALLAS = 3
 N_PHASES = 8
 PHASE_NAMES = ("total", "upload", "digits", "sort", "accumulate", "reduce", "final", "accumulate_round1")
 

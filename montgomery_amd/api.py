@@ -76,8 +76,22 @@ BLS12_381_PARAMS = WeierstrassParams(  # src/concrete/bls12-381.params.ts:6-55
     ),
 )
 
+_PALLAS_P = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+_PALLAS_Q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+PALLAS_PARAMS = WeierstrassParams(  # src/concrete/pasta.params.ts:10-53
+    label="pallas",
+    modulus=_PALLAS_P,
+    order=_PALLAS_Q,
+    cofactor=1,
+    a=0,
+    b=5,
+    generator=(1, 0x1B74B5A30A12937C53DFA9F06378EE548F655BD4333D477119CF7A23CAED2ABB),
+    endomorphism=(pow(5, (_PALLAS_Q - 1) // 3, _PALLAS_Q), pow(pow(5, (_PALLAS_P - 1) // 3, _PALLAS_P), 2, _PALLAS_P)),
+)
+
 # curves with device constants (montgomery_amd/csrc/constants_gen.h), by label
-_WEIERSTRASS_CURVE_IDS = {"bls12-377": _lib.CURVE_BLS12_377_G1, "bls12-381": _lib.CURVE_BLS12_381_G1}
+_WEIERSTRASS_CURVE_IDS = {"bls12-377": _lib.CURVE_BLS12_377_G1, "bls12-381": _lib.CURVE_BLS12_381_G1,
+                          "pallas": _lib.CURVE_PALLAS}
 
 
 @dataclass(frozen=True)
@@ -322,6 +336,9 @@ class _Parallel:
     def __init__(self, ctx: MsmContext, params):
         self._ctx = ctx
         self._params = params
+        # wire bytes per coordinate = the reference's packed field size (src/wasm/field-helpers.ts:211-301);
+        # Pallas (32) differs from the 48-byte coordinates its context takes at the C ABI
+        self._wire_bytes = (params.modulus.bit_length() + 7) // 8 if hasattr(params, "modulus") else ctx.coord_bytes
 
     def getPointer(self, size: int) -> PointPtr:
         return PointPtr(size=size)
@@ -331,7 +348,15 @@ class _Parallel:
 
     def pointsFromBytes(self, pointPtr: PointPtr, pointInput: BytesLike, n: int) -> None:
         """src/parallel.ts:97-116 (96 B/point) / :215-229 (64 B/point): x || y little-endian -> resident device points."""
-        self._ctx.set_points(bytes(pointInput)[: 2 * self._ctx.coord_bytes * n])
+        wb, cb = self._wire_bytes, self._ctx.coord_bytes
+        buf = bytes(pointInput)[: 2 * wb * n]
+        if wb != cb:   # zero-pad every coordinate to the ABI width
+            import numpy as np
+
+            padded = np.zeros((2 * n, cb), dtype=np.uint8)
+            padded[:, :wb] = np.frombuffer(buf, dtype=np.uint8).reshape(2 * n, wb)
+            buf = padded.tobytes()
+        self._ctx.set_points(buf)
         pointPtr.n = n
 
     def scalarsFromBytes(self, scalarPtr: ScalarPtr, scalarInput: BytesLike, n: int) -> None:
@@ -368,6 +393,11 @@ class _Parallel:
             for name, ms in info["phase_ms"].items():
                 log.append([f"{name}... {ms:.3f}ms"])
         return {"result": res, "log": log, "info": info}
+
+    def msmProjective(self, scalarPtr: ScalarPtr, pointPtr: PointPtr, N: int, options: Optional[Dict] = None) -> Dict:
+        """`msmProjective` (src/parallel.ts:69-87: msmBasic over projective points, no GLV).  The value is the same
+        group element whichever algorithm sums it, so the one GPU path serves this entry too."""
+        return self.msm(scalarPtr, pointPtr, N, False, options)
 
     def msmUnsafe(self, scalarPtr: ScalarPtr, pointPtr: PointPtr, N: int, verboseTiming: bool = False,
                   options: Optional[Dict] = None) -> Dict:

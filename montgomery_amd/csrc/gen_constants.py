@@ -22,6 +22,13 @@ LAMBDA381 = 0xD201000000010000 ** 2 - 1
 BETA381 = 0x1A0111EA397FE699EC02408663D4DE85AA0D857D89759AD4897D29650FB85F9B409427EB4F49FFFD8BFD00000000AAAC
 G381X = 0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB
 G381Y = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1
+# Pallas (src/concrete/pasta.params.ts:10-53): y^2 = x^3 + 5, lambda = 5^((q-1)/3), beta = (5^((p-1)/3))^2
+FP_PALLAS = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+FQ_PALLAS = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+LAMBDA_PALLAS = pow(5, (FQ_PALLAS - 1) // 3, FQ_PALLAS)
+BETA_PALLAS = pow(pow(5, (FP_PALLAS - 1) // 3, FP_PALLAS), 2, FP_PALLAS)
+GX_PALLAS = 1
+GY_PALLAS = 0x1B74B5A30A12937C53DFA9F06378EE548F655BD4333D477119CF7A23CAED2ABB
 ED_D = 3021
 EDGX = 0x9F1B5A5BAF6ACF06FED91C9AE9EBFA06068DD2835790980894E2328F3EBCA05
 EDGY = 0x9A20DF36571AC3CD906B256080BA8454453C177AAF3131BB50A67BF1A806781
@@ -111,7 +118,11 @@ def main():
     out += field_block("Fp253", FR377, 9, 8, {"K2DW": 2 * ED_D, "DW": ED_D, "GXW": EDGX, "GYW": EDGY})
     # BLS12-381 G1 (src/concrete/bls12-381.params.ts:6-55): y^2 = x^3 + 4, lambda = z^2 - 1, z = 0xd201000000010000
     out += field_block("Fp381", FP381, 13, 12, {"BETAW": BETA381, "BW": 4, "GXW": G381X, "GYW": G381Y})
+    # Pallas runs through the same 13-limb / 12-word code path with zero upper limbs (R = 2^390 is a valid
+    # Montgomery radix for any odd p < R): a curve "by constants only", at the 381-bit path's cost
+    out += field_block("FpPallas", FP_PALLAS, 13, 12, {"BETAW": BETA_PALLAS, "BW": 5, "GXW": GX_PALLAS, "GYW": GY_PALLAS})
     out += glv_block()
+    out += glv_block("GlvPallas", LAMBDA_PALLAS, FQ_PALLAS, 127)
     out += glv_block("GlvBls381", LAMBDA381, FR381, 127)
     out += arr("FR377_Q", limbs(FR377, 8, 32)).replace("  static", "static")
     out += arr("FRED_Q", limbs(FR_ED, 8, 32)).replace("  static", "static")

@@ -58,8 +58,9 @@ struct CurveInfo {
 inline const CurveInfo& curve_info(int curve) {
   static const CurveInfo bls377 = {msm::Fp377::PW, msm::GlvBls377::Q, msm::Fp377::GXW, msm::Fp377::GYW, msm::GlvBls377::MAX_BITS, 253};
   static const CurveInfo bls381 = {msm::Fp381::PW, msm::GlvBls381::Q, msm::Fp381::GXW, msm::Fp381::GYW, msm::GlvBls381::MAX_BITS, 255};
+  static const CurveInfo pallas = {msm::FpPallas::PW, msm::GlvPallas::Q, msm::FpPallas::GXW, msm::FpPallas::GYW, msm::GlvPallas::MAX_BITS, 255};
   static const CurveInfo ed377 = {msm::Fp253::PW, msm::FRED_Q, nullptr, nullptr, 251, 251};
-  return curve == MSM_CURVE_BLS12_381_G1 ? bls381 : curve == MSM_CURVE_ED_ON_BLS12_377 ? ed377 : bls377;
+  return curve == MSM_CURVE_BLS12_381_G1 ? bls381 : curve == MSM_CURVE_PALLAS ? pallas : curve == MSM_CURVE_ED_ON_BLS12_377 ? ed377 : bls377;
 }
 
 struct msm_ctx {
@@ -120,11 +121,13 @@ struct msm_ctx {
 #define W_LAUNCH(ctx, KERNEL, ...)                                                         \
   do {                                                                                     \
     if ((ctx)->curve == MSM_CURVE_BLS12_381_G1) hipLaunchKernelGGL((KERNEL<msm::CvBls381>), __VA_ARGS__); \
+    else if ((ctx)->curve == MSM_CURVE_PALLAS) hipLaunchKernelGGL((KERNEL<msm::CvPallas>), __VA_ARGS__);  \
     else hipLaunchKernelGGL((KERNEL<msm::CvBls377>), __VA_ARGS__);                          \
   } while (0)
 #define W_LAUNCH_MODE(ctx, KERNEL, MODE, ...)                                              \
   do {                                                                                     \
     if ((ctx)->curve == MSM_CURVE_BLS12_381_G1) hipLaunchKernelGGL((KERNEL<msm::CvBls381, MODE>), __VA_ARGS__); \
+    else if ((ctx)->curve == MSM_CURVE_PALLAS) hipLaunchKernelGGL((KERNEL<msm::CvPallas, MODE>), __VA_ARGS__);  \
     else hipLaunchKernelGGL((KERNEL<msm::CvBls377, MODE>), __VA_ARGS__);                    \
   } while (0)
 
@@ -789,7 +792,9 @@ extern "C" {
 int msm_ctx_create(msm_ctx** out, int curve, int device) {
   if (!out) return MSM_ERR_ARG;
   *out = nullptr;
-  if (curve != MSM_CURVE_BLS12_377_G1 && curve != MSM_CURVE_ED_ON_BLS12_377 && curve != MSM_CURVE_BLS12_381_G1) return MSM_ERR_ARG;
+  if (curve != MSM_CURVE_BLS12_377_G1 && curve != MSM_CURVE_ED_ON_BLS12_377 && curve != MSM_CURVE_BLS12_381_G1 &&
+      curve != MSM_CURVE_PALLAS)
+    return MSM_ERR_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MSM_ERR_NO_DEVICE;
   msm_ctx* ctx = new msm_ctx();
@@ -821,7 +826,7 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     delete ctx;
     return MSM_ERR_HIP;
   }
-  ctx->hc.F.init(curve == MSM_CURVE_BLS12_381_G1 ? Fp381::PW : Fp377::PW);
+  ctx->hc.F.init(curve == MSM_CURVE_ED_ON_BLS12_377 ? Fp377::PW : curve_info(curve).pw);   // (the Edwards context uses hte)
   ctx->k_dev_to_host = ctx->hc.F.pow2(378);
   {
     uint32_t pw[12] = {0};

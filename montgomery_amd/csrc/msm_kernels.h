@@ -35,6 +35,7 @@ namespace msm {
 // and the curve-independent sort / scan kernels are shared.
 struct CvBls377 { using F = Fp377; using G = GlvBls377; };   // src/concrete/bls12-377.params.ts
 struct CvBls381 { using F = Fp381; using G = GlvBls381; };   // src/concrete/bls12-381.params.ts
+struct CvPallas { using F = FpPallas; using G = GlvPallas; }; // src/concrete/pasta.params.ts (255-bit p, zero upper limbs)
 constexpr int NL = 13;
 constexpr int NW = 12;
 static_assert(Fp377::NL == NL && Fp377::NW == NW && Fp381::NL == NL && Fp381::NW == NW, "shared layouts");

@@ -165,5 +165,7 @@ NAPI_MODULE_INIT() {
   napi_set_named_property(env, exports, "CURVE_ED_ON_BLS12_377", v);
   napi_create_int32(env, MSM_CURVE_BLS12_381_G1, &v);
   napi_set_named_property(env, exports, "CURVE_BLS12_381_G1", v);
+  napi_create_int32(env, MSM_CURVE_PALLAS, &v);
+  napi_set_named_property(env, exports, "CURVE_PALLAS", v);
   return exports;
 }

@@ -79,6 +79,21 @@ BLS12_381 = WeierstrassParams(  # src/concrete/bls12-381.params.ts:6-55 (lambda2
     n_bytes=48,
 )
 
+_PALLAS_P = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+_PALLAS_Q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+PALLAS = WeierstrassParams(  # src/concrete/pasta.params.ts:10-53
+    label="pallas",
+    p=_PALLAS_P,
+    q=_PALLAS_Q,
+    h=1,
+    b=5,
+    gx=1,
+    gy=0x1B74B5A30A12937C53DFA9F06378EE548F655BD4333D477119CF7A23CAED2ABB,
+    lam=pow(5, (_PALLAS_Q - 1) // 3, _PALLAS_Q),                     # :24
+    beta=pow(pow(5, (_PALLAS_P - 1) // 3, _PALLAS_P), 2, _PALLAS_P),  # :33-34
+    n_bytes=32,
+)
+
 ED_ON_BLS12_377 = TwistedEdwardsParams(
     label="ed-on-bls12-377",
     p=0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001,

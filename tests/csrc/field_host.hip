@@ -36,18 +36,20 @@ static void op(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
 }
 
 extern "C" {
-// field 0 = Fp377 (12 words), 1 = Fp253 (8 words), 2 = Fp381 (12 words); operands are canonical Montgomery-form words
+// field 0 = Fp377 (12 words), 1 = Fp253 (8 words), 2 = Fp381 (12 words), 3 = FpPallas (12 words, upper 4 zero); operands are canonical Montgomery-form words
 void host_fp_op(int field, int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
   if (field == 0) op<Fp377>(which, a, b, out);
   else if (field == 1) op<Fp253>(which, a, b, out);
-  else op<Fp381>(which, a, b, out);
+  else if (field == 2) op<Fp381>(which, a, b, out);
+  else op<FpPallas>(which, a, b, out);
 }
-// curve 0 = BLS12-377 lattice, 2 = BLS12-381 lattice
+// curve 0 = BLS12-377 lattice, 2 = BLS12-381 lattice, 3 = Pallas lattice
 void host_glv(int curve, const uint32_t* s8, uint32_t* out10) {
   uint32_t s[8];
   for (int i = 0; i < 8; i++) s[i] = s8[i];
   GlvHalf h0, h1;
   if (curve == 2) glv_decompose<GlvBls381>(h0, h1, s);
+  else if (curve == 3) glv_decompose<GlvPallas>(h0, h1, s);
   else glv_decompose<GlvBls377>(h0, h1, s);
   for (int i = 0; i < 4; i++) { out10[i] = h0.mag[i]; out10[4 + i] = h1.mag[i]; }
   out10[8] = h0.neg; out10[9] = h1.neg;

@@ -145,23 +145,30 @@ def ed_vectors():
 
 
 def bls381_vectors():
-    """BLS12-381 G1 (src/concrete/bls12-381.params.ts; the reference covers it in src/msm.test.ts:31):
-    field, GLV and MSM vectors in one file."""
-    B = O.BLS12_381
+    return curve_vectors(O.BLS12_381, "381")
+
+
+def pallas_vectors():
+    return curve_vectors(O.PALLAS, "pallas")
+
+
+def curve_vectors(B, tag):
+    """BLS12-381 G1 / Pallas (src/concrete/bls12-381.params.ts, pasta.params.ts; the reference covers both in
+    src/msm.test.ts:29-31): field, GLV and MSM vectors in one file."""
     p, q = B.p, B.q
     g = O.glv_params(q, B.lam)
-    vals = [0, 1, 2, p - 1, p - 2, (p + 1) // 2, 1 << 380, (1 << 30) - 1] + O.prng_ints("golden/fp381", 24, p)
+    vals = [0, 1, 2, p - 1, p - 2, (p + 1) // 2, 1 << (p.bit_length() - 1), (1 << 30) - 1] + O.prng_ints(f"golden/fp{tag}", 24, p)
     fp = []
     for i, a in enumerate(vals):
         b = vals[(i * 7 + 3) % len(vals)]
         fp.append({"a": hx(a), "b": hx(b), "mul": hx(a * b % p), "add": hx((a + b) % p), "sub": hx((a - b) % p),
                    "sqr": hx(a * a % p), "inv": hx(pow(a, -1, p)) if a else None})
-    scalars = [0, 1, 2, q - 1, q - 2, B.lam, B.lam - 1, B.lam + 1, q // 2, 1 << 254, (1 << 127) - 1, 1 << 127] + O.prng_ints("golden/glv381", 52, q)
+    scalars = [0, 1, 2, q - 1, q - 2, B.lam, B.lam - 1, B.lam + 1, q // 2, 1 << 254, (1 << 127) - 1, 1 << 127] + O.prng_ints(f"golden/glv{tag}", 52, q)
     glv = []
     for s in scalars:
         a0, a1, n0, n1 = O.glv_decompose(s, g)
         glv.append({"s": hx(s), "s0": hx(a0), "s1": hx(a1), "neg0": n0, "neg1": n1})
-    pts, ks = O.random_points_bls377("golden/msm381", 1024, B)
+    pts, ks = O.random_points_bls377(f"golden/msm{tag}", 1024, B)
     G = (B.gx, B.gy)
     cases = []
 
@@ -174,10 +181,10 @@ def bls381_vectors():
 
     assert add("2G_minus_G", [2, q - 1], [G, G]) == G
     add("single_generator", [1], [G])
-    add("n3_c4", O.prng_ints("golden/381/s3", 3, q), pts[:3], 4)
-    add("n64_c7", O.prng_ints("golden/381/s64", 64, q), pts[:64], 7)
-    add("n100_c5_ragged", O.prng_ints("golden/381/s100", 100, q), pts[:100], 5)
-    sc = O.prng_ints("golden/381/edge", 40, q)
+    add("n3_c4", O.prng_ints(f"golden/{tag}/s3", 3, q), pts[:3], 4)
+    add("n64_c7", O.prng_ints(f"golden/{tag}/s64", 64, q), pts[:64], 7)
+    add("n100_c5_ragged", O.prng_ints(f"golden/{tag}/s100", 100, q), pts[:100], 5)
+    sc = O.prng_ints(f"golden/{tag}/edge", 40, q)
     sc[0] = 0; sc[1] = q - 1; sc[2] = 1; sc[3] = 0
     epts = list(pts[:40])
     epts[5] = epts[4]; sc[5] = sc[4]
@@ -186,7 +193,7 @@ def bls381_vectors():
     add("edge_mix_c6", sc, epts, 6)
     add("all_zero_scalars", [0] * 9, pts[:9], 4)
     add("cancel_to_identity", [5, q - 5], [pts[0], pts[0]], 4)
-    s1k = O.prng_ints("golden/381/s1k", 1024, q)
+    s1k = O.prng_ints(f"golden/{tag}/s1k", 1024, q)
     r = add("n1024_c9", s1k, pts, 9)
     assert r == O.aff_scale(sum(a * b for a, b in zip(s1k, ks)) % q, G, p)
     return {
@@ -206,6 +213,7 @@ def main():
         "msm377_4096.json": msm_large_vector,
         "msm_ed377.json": ed_vectors,
         "bls381.json": bls381_vectors,
+        "pallas.json": pallas_vectors,
     }
     for name, fn in files.items():
         if only and name not in only:

@@ -15,6 +15,7 @@ FIELDS = {
     0: (O.BLS12_377.p, 12, 13),   # modulus, packed words, 30-bit limbs
     1: (O.ED_ON_BLS12_377.p, 8, 9),
     2: (0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 12, 13),  # BLS12-381: p != 1 mod 2^30
+    3: (O.PALLAS.p, 12, 13),  # Pallas in the 13-limb path (zero upper limbs)
 }
 
 
@@ -36,7 +37,7 @@ def fp_op(lib, field, which, a, b=0):
     return sum(int(w) << (32 * i) for i, w in enumerate(out))
 
 
-@pytest.mark.parametrize("field", [0, 1, 2])
+@pytest.mark.parametrize("field", [0, 1, 2, 3])
 def test_mul_sqr_add_sub(lib, field):
     p, _, nl = FIELDS[field]
     R = 1 << (30 * nl)
@@ -50,7 +51,7 @@ def test_mul_sqr_add_sub(lib, field):
         assert fp_op(lib, field, 3, a, b) == (a - b) % p
 
 
-@pytest.mark.parametrize("field", [0, 1, 2])
+@pytest.mark.parametrize("field", [0, 1, 2, 3])
 def test_inverse_divsteps_and_fermat(lib, field):
     """fe_inv (division steps) == fe_inv_fermat == a^-1 R^2 for Montgomery-form input a R."""
     p, _, nl = FIELDS[field]
@@ -67,9 +68,9 @@ def test_inverse_divsteps_and_fermat(lib, field):
     assert fp_op(lib, field, 4, 0) == 0
 
 
-@pytest.mark.parametrize("curve", [0, 2])
+@pytest.mark.parametrize("curve", [0, 2, 3])
 def test_glv_decompose_host_build(lib, curve):
-    Cc = O.BLS12_381 if curve == 2 else O.BLS12_377
+    Cc = {0: O.BLS12_377, 2: O.BLS12_381, 3: O.PALLAS}[curve]
     g = O.glv_params(Cc.q, Cc.lam)
     for s in O.prng_ints("host/glv", 3000, Cc.q) + [0, 1, Cc.q - 1, Cc.lam, Cc.lam + 1]:
         S = (C.c_uint32 * 8)(*[(s >> (32 * i)) & 0xFFFFFFFF for i in range(8)])

@@ -211,25 +211,32 @@ def test_config1_msm_basic_2p14_cpu_plumbing(c_oracle):
     assert ref == got
 
 
-# ---- BLS12-381 G1 (src/concrete/bls12-381.params.ts; covered by the reference in src/msm.test.ts:31) ----
+# ---- BLS12-381 G1 and Pallas (src/concrete/bls12-381.params.ts, pasta.params.ts; src/msm.test.ts:29-31) ----
+
+EXTRA_CURVES = [("bls381", "bls381.json"), ("pallas", "pallas.json")]
 
 
-def test_bls12_381_params_glv_and_msm_identities():
-    B = O.BLS12_381
+def extra_curve(name):
+    return O.BLS12_381 if name == "bls381" else O.PALLAS
+
+
+@pytest.mark.parametrize("name,gold", EXTRA_CURVES)
+def test_extra_curve_params_glv_and_msm_identities(name, gold):
+    B = extra_curve(name)
     G = (B.gx, B.gy)
     assert O.aff_is_on_curve(G, B) and O.aff_scale(B.q, G, B.p) is None
-    # (beta x, y) = lambda (x, y): src/concrete/bls12-381.params.ts:11-31 (the lambda2 / beta2 pair)
+    # (beta x, y) = lambda (x, y): bls12-381.params.ts:11-31 (the lambda2 / beta2 pair), pasta.params.ts:24-36
     assert pow(B.lam, 3, B.q) == 1 and pow(B.beta, 3, B.p) == 1
     assert O.aff_scale(B.lam, G, B.p) == (B.beta * B.gx % B.p, B.gy)
     g = O.glv_params(B.q, B.lam)
     assert (g.n, g.n0, g.m, g.k, g.max_bits) == (9, 5, 145, 116, 127)
     assert g.v00 * g.v11 - g.v10 * g.v01 == B.q
-    for s in O.prng_ints("kat/glv381", 2000, B.q) + [0, 1, B.q - 1]:
+    for s in O.prng_ints(f"kat/glv{name}", 2000, B.q) + [0, 1, B.q - 1]:
         a0, a1, n0, n1 = O.glv_decompose(s, g)
         s0, s1 = (-a0 if n0 else a0), (-a1 if n1 else a1)
         assert (s0 + s1 * B.lam - s) % B.q == 0 and max(a0, a1) < (1 << g.max_bits)
-    pts, ks = O.random_points_bls377("kat/381", 40, B)
-    sc = O.prng_ints("kat/381/s", 40, B.q)
+    pts, ks = O.random_points_bls377(f"kat/{name}", 40, B)
+    sc = O.prng_ints(f"kat/{name}/s", 40, B.q)
     spec = O.msm_naive_affine(sc, pts, B)
     assert spec == O.aff_scale(sum(a * b for a, b in zip(sc, ks)) % B.q, G, B.p)
     for c, safe, chunks in ((None, True, 1), (4, False, 3), (7, True, 2)):
@@ -237,9 +244,10 @@ def test_bls12_381_params_glv_and_msm_identities():
     assert O.msm_basic_projective(sc, pts, B, c=6) == spec
 
 
-def test_golden_bls12_381():
-    B = O.BLS12_381
-    d = load("bls381.json")
+@pytest.mark.parametrize("name,gold", EXTRA_CURVES)
+def test_golden_extra_curves(name, gold):
+    B = extra_curve(name)
+    d = load(gold)
     p = H(d["modulus"])
     assert p == B.p and H(d["q"]) == B.q and d["max_bits"] == 127
     for c in d["fp"]:
