@@ -208,7 +208,7 @@ def test_msm_large_known_discrete_logs(cv, lg):
         assert ctx.get_point(i) == O.aff_scale(a[i], G, P_MOD)
     dev, sb = ctx.generate_scalars(n, seed=400 + lg, to_host=True)
     s = O.scalars_from_bytes(sb)
-    assert all(v < B.q for v in s) and max(s).bit_length() == B.q.bit_length()
+    assert all(v < B.q for v in s) and max(s).bit_length() >= B.q.bit_length() - 1
     res, info = ctx.run_device(dev, n)
     assert res.as_tuple() == O.aff_scale(sum(x * y for x, y in zip(a, s)) % B.q, G, P_MOD), info
     res2, _ = ctx.run_device(dev, n, c=11)
