@@ -469,6 +469,10 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       a.scratch = (uint32_t*)w.scratch.p;
       a.n_out = n_out;
       a.steps = g.steps;
+      {
+        static const int wm = getenv("MSM_WAVE_MAJOR") ? atoi(getenv("MSM_WAVE_MAJOR")) : 0;   // experiment knob
+        a.wave_major = (r == 1) ? (wm & 1) : ((wm >> 1) & 1);
+      }
       if (r == 1) {
         if (te) hipLaunchKernelGGL(te::k_te_add<MODE_GATHER>, dim3(g.grid), dim3(256), 0, s, a);
         else W_LAUNCH_MODE(ctx, k_batch_add, MODE_GATHER, dim3(g.grid), dim3(256), 0, s, a);
@@ -549,14 +553,18 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       ctx->ensure(w.rows_sum, (size_t)kc * nchunks * 3 * NL * 4);
       W_LAUNCH(ctx, k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p,
                          (uint32_t*)w.rows_sum.p, fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
-      const uint32_t per_block = 2 * WS_THREADS;
-      const uint32_t nblk = (nchunks + per_block - 1) / per_block;
-      ctx->ensure(w.columns2, (size_t)kc * (nbits + 1) * nblk * 3 * NL * 4);
+      // first stage: one wave per 512 elements (8 per lane; at 2^20 that is about one wave per SIMD) -- the masked sums
+      // have half as many elements as the triangle sum and get half as many blocks; second stage: one wave per
+      // (window, bit) over the block sums (unused block slots stay zero = the identity)
+      const uint32_t nblk = std::max<uint32_t>(2, nchunks / (8 * BT_THREADS));
+      const size_t c2_bytes = (size_t)kc * (nbits + 1) * nblk * 3 * NL * 4;
+      ctx->ensure(w.columns2, c2_bytes);
       ctx->ensure(w.partials, (size_t)kc * (nbits + 1) * 36 * 4);
-      W_LAUNCH(ctx, k_bit_tree, dim3(nblk, nbits + 1, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.columns2.p,
-                         (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, per_block, nbits, 1, 0);
-      W_LAUNCH(ctx, k_bit_tree, dim3(1, nbits + 1, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
-                         (const uint32_t*)w.columns2.p, (const uint32_t*)nullptr, nblk, nblk, nbits, 0, 1);
+      HIPCHK(hipMemsetAsync(w.columns2.p, 0, c2_bytes, s));
+      W_LAUNCH(ctx, k_bit_tree, dim3(nbits * (nblk / 2) + nblk, 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.columns2.p,
+                         (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, nbits, 1, 0, nblk);
+      W_LAUNCH(ctx, k_bit_tree, dim3(1, nbits + 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.partials.p,
+                         (const uint32_t*)w.columns2.p, (const uint32_t*)nullptr, nblk, nbits, 0, 1, 1u);
     } else {
       W_LAUNCH(ctx, k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, (uint32_t*)nullptr,
                          fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);

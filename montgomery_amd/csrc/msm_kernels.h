@@ -605,6 +605,7 @@ struct BatchArgs {
   const uint32_t* off_out;
   uint32_t nb;
   const uint32_t* desc;     // MODE_SEARCH: operand descriptors from k_tail_desc (replaces the search when set)
+  uint32_t wave_major;      // element -> lane mapping, see k_batch_add
 };
 
 // One operand of a pair: where it lives and how to read it.
@@ -750,9 +751,15 @@ __global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
   using F = typename CV::F;
   const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.n_out) return;   // whole lane idle (steps * T >= n_out, lane t owns e = t, t + T, ...)
+  // lane t owns the pairs e = e0 + i * es, i < steps.  Interleaved (default): e0 = t, es = T -- at any moment the
+  // grid works on one contiguous span of T pairs.  Wave-contiguous (a.wave_major): every wave walks its own run
+  // of steps * 64 consecutive pairs, so concurrently running waves sit at the same relative position of many
+  // different buckets -- i.e. in the same region of the index-ordered point table.
+  const uint64_t e0 = a.wave_major ? ((t >> 6) * a.steps << 6) + (t & 63) : t;
+  const uint64_t es = a.wave_major ? 64 : T;
+  if (e0 >= a.n_out) return;   // whole lane idle
   // number of pairs this lane owns
-  const uint32_t my_steps = (uint32_t)min((uint64_t)a.steps, (a.n_out - t + T - 1) / T);
+  const uint32_t my_steps = (uint32_t)min((uint64_t)a.steps, (a.n_out - e0 + es - 1) / es);
 
   Fe<F> acc;
   fe_set_one<F>(acc);
@@ -760,12 +767,12 @@ __global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
   // ---- forward sweep: prefix products of the denominators -------------------------------------
   {
     PairFetch<MODE> nxt;
-    fetch_pair_x<MODE>(a, t, nxt);
+    fetch_pair_x<MODE>(a, e0, nxt);
 #pragma unroll 1
     for (uint32_t i = 0; i < my_steps; i++) {
       PairFetch<MODE> cur;
       copy_fetch<MODE>(cur, nxt);
-      if (i + 1 < my_steps) fetch_pair_x<MODE>(a, (uint64_t)(i + 1) * T + t, nxt);   // in flight during the multiply
+      if (i + 1 < my_steps) fetch_pair_x<MODE>(a, e0 + (uint64_t)(i + 1) * es, nxt);   // in flight during the multiply
       Fe<F> den;
       bool inf1, inf2;
       classify<F, MODE>(a, cur, inf1, inf2, den);
@@ -785,14 +792,14 @@ __global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
     uint32_t npre[NL];
     {
       const uint32_t i = my_steps - 1;
-      fetch_pair_x<MODE>(a, (uint64_t)i * T + t, nxt);
+      fetch_pair_x<MODE>(a, e0 + (uint64_t)i * es, nxt);
       const uint32_t* sp = a.scratch + ((uint64_t)i * NL) * T + t;
 #pragma unroll
       for (int l = 0; l < NL; l++) npre[l] = sp[(uint64_t)l * T];
     }
 #pragma unroll 1
     for (int i = (int)my_steps - 1; i >= 0; i--) {
-      const uint64_t e = (uint64_t)i * T + t;
+      const uint64_t e = e0 + (uint64_t)i * es;
       PairFetch<MODE> cur;
       copy_fetch<MODE>(cur, nxt);
       Fe<F> pre;
@@ -804,7 +811,7 @@ __global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
       load_y_raw<MODE>(a, cur.B, y2);
       // next pair's x coordinates and prefix product: in flight during this pair's arithmetic
       if (i > 0) {
-        fetch_pair_x<MODE>(a, (uint64_t)(i - 1) * T + t, nxt);
+        fetch_pair_x<MODE>(a, e0 + (uint64_t)(i - 1) * es, nxt);
         const uint32_t* sp = a.scratch + ((uint64_t)(i - 1) * NL) * T + t;
 #pragma unroll
         for (int l = 0; l < NL; l++) npre[l] = sp[(uint64_t)l * T];
@@ -875,6 +882,26 @@ MSM_DEV void proj_load(Proj<F>& P, const uint32_t* src) {
   for (int l = 0; l < NL; l++) { P.X.l[l] = src[l]; P.Y.l[l] = src[NL + l]; P.Z.l[l] = src[2 * NL + l]; }
 }
 
+// "planar" form for arrays that consecutive lanes walk together: word w of element j at base[w * stride + j]
+template <class F>
+MSM_DEV void proj_store_planar(uint32_t* base, uint64_t stride, uint64_t j, const Proj<F>& P) {
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    base[(uint64_t)l * stride + j] = P.X.l[l];
+    base[(uint64_t)(NL + l) * stride + j] = P.Y.l[l];
+    base[(uint64_t)(2 * NL + l) * stride + j] = P.Z.l[l];
+  }
+}
+template <class F>
+MSM_DEV void proj_load_planar(Proj<F>& P, const uint32_t* base, uint64_t stride, uint64_t j) {
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    P.X.l[l] = base[(uint64_t)l * stride + j];
+    P.Y.l[l] = base[(uint64_t)(NL + l) * stride + j];
+    P.Z.l[l] = base[(uint64_t)(2 * NL + l) * stride + j];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_bucket_finish: once every bucket is down to a handful of elements the remaining tree rounds are pure
 // latency (one shared inversion per launch for a few additions per lane).  This kernel ends the accumulation
@@ -891,15 +918,23 @@ __global__ void __launch_bounds__(256) k_bucket_finish(uint32_t* bucket_proj, co
   const uint32_t o0 = off[b], o1 = off[b + 1];
   Proj<F> acc;
   proj_set_zero<F>(acc);
+  // the next element's words are in flight while the current one is added (lanes read 16-byte pieces a bucket
+  // length apart: nothing coalesces, so the latency has to be covered by arithmetic)
+  uint32_t nx[NW], ny[NW];
+  if (o0 < o1) {
+    load_planes3(nx, in, in_cap, 0, o0);
+    load_planes3(ny, in, in_cap, 3, o0);
+  }
 #pragma unroll 1
   for (uint32_t o = o0; o < o1; o++) {
     Proj<F> Q;
-    uint32_t w[NW];
-    load_planes3(w, in, in_cap, 0, o);
-    bool qinf = w[NW - 1] == INF_WORD;
-    fe_unpack<F>(Q.X, w);
-    load_planes3(w, in, in_cap, 3, o);
-    fe_unpack<F>(Q.Y, w);
+    const bool qinf = nx[NW - 1] == INF_WORD;
+    fe_unpack<F>(Q.X, nx);
+    fe_unpack<F>(Q.Y, ny);
+    if (o + 1 < o1) {
+      load_planes3(nx, in, in_cap, 0, o + 1);
+      load_planes3(ny, in, in_cap, 3, o + 1);
+    }
     proj_add_mixed<F>(acc, acc, Q, qinf);
   }
   proj_store(bucket_proj + (uint64_t)b * (3 * NL), acc);
@@ -944,9 +979,9 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, uint32_
     }
     proj_add<F>(tri, tri, row);
   }
-  if (rows) {
-    proj_store(rows + (uint64_t)id * (3 * NL), row);
-    proj_store(columns + (uint64_t)id * (3 * NL), tri);
+  if (rows) {   // per window a [39][nchunks] matrix each: lanes (= consecutive chunks) write and k_bit_tree reads coalesced
+    proj_store_planar(rows + (uint64_t)kk * (3 * NL) * nchunks, nchunks, ch, row);
+    proj_store_planar(columns + (uint64_t)kk * (3 * NL) * nchunks, nchunks, ch, tri);
     return;
   }
   uint32_t ls = lstart - 1;
@@ -1068,58 +1103,88 @@ __global__ void __launch_bounds__(WS_THREADS) k_column_tree(uint32_t* out, const
 }
 
 // Bit-sliced weighting of the chunk sums:  sum_ch (ch * TC) * row_ch = TC * sum_b 2^b * S_b  with
-// S_b = sum of row_ch over the chunks whose index has bit b set.  Block (blk, y, kk) tree-sums, for window kk,
-//   y <  nbits : the rows of its slice whose chunk index has bit y set,
-//   y == nbits : the local triangles (columns) of its slice, unmasked.
-// in_stride / masked select between the first stage (chunk arrays) and the second stage (block sums, unmasked).
+// S_b = sum of row_ch over the chunks whose index has bit b set.  Wave (blk, y, kk) sums, for window kk,
+//   y <  nbits : its share of the n_in / 2 rows whose chunk index has bit y set (enumerated directly),
+//   y == nbits : its share of the n_in local triangles (columns), unmasked.
+// masked = 0 is the second stage: plain sums of the first stage's [kk][y][n_in] block results.
 // The K * (nbits + 1) results go to the host, which applies the 2^b weights with nbits doublings per window --
 // one chain per window instead of one per lane (the reference applies the same weight by double-and-add per
 // chunk, src/msm-batched-affine.ts:574-580).
+//
+// One wave per block: every lane adds a few elements serially, then the lane sums are folded through LDS in
+// log2 steps.  A projective addition is ~7000 dependent VALU instructions (15 us for a lone wave), so what
+// matters is the number of additions in sequence, not their count: ~8 + 6 here, then log2(n_in) in the second stage.
+constexpr int BT_THREADS = 64;
+
+// amdgpu_waves_per_eu(1, 1): one wave per SIMD.  The work is a chain of dependent additions per wave; a second wave on
+// the same SIMD halves the speed of both, and the dispatcher fills a SIMD before it moves to the next one (measured:
+// 40 us per addition in sequence with two resident waves against 19 us alone).
 template <class CV>
-__global__ void __launch_bounds__(WS_THREADS) k_bit_tree(uint32_t* out, const uint32_t* rows, const uint32_t* tris,
-                                                         uint32_t n_in, uint32_t per_block, uint32_t nbits, int masked,
-                                                         int pack_out) {
+__global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_bit_tree(uint32_t* out, const uint32_t* rows, const uint32_t* tris,
+                                                         uint32_t n_in, uint32_t nbits, int masked, int pack_out,
+                                                         uint32_t nblk_out) {
   using F = typename CV::F;
-  __shared__ uint32_t lds[3 * NL * WS_THREADS];
-  const uint32_t blk = blockIdx.x, y = blockIdx.y, kk = blockIdx.z, tid = threadIdx.x, nblk = gridDim.x;
-  const uint32_t beg = blk * per_block, end = min(beg + per_block, n_in);
-  // first stage: arrays are [kk][n_in]; second stage: [kk][y][n_in]
-  const uint64_t base = masked ? (uint64_t)kk * n_in : ((uint64_t)kk * (nbits + 1) + y) * n_in;
+  __shared__ uint32_t lds[3 * NL * BT_THREADS];
+  // First stage (masked): grid.x enumerates, per window, nbits masked sums of nblk_out / 2 blocks each and then the
+  // triangle sum of nblk_out blocks -- the masked sums have half as many elements, so every wave of the launch has
+  // the same number of additions in sequence.  The unused upper half of a masked sum's block slots in `out` is
+  // zero-filled (= the identity) by the host.  Second stage: grid (1, nbits + 1, kc).
+  uint32_t blk = blockIdx.x, y = blockIdx.y, nblk = gridDim.x;
+  const uint32_t kk = blockIdx.z, tid = threadIdx.x;
+  if (masked) {
+    const uint32_t half = nblk_out >> 1;
+    if (blk < nbits * half) { y = blk / half; blk -= y * half; nblk = half; }
+    else { blk -= nbits * half; y = nbits; nblk = nblk_out; }
+  }
+  const bool sel = masked && y < nbits;              // n_in = 2^nbits on the masked stage
+  const uint32_t count = sel ? n_in >> 1 : n_in;
+  const uint32_t span = (count + nblk - 1) / nblk;
+  const uint32_t beg = min(blk * span, count), end = min(beg + span, count);
+  // first stage: planar arrays [kk][39][n_in] written by k_bucket_reduce; second stage: [kk][y][n_in] points of 39 words
+  const uint64_t base = ((uint64_t)kk * (nbits + 1) + y) * n_in;
   const uint32_t* src = (masked && y == nbits) ? tris : rows;
+  // Every lane takes part in every addition: a wave whose EXEC mask is down to a few lanes runs this arithmetic
+  // up to 3.5x slower per instruction when the chip is busy (tools/ubench_exec.hip), so the usual halving tree --
+  // 32, 16, ... 1 active lanes -- is the worst shape.  Instead the lanes form groups of m = min(64, 2^ceil(log2 n))
+  // lanes, each group sums all n elements of the block (64 / m groups do the same work redundantly), and the fold is
+  // a cyclic all-reduce inside the group: after log2 m steps every lane holds the total.
+  const uint32_t n_el = end - beg;
+  uint32_t m = 1;
+  while (m < n_el && m < BT_THREADS) m <<= 1;
+  const uint32_t gl = tid & (m - 1);
   Proj<F> acc;
   proj_set_zero<F>(acc);
 #pragma unroll 1
-  for (uint32_t j = beg + tid; j < end; j += WS_THREADS) {
-    if (masked && y < nbits && !((j >> y) & 1u)) continue;
+  for (uint32_t i = beg + gl; i < end; i += m) {
+    // i-th index with bit y set: insert a one at bit position y
+    const uint32_t j = sel ? ((((i >> y) << 1) | 1u) << y) | (i & ((1u << y) - 1u)) : i;
     Proj<F> Q;
-    proj_load(Q, src + (base + j) * (3 * NL));
+    if (masked) proj_load_planar(Q, src + (uint64_t)kk * (3 * NL) * n_in, n_in, j);
+    else proj_load(Q, src + (base + j) * (3 * NL));
     proj_add<F>(acc, acc, Q);
   }
 #pragma unroll 1
-  for (uint32_t s = WS_THREADS / 2; s >= 1; s >>= 1) {
-    if (tid >= s && tid < 2 * s) {
+  for (uint32_t s = m >> 1; s >= 1; s >>= 1) {
 #pragma unroll
-      for (int l = 0; l < NL; l++) {
-        lds[(l)*WS_THREADS + tid] = acc.X.l[l];
-        lds[(NL + l) * WS_THREADS + tid] = acc.Y.l[l];
-        lds[(2 * NL + l) * WS_THREADS + tid] = acc.Z.l[l];
-      }
+    for (int l = 0; l < NL; l++) {
+      lds[(l)*BT_THREADS + tid] = acc.X.l[l];
+      lds[(NL + l) * BT_THREADS + tid] = acc.Y.l[l];
+      lds[(2 * NL + l) * BT_THREADS + tid] = acc.Z.l[l];
     }
     __syncthreads();
-    if (tid < s) {
-      Proj<F> Q;
+    const uint32_t partner = (tid & ~(m - 1)) | ((gl + s) & (m - 1));
+    Proj<F> Q;
 #pragma unroll
-      for (int l = 0; l < NL; l++) {
-        Q.X.l[l] = lds[(l)*WS_THREADS + tid + s];
-        Q.Y.l[l] = lds[(NL + l) * WS_THREADS + tid + s];
-        Q.Z.l[l] = lds[(2 * NL + l) * WS_THREADS + tid + s];
-      }
-      proj_add<F>(acc, acc, Q);
+    for (int l = 0; l < NL; l++) {
+      Q.X.l[l] = lds[(l)*BT_THREADS + partner];
+      Q.Y.l[l] = lds[(NL + l) * BT_THREADS + partner];
+      Q.Z.l[l] = lds[(2 * NL + l) * BT_THREADS + partner];
     }
     __syncthreads();
+    proj_add<F>(acc, acc, Q);
   }
   if (tid == 0) {
-    const uint64_t o = ((uint64_t)kk * (nbits + 1) + y) * nblk + blk;
+    const uint64_t o = ((uint64_t)kk * (nbits + 1) + y) * nblk_out + blk;
     if (!pack_out) {
       proj_store(out + o * (3 * NL), acc);
     } else {
