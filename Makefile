@@ -3,20 +3,35 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := montgomery_amd/csrc
 LIB := montgomery_amd/libmsm_hip.so
-HIPFLAGS := -O3 -pthread -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function -Wno-unused-variable \
+HIPFLAGS := -O3 -pthread -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -Wno-unused-variable \
             -Iinclude -I$(CSRC)
+BUILD := build
+CURVES := CvBls377 CvBls381 CvPallas
+CURVE_OBJS := $(CURVES:%=$(BUILD)/kernels_%.o)
+KHDRS := $(CSRC)/msm_kernels.h $(CSRC)/msm_gen_kernels.h $(CSRC)/kernel_inst.h $(CSRC)/field.h $(CSRC)/packed.h $(CSRC)/curve.h \
+         $(CSRC)/glv.h $(CSRC)/constants_gen.h
 
-all: $(LIB)
+# the curve-templated kernels compile once per curve, in parallel with the host pipeline
+all:
+	$(MAKE) -j4 $(LIB)
 
 $(CSRC)/constants_gen.h: $(CSRC)/gen_constants.py
 	python3 $(CSRC)/gen_constants.py
 
-$(LIB): $(CSRC)/msm_api.hip $(CSRC)/msm_kernels.h $(CSRC)/msm_gen.h $(CSRC)/field.h $(CSRC)/curve.h $(CSRC)/glv.h \
-        $(CSRC)/host_field.h $(CSRC)/constants_gen.h include/msm_hip.h
-	$(HIPCC) $(HIPFLAGS) $(CSRC)/msm_api.hip -o $(LIB)
+$(BUILD)/kernels_%.o: $(CSRC)/kernels_curve.hip $(KHDRS)
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -DMSM_CURVE_TU=$* -c $(CSRC)/kernels_curve.hip -o $@
+
+$(BUILD)/msm_api.o: $(CSRC)/msm_api.hip $(KHDRS) $(CSRC)/sort_kernels.h $(CSRC)/te_kernels.h $(CSRC)/msm_gen.h $(CSRC)/host_field.h \
+                    include/msm_hip.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/msm_api.hip -o $@
+
+$(LIB): $(BUILD)/msm_api.o $(CURVE_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -pthread $(BUILD)/msm_api.o $(CURVE_OBJS) -o $(LIB)
 
 clean:
-	rm -f $(LIB)
+	rm -rf $(LIB) $(BUILD)
 
 .PHONY: all clean
 

@@ -2,7 +2,8 @@
 // declared in include/msm_hip.h.  Orchestration follows `createMsm().msm`
 // (reference src/msm-batched-affine.ts:69-340); the per-thread SPMD phases separated by
 // `barrier()` there become kernel launches on one HIP stream here.
-#include "msm_kernels.h"
+#include "kernel_inst.h"   // curve-templated kernels: extern templates, defined in kernels_curve.hip per curve
+#include "sort_kernels.h"
 #include "te_kernels.h"
 #include "host_field.h"
 #include "../../include/msm_hip.h"

@@ -217,372 +217,6 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts,
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_scan (single workgroup): bucket sizes -> padded slot offsets, cursor, tail-round offsets
-//   info[0] = total slots, info[1] = max bucket size, info[2] = RT (tail rounds),
-//   info[3 + r] = number of elements entering tail round r (r = 0..RT)
-//   tail_off[r] has nb + 1 entries: offsets of ceil(ceil(n/G) / 2^r)
-// ---------------------------------------------------------------------------------------------
-
-constexpr int SCAN_THREADS = 1024;
-constexpr int SCAN_ITEMS = 4;
-
-MSM_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wave, uint32_t& total) {
-  // inclusive scan inside the wave
-  uint32_t x = v;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t y = __shfl_up(x, d, 64);
-    if (lane >= d) x += y;
-  }
-  __syncthreads();
-  if (lane == 63) lds_wave[wave] = x;
-  __syncthreads();
-  uint32_t wave_base = 0, tot = 0;
-  const int nw = blockDim.x >> 6;
-  for (int w = 0; w < nw; w++) {
-    uint32_t t = lds_wave[w];
-    if (w < wave) wave_base += t;
-    tot += t;
-  }
-  total = tot;
-  return wave_base + x - v;
-}
-
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan(const uint32_t* counts, uint32_t nb, uint32_t logG,
-                                                       uint32_t* cursor, uint32_t* tail_off, uint32_t* info) {
-  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
-  __shared__ uint32_t lds_max;
-  const uint32_t G1 = (1u << logG) - 1;
-  if (threadIdx.x == 0) lds_max = 0;
-  __syncthreads();
-  // pass A: max bucket size
-  uint32_t mx = 0;
-  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) mx = max(mx, counts[b]);
-  atomicMax(&lds_max, mx);
-  __syncthreads();
-  mx = lds_max;
-  uint32_t capmax = (mx + G1) >> logG;
-  int RT = 0;
-  while ((1u << RT) < capmax) RT++;
-  // pass B: slot offsets (cursor) with padding to multiples of G
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < nb; base += SCAN_THREADS * SCAN_ITEMS) {
-    uint32_t v[SCAN_ITEMS], sum = 0;
-    uint32_t b0 = base + threadIdx.x * SCAN_ITEMS;
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) {
-      uint32_t b = b0 + j;
-      v[j] = b < nb ? ((counts[b] + G1) >> logG) << logG : 0u;
-      sum += v[j];
-    }
-    uint32_t tot;
-    uint32_t ex = block_excl_scan(sum, lds_wave, tot) + carry;
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) {
-      uint32_t b = b0 + j;
-      if (b < nb) cursor[b] = ex;
-      ex += v[j];
-    }
-    carry += tot;
-  }
-  if (threadIdx.x == 0) { info[0] = carry; info[1] = mx; info[2] = (uint32_t)RT; }
-  // pass C: tail-round offsets
-  for (int r = 0; r <= RT; r++) {
-    uint32_t* off = tail_off + (uint64_t)r * (nb + 1);
-    const uint32_t rnd = (1u << r) - 1;
-    carry = 0;
-    for (uint32_t base = 0; base < nb; base += SCAN_THREADS * SCAN_ITEMS) {
-      uint32_t v[SCAN_ITEMS], sum = 0;
-      uint32_t b0 = base + threadIdx.x * SCAN_ITEMS;
-#pragma unroll
-      for (int j = 0; j < SCAN_ITEMS; j++) {
-        uint32_t b = b0 + j;
-        uint32_t cg = b < nb ? (counts[b] + G1) >> logG : 0u;
-        v[j] = (cg + rnd) >> r;
-        sum += v[j];
-      }
-      uint32_t tot;
-      uint32_t ex = block_excl_scan(sum, lds_wave, tot) + carry;
-#pragma unroll
-      for (int j = 0; j < SCAN_ITEMS; j++) {
-        uint32_t b = b0 + j;
-        if (b < nb) off[b] = ex;
-        ex += v[j];
-      }
-      carry += tot;
-    }
-    if (threadIdx.x == 0) { off[nb] = carry; info[3 + r] = carry; }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Multi-block scan of the bucket sizes (replaces the single-workgroup k_scan on the LDS-sort path):
-//   quantity 0      : padded slot count  roundup(n, G)          -> cursor (slot offsets), total -> info[0]
-//   quantity 1 + r  : ceil(ceil(n / G) / 2^r), r = 0..RT          -> tail_off[r] (nb + 1 entries), totals -> info[3 + r]
-// k_pscan_partial sums each quantity per block of PS_BLOCK * PS_ITEMS buckets, k_pscan_top scans the
-// block sums (one workgroup), k_pscan_final rescans each block with its base.  k_bucket_max gives the
-// largest bucket (host needs RT before it can size this scan).
-// ---------------------------------------------------------------------------------------------
-
-constexpr int PS_BLOCK = 256;
-constexpr int PS_ITEMS = 16;
-constexpr int PS_SPAN = PS_BLOCK * PS_ITEMS;
-
-MSM_DEV uint32_t scan_quantity(uint32_t n, uint32_t logG, int q) {
-  const uint32_t cg = (n + ((1u << logG) - 1)) >> logG;
-  if (q == 0) return cg << logG;
-  const int r = q - 1;
-  return (cg + ((1u << r) - 1)) >> r;
-}
-
-__global__ void __launch_bounds__(256) k_bucket_max(const uint32_t* counts, uint32_t nb, uint32_t* info) {
-  __shared__ uint32_t lds_max;
-  if (threadIdx.x == 0) lds_max = 0;
-  __syncthreads();
-  uint32_t mx = 0;
-  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) mx = max(mx, counts[b]);
-  atomicMax(&lds_max, mx);
-  __syncthreads();
-  if (threadIdx.x == 0) atomicMax(&info[1], lds_max);
-}
-
-__global__ void __launch_bounds__(PS_BLOCK) k_pscan_partial(const uint32_t* counts, uint32_t nb, uint32_t logG, int nq,
-                                                            uint32_t* partial, uint32_t nblocks) {
-  __shared__ uint32_t lds_wave[PS_BLOCK / 64];
-  const uint32_t b0 = blockIdx.x * PS_SPAN + threadIdx.x * PS_ITEMS;
-  uint32_t n[PS_ITEMS];
-#pragma unroll
-  for (int j = 0; j < PS_ITEMS; j++) n[j] = (b0 + j) < nb ? counts[b0 + j] : 0u;
-  for (int q = 0; q < nq; q++) {
-    uint32_t sum = 0;
-#pragma unroll
-    for (int j = 0; j < PS_ITEMS; j++) sum += scan_quantity(n[j], logG, q);
-    uint32_t tot;
-    block_excl_scan(sum, lds_wave, tot);
-    if (threadIdx.x == 0) partial[(uint64_t)q * nblocks + blockIdx.x] = tot;
-  }
-}
-
-__global__ void __launch_bounds__(SCAN_THREADS) k_pscan_top(uint32_t* partial, uint32_t nblocks, int nq, uint32_t* info) {
-  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
-  for (int q = 0; q < nq; q++) {
-    uint32_t* p = partial + (uint64_t)q * nblocks;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < nblocks; base += SCAN_THREADS) {
-      uint32_t i = base + threadIdx.x;
-      uint32_t v = i < nblocks ? p[i] : 0u;
-      uint32_t tot;
-      uint32_t ex = block_excl_scan(v, lds_wave, tot) + carry;
-      if (i < nblocks) p[i] = ex;
-      carry += tot;
-    }
-    if (threadIdx.x == 0) {
-      if (q == 0) info[0] = carry; else info[3 + (q - 1)] = carry;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(PS_BLOCK) k_pscan_final(const uint32_t* counts, uint32_t nb, uint32_t logG, int nq,
-                                                          const uint32_t* partial, uint32_t nblocks, uint32_t* cursor,
-                                                          uint32_t* tail_off, const uint32_t* info) {
-  __shared__ uint32_t lds_wave[PS_BLOCK / 64];
-  const uint32_t b0 = blockIdx.x * PS_SPAN + threadIdx.x * PS_ITEMS;
-  uint32_t n[PS_ITEMS];
-#pragma unroll
-  for (int j = 0; j < PS_ITEMS; j++) n[j] = (b0 + j) < nb ? counts[b0 + j] : 0u;
-  for (int q = 0; q < nq; q++) {
-    uint32_t v[PS_ITEMS], sum = 0;
-#pragma unroll
-    for (int j = 0; j < PS_ITEMS; j++) { v[j] = scan_quantity(n[j], logG, q); sum += v[j]; }
-    uint32_t tot;
-    uint32_t ex = block_excl_scan(sum, lds_wave, tot) + partial[(uint64_t)q * nblocks + blockIdx.x];
-    uint32_t* out = q == 0 ? cursor : tail_off + (uint64_t)(q - 1) * (nb + 1);
-#pragma unroll
-    for (int j = 0; j < PS_ITEMS; j++) {
-      if (b0 + j < nb) out[b0 + j] = ex;
-      ex += v[j];
-    }
-    if (q > 0 && blockIdx.x == 0 && threadIdx.x == 0) out[nb] = info[3 + (q - 1)];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_tail_desc: per tail round, the operand locations of every output element, found once by binary
-// search here (thousands of resident waves hide the dependent loads) instead of twice per pair inside
-// the latency-critical batch-add kernel.  desc[e] = (index of the first operand << 1) | second operand present.
-// ---------------------------------------------------------------------------------------------
-
-__global__ void __launch_bounds__(256) k_tail_desc(uint32_t* desc, const uint32_t* off_in, const uint32_t* off_out, uint32_t nb,
-                                                   uint32_t n_out) {
-  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_out) return;
-  uint32_t lo = 0, hi = nb;
-  while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (off_out[mid] <= e) lo = mid; else hi = mid;
-  }
-  uint32_t j = e - off_out[lo];
-  uint32_t ia = off_in[lo] + 2 * j;
-  desc[e] = (ia << 1) | ((ia + 1) < off_in[lo + 1] ? 1u : 0u);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_scatter: digits -> bucket-ordered payload slots (order inside a bucket is arbitrary; the
-// bucket sum does not depend on it)
-// ---------------------------------------------------------------------------------------------
-
-__global__ void __launch_bounds__(256) k_scatter(uint32_t* slots, uint32_t* cursor, const uint32_t* dig, uint64_t two_n,
-                                                 uint64_t total, uint32_t L) {
-  uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= total) return;
-  uint32_t d = dig[id];
-  uint32_t l = d & 0x7FFFFFFFu;
-  if (l == 0) return;
-  uint64_t kk = id / two_n;
-  uint32_t j = (uint32_t)(id - kk * two_n);
-  uint32_t pos = atomicAdd(&cursor[kk * L + (l - 1)], 1u);
-  slots[pos] = (j << 1) | (d >> 31);
-}
-
-// ---------------------------------------------------------------------------------------------
-// LDS-privatised counting sort (used whenever one window's L counters fit the 160 KB LDS, c <= 16).
-//   k_hist      : grid (B, Kg); block (b, kk) histograms its slice of window kk's digits in LDS and
-//                 writes the L counters to block_hist[kk][b][.] with plain coalesced stores
-//   k_colscan   : per bucket, exclusive prefix over the B blocks (in place) and the bucket total
-//   k_scatter_lds: block (b, kk) loads its L start positions (bucket slot offset + block prefix) into
-//                 LDS and ranks its entries with returning LDS atomics
-// The only global atomics left are none at all; the reference's Atomics.add histogram
-// (src/msm-batched-affine.ts:197) becomes ds_add_u32 on a CU-private copy.
-// ---------------------------------------------------------------------------------------------
-
-constexpr int SORT_THREADS = 1024;
-
-// part_start == nullptr: window kk owns digits dig[kk * two_n ..) and block b the slice [b * chunk, (b+1) * chunk).
-// part_start != nullptr (second level of the two-level sort): "window" kk is the partition
-// [part_start[kk], part_start[kk + 1]) of a flat digit array.  bin = (l - 1) >> shift (shift > 0: coarse level).
-// blk_tab != nullptr (with part_start): 1-D grid over the ACTIVE (partition, block) pairs listed in blk_tab as
-// (kk, b, first histogram row of kk); partitions differ 50x in size, idle blocks would dominate otherwise.
-__global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, const uint32_t* dig, uint64_t two_n,
-                                                       uint64_t chunk, uint32_t L, uint32_t shift,
-                                                       const uint32_t* part_start, const uint32_t* blk_tab) {
-  extern __shared__ uint32_t lds_hist[];
-  uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
-  uint64_t hist_row = (uint64_t)kk * B + b;
-  if (blk_tab) {
-    kk = blk_tab[3 * blockIdx.x];
-    b = blk_tab[3 * blockIdx.x + 1];
-    hist_row = (uint64_t)blk_tab[3 * blockIdx.x + 2] + b;
-  }
-  for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) lds_hist[l] = 0;
-  __syncthreads();
-  uint64_t beg, end;
-  const uint32_t* d;
-  if (part_start) {
-    beg = (uint64_t)part_start[kk] + (uint64_t)b * chunk;
-    end = min(beg + chunk, (uint64_t)part_start[kk + 1]);
-    d = dig;
-  } else {
-    beg = (uint64_t)b * chunk;
-    end = min(beg + chunk, two_n);
-    d = dig + (uint64_t)kk * two_n;
-  }
-  for (uint64_t j = beg + threadIdx.x; j < end; j += SORT_THREADS) {
-    uint32_t l = d[j] & 0x7FFFFFFFu;
-    if (l) atomicAdd(&lds_hist[(l - 1) >> shift], 1u);
-  }
-  __syncthreads();
-  uint32_t* out = block_hist + hist_row * L;
-  for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) out[l] = lds_hist[l];
-}
-
-// row_tab != nullptr: partition kk owns histogram rows [row_tab[kk], row_tab[kk + 1]) (variable block counts)
-__global__ void __launch_bounds__(256) k_colscan(uint32_t* block_hist, uint32_t* counts, uint32_t B, uint32_t L,
-                                                 uint32_t k_cnt, const uint32_t* row_tab) {
-  uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (uint64_t)k_cnt * L) return;
-  uint32_t kk = (uint32_t)(id / L), l = (uint32_t)(id - (uint64_t)kk * L);
-  uint32_t* p = block_hist + (uint64_t)kk * B * L + l;
-  if (row_tab) {
-    p = block_hist + (uint64_t)row_tab[kk] * L + l;
-    B = row_tab[kk + 1] - row_tab[kk];
-  }
-  uint32_t run = 0;
-  for (uint32_t b = 0; b < B; b++) {
-    uint32_t v = p[(uint64_t)b * L];
-    p[(uint64_t)b * L] = run;
-    run += v;
-  }
-  counts[id] = run;
-}
-
-__global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(uint32_t* slots, const uint32_t* cursor,
-                                                              const uint32_t* block_hist, const uint32_t* dig,
-                                                              uint64_t two_n, uint64_t chunk, uint32_t L,
-                                                              const uint32_t* part_start, const uint32_t* idx,
-                                                              const uint32_t* blk_tab) {
-  extern __shared__ uint32_t lds_pos[];
-  uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
-  uint64_t hist_row = (uint64_t)kk * B + b;
-  if (blk_tab) {
-    kk = blk_tab[3 * blockIdx.x];
-    b = blk_tab[3 * blockIdx.x + 1];
-    hist_row = (uint64_t)blk_tab[3 * blockIdx.x + 2] + b;
-  }
-  const uint32_t* base = block_hist + hist_row * L;
-  const uint32_t* cur = cursor + (uint64_t)kk * L;
-  for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) lds_pos[l] = cur[l] + base[l];
-  __syncthreads();
-  uint64_t beg, end;
-  const uint32_t* d;
-  if (part_start) {
-    beg = (uint64_t)part_start[kk] + (uint64_t)b * chunk;
-    end = min(beg + chunk, (uint64_t)part_start[kk + 1]);
-    d = dig;
-  } else {
-    beg = (uint64_t)b * chunk;
-    end = min(beg + chunk, two_n);
-    d = dig + (uint64_t)kk * two_n;
-  }
-  for (uint64_t j = beg + threadIdx.x; j < end; j += SORT_THREADS) {
-    uint32_t v = d[j];
-    uint32_t l = v & 0x7FFFFFFFu;
-    if (l) {
-      uint32_t pos = atomicAdd(&lds_pos[l - 1], 1u);
-      uint32_t entry = idx ? idx[j] : (uint32_t)j;
-      slots[pos] = (entry << 1) | (v >> 31);
-    }
-  }
-}
-
-// First level of the two-level sort (windows with more than 2^15 buckets, c > 16): entries of window kk are
-// partitioned by the high bits of their bucket index into Hn = L >> 15 coarse bins (k_hist with shift = 15 and
-// k_colscan provide the offsets); the entry keeps its low 15 bits (+1, so 0 still means "no entry"), its sign and
-// its entry index in two flat arrays.  Every block writes Hn sequential streams, which the L2 can merge -- the
-// direct scatter over 2^21 buckets could not.  The second level is the ordinary LDS sort per coarse bin.
-__global__ void __launch_bounds__(SORT_THREADS) k_scatter_coarse(uint32_t* dig2, uint32_t* idx2, const uint32_t* part_start,
-                                                                 const uint32_t* block_hist, const uint32_t* dig,
-                                                                 uint64_t two_n, uint64_t chunk, uint32_t Hn, uint32_t shift) {
-  extern __shared__ uint32_t lds_pos[];
-  const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
-  const uint32_t* base = block_hist + ((uint64_t)kk * B + b) * Hn;
-  for (uint32_t h = threadIdx.x; h < Hn; h += SORT_THREADS) lds_pos[h] = part_start[kk * Hn + h] + base[h];
-  __syncthreads();
-  const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
-  const uint32_t* d = dig + (uint64_t)kk * two_n;
-  const uint32_t lo_mask = (1u << shift) - 1;
-  for (uint64_t j = beg + threadIdx.x; j < end; j += SORT_THREADS) {
-    uint32_t v = d[j];
-    uint32_t l = v & 0x7FFFFFFFu;
-    if (l) {
-      uint32_t pos = atomicAdd(&lds_pos[(l - 1) >> shift], 1u);
-      dig2[pos] = (((l - 1) & lo_mask) + 1) | (v & 0x80000000u);
-      idx2[pos] = (uint32_t)j;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_batch_add: one tree round of the bucket accumulation.
 //   output element e = input element 2e + input element 2e+1 (affine, edge cases included),
 //   each lane walks `steps` pairs e = i*T + t and shares ONE field inversion among them
