@@ -1,0 +1,67 @@
+"""Shapes the small parity cases do not reach, on every Weierstrass curve: ragged large N, forced window sizes on
+either side of the one-level / two-level sort boundary, few distinct scalars (a handful of enormous buckets per
+window: deep trees, long tail rounds), short scalars (empty upper windows), two live contexts.  `-m gpu`.
+Checked through the discrete logs of the generated points: sum s_i P_i = (sum s_i a_i) G."""
+import pytest
+
+from oracle import msm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def curve(name):
+    from montgomery_amd import _lib
+
+    return {"bls12-377": (_lib.CURVE_BLS12_377_G1, O.BLS12_377), "bls12-381": (_lib.CURVE_BLS12_381_G1, O.BLS12_381),
+            "pallas": (_lib.CURVE_PALLAS, O.PALLAS)}[name]
+
+
+def expected(B, a, s):
+    return O.aff_scale(sum(x * y for x, y in zip(a, s)) % B.q, (B.gx, B.gy), B.p)
+
+
+@pytest.mark.parametrize("name", ["bls12-377", "bls12-381", "pallas"])
+@pytest.mark.parametrize("n", [(1 << 17) - 1, 3 * (1 << 18) + 7])
+def test_ragged_skewed_short(name, n):
+    from montgomery_amd.api import MsmContext
+
+    cid, B = curve(name)
+    ctx = MsmContext(cid)
+    try:
+        a = O.scalars_from_bytes(ctx.generate_points(n, seed=n & 0xFFFF, want_scalars=True))
+        dev, sb = ctx.generate_scalars(n, seed=99, to_host=True)
+        exp = expected(B, a, O.scalars_from_bytes(sb))
+        for c in (None, 12, 19):
+            res, info = ctx.run_device(dev, n, c=c)
+            assert res.as_tuple() == exp, (name, n, info)
+        vals = O.prng_ints(f"stress/{name}", 5, B.q)
+        sk = [vals[i % 5] for i in range(n)]
+        res, info = ctx.run(O.scalars_to_bytes(sk))
+        assert res.as_tuple() == expected(B, a, sk), info
+        assert info["max_bucket"] >= n // 5
+        sm = [(i * 2654435761) & 0xFFFFF for i in range(n)]
+        res, info = ctx.run(O.scalars_to_bytes(sm))
+        assert res.as_tuple() == expected(B, a, sm), info
+    finally:
+        ctx.close()
+
+
+def test_two_live_contexts_interleaved():
+    from montgomery_amd.api import MsmContext
+
+    (c1id, B1), (c2id, B2) = curve("bls12-377"), curve("bls12-381")
+    c1, c2 = MsmContext(c1id), MsmContext(c2id)
+    try:
+        n = 1 << 16
+        a1 = O.scalars_from_bytes(c1.generate_points(n, seed=1, want_scalars=True))
+        a2 = O.scalars_from_bytes(c2.generate_points(n, seed=2, want_scalars=True))
+        d1, s1 = c1.generate_scalars(n, seed=3, to_host=True)
+        d2, s2 = c2.generate_scalars(n, seed=4, to_host=True)
+        for _ in range(3):
+            r1, _i = c1.run_device(d1, n)
+            r2, _i = c2.run_device(d2, n)
+        assert r1.as_tuple() == expected(B1, a1, O.scalars_from_bytes(s1))
+        assert r2.as_tuple() == expected(B2, a2, O.scalars_from_bytes(s2))
+    finally:
+        c1.close()
+        c2.close()
