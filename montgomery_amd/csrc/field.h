@@ -46,6 +46,20 @@ MSM_DEV uint32_t fe_funnel_r(uint32_t lo, uint32_t hi, int sh) {
 #endif
 }
 
+// c + a * K for the small constants K = 1 and 4 as ONE v_mad_u64_u32.  Written as plain C the compiler turns them
+// into a zero-extension (v_mov) plus a 64-bit shift-add; the multiplier's carry steps use them 25 times.
+template <int K>
+MSM_DEV uint64_t fe_mad_const(uint32_t a, uint64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint64_t cy;   // carry-out operand of the VOP3b encoding, unused; accumulate in place: no extra registers
+  if (K == 1) asm("v_mad_u64_u32 %0, %1, %2, 1, %0" : "+v"(c), "=s"(cy) : "v"(a));
+  else asm("v_mad_u64_u32 %0, %1, %2, 4, %0" : "+v"(c), "=s"(cy) : "v"(a));
+  return c;
+#else
+  return c + (uint64_t)a * (uint32_t)K;
+#endif
+}
+
 // words (32-bit packed, little endian) -> 30-bit limbs
 template <class C>
 MSM_DEV void fe_unpack(Fe<C>& r, const uint32_t (&w)[C::NW]) {
@@ -215,7 +229,7 @@ MSM_DEV void fe_mul(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) {
     if (UNIT) {
       uint32_t lo = (uint32_t)t[0] & LMASK;
       m = (0u - lo) & LMASK;
-      carry = (t[0] + m) >> LB;   // t[0] + m*P[0] = t[0] + m is a multiple of 2^30
+      carry = fe_mad_const<1>(m, t[0]) >> LB;   // t[0] + m*P[0] = t[0] + m is a multiple of 2^30
     } else {
       m = ((uint32_t)t[0] * C::MU) & LMASK;
       carry = (t[0] + (uint64_t)m * C::P[0]) >> LB;
@@ -227,10 +241,12 @@ MSM_DEV void fe_mul(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) {
     for (int j = 0; j + 1 < N; j++) t[j] = t[j + 1];
     t[N - 1] = 0;
     if (N > 7 && i == N / 2) {
+      // overflow guard, not a normalisation: move each accumulator's high word up one column (x 2^32 = 4 x 2^30),
+      // one MAD + one clear per column; the low words stay as they are (< 2^32)
 #pragma unroll
       for (int j = 0; j + 1 < N; j++) {
-        t[j + 1] += t[j] >> LB;
-        t[j] &= LMASK;
+        t[j + 1] = fe_mad_const<4>((uint32_t)(t[j] >> 32), t[j + 1]);
+        t[j] = (uint32_t)t[j];
       }
     }
   }
@@ -261,11 +277,12 @@ MSM_DEV void fe_sqr(Fe<C>& r, const Fe<C>& a) {
 #pragma unroll
     for (int j = i + 1; j < N; j++) t[i + j] += (uint64_t)a.l[i] * a2[j];
   }
-  // normalize the low half so the reduction rows cannot overflow the accumulators
+  // overflow guard before the reduction rows are added (not a normalisation): every accumulator's high word moves
+  // up one column (x 2^32 = 4 x 2^30) with one MAD, leaving < 2^32 behind
 #pragma unroll
   for (int j = 0; j + 1 < 2 * N; j++) {
-    t[j + 1] += t[j] >> LB;
-    t[j] &= LMASK;
+    t[j + 1] = fe_mad_const<4>((uint32_t)(t[j] >> 32), t[j + 1]);
+    t[j] = (uint32_t)t[j];
   }
   // reduction: N rows of m_i * p
   constexpr bool UNIT = (C::MU == LMASK) && (C::P[0] == 1);
@@ -276,7 +293,7 @@ MSM_DEV void fe_sqr(Fe<C>& r, const Fe<C>& a) {
     if (UNIT) {
       uint32_t lo = (uint32_t)t[i] & LMASK;
       m = (0u - lo) & LMASK;
-      carry = (t[i] + m) >> LB;
+      carry = fe_mad_const<1>(m, t[i]) >> LB;
     } else {
       m = ((uint32_t)t[i] * C::MU) & LMASK;
       carry = (t[i] + (uint64_t)m * C::P[0]) >> LB;
