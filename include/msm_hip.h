@@ -54,7 +54,10 @@ typedef struct msm_opts {
   int32_t k_lo, k_hi;   /* window shard [k_lo, k_hi) for msm_window_sums; 0,0 = all windows */
   int32_t serial;       /* != 0: run the window groups one after the other on one stream (no overlap): phase_ms then
                            hold exclusive kernel times -- used for roofline measurements */
-  int32_t reserved[3];
+  int32_t no_glv;       /* != 0 (Weierstrass curves): no endomorphism split -- digits of the full scalar, K = ceil((b + 1) / c)
+                           with b = bit length of q: the window structure of msmProjective / msmBasic
+                           (src/parallel.ts:69-87, src/msm-basic.ts:56-91).  Same group element, 2x the additions */
+  int32_t reserved[2];
 } msm_opts;
 
 #define MSM_N_PHASES 8

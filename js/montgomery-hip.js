@@ -64,13 +64,14 @@ function createCurve(params, curveId, coordBytes, device, wireBytes) {
     },
     async msm(scalarPtr, pointPtr, N, verboseTiming, options) {
       const c = (options && options.c) || 0;
-      const r = hip.msm(ctx, scalarPtr.bytes.slice(0, 32 * N), c, coordBytes);
+      const r = hip.msm(ctx, scalarPtr.bytes.slice(0, 32 * N), c, coordBytes, options && options.noGlv ? 1 : 0);
       const result = { x: leBytesToBigint(r.x), y: leBytesToBigint(r.y), isZero: r.isZero };
       const log = verboseTiming ? [[{ n: Math.ceil(Math.log2(Math.max(N, 1))), K: r.K, c: r.c }], [`msm total... ${r.phaseMs[0].toFixed(3)}ms`]] : [];
       return { result, log };
     },
     msmProjective(scalarPtr, pointPtr, N, options) {
-      return Parallel.msm(scalarPtr, pointPtr, N, false, options);   // src/parallel.ts:69-87: same group element
+      // src/parallel.ts:69-87: signed windows of the whole scalar, no endomorphism split (same group element)
+      return Parallel.msm(scalarPtr, pointPtr, N, false, Object.assign({}, options, { noGlv: true }));
     },
     msmUnsafe(scalarPtr, pointPtr, N, verboseTiming, options) {
       return Parallel.msm(scalarPtr, pointPtr, N, verboseTiming, options);   // the GPU kernels always handle the edge cases

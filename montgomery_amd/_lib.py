@@ -32,7 +32,7 @@ EXPORTS = (
 
 class MsmOpts(C.Structure):
     _fields_ = [("c", C.c_int32), ("unsafe", C.c_int32), ("k_lo", C.c_int32), ("k_hi", C.c_int32), ("serial", C.c_int32),
-                ("reserved", C.c_int32 * 3)]
+                ("no_glv", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class MsmResult(C.Structure):

@@ -225,18 +225,20 @@ class MsmContext:
         self._check(self._lib.msm_plan(self._h, n, C.byref(opts), C.byref(cc), C.byref(kk)))
         return cc.value, kk.value
 
-    def run(self, scalars: BytesLike, c: Optional[int] = None, unsafe: bool = False) -> Tuple[AffineResult, Dict]:
+    def run(self, scalars: BytesLike, c: Optional[int] = None, unsafe: bool = False, no_glv: bool = False) -> Tuple[AffineResult, Dict]:
         if len(scalars) % 32:
             raise MsmError(_lib.MSM_ERR_ARG, f"scalar buffer length {len(scalars)} is not a multiple of 32")
         n = len(scalars) // 32
         buf = (C.c_uint8 * max(len(scalars), 1)).from_buffer_copy(bytes(scalars) or b"\0")
-        return self._run(buf, n, 0, c, unsafe)
+        return self._run(buf, n, 0, c, unsafe, no_glv=no_glv)
 
-    def run_device(self, dev_ptr: int, n: int, c: Optional[int] = None, unsafe: bool = False, serial: bool = False) -> Tuple[AffineResult, Dict]:
-        return self._run(C.c_void_p(dev_ptr), n, 1, c, unsafe, serial)
+    def run_device(self, dev_ptr: int, n: int, c: Optional[int] = None, unsafe: bool = False, serial: bool = False,
+                   no_glv: bool = False) -> Tuple[AffineResult, Dict]:
+        return self._run(C.c_void_p(dev_ptr), n, 1, c, unsafe, serial, no_glv)
 
-    def _run(self, ptr, n: int, on_device: int, c: Optional[int], unsafe: bool, serial: bool = False) -> Tuple[AffineResult, Dict]:
-        opts = MsmOpts(c=c or 0, unsafe=int(unsafe), serial=int(serial))
+    def _run(self, ptr, n: int, on_device: int, c: Optional[int], unsafe: bool, serial: bool = False,
+             no_glv: bool = False) -> Tuple[AffineResult, Dict]:
+        opts = MsmOpts(c=c or 0, unsafe=int(unsafe), serial=int(serial), no_glv=int(no_glv))
         res = MsmResult()
         self._check(self._lib.msm_run(self._h, ptr, n, on_device, C.byref(opts), C.byref(res)))
         nb = self.coord_bytes
@@ -383,10 +385,11 @@ class _Parallel:
         if N > self._ctx.n_points:
             raise MsmError(_lib.MSM_ERR_NO_POINTS, f"{N} scalars but {self._ctx.n_points} resident points")
         unsafe = not options.get("useSafeAdditions", True)
+        no_glv = bool(options.get("noGlv", False))
         if scalarPtr.dev_ptr:
-            res, info = self._ctx.run_device(scalarPtr.dev_ptr, N, options.get("c"), unsafe)
+            res, info = self._ctx.run_device(scalarPtr.dev_ptr, N, options.get("c"), unsafe, no_glv=no_glv)
         else:
-            res, info = self._ctx.run(scalarPtr.data[: 32 * N], options.get("c"), unsafe)
+            res, info = self._ctx.run(scalarPtr.data[: 32 * N], options.get("c"), unsafe, no_glv=no_glv)
         log: List = []
         if verboseTiming:
             log.append([{"n": (N - 1).bit_length() if N > 1 else 0, "K": info["K"], "c": info["c"]}])
@@ -395,8 +398,11 @@ class _Parallel:
         return {"result": res, "log": log, "info": info}
 
     def msmProjective(self, scalarPtr: ScalarPtr, pointPtr: PointPtr, N: int, options: Optional[Dict] = None) -> Dict:
-        """`msmProjective` (src/parallel.ts:69-87: msmBasic over projective points, no GLV).  The value is the same
-        group element whichever algorithm sums it, so the one GPU path serves this entry too."""
+        """`msmProjective` (src/parallel.ts:69-87: msmBasic over projective points): signed windows of the whole scalar,
+        no endomorphism split, K = ceil((b + 1) / c) with b = bit length of q (src/msm-basic.ts:56-59).  The bucket sums
+        still come from the batched-affine tree; the value is the same group element either way."""
+        options = dict(options or {})
+        options["noGlv"] = True
         return self.msm(scalarPtr, pointPtr, N, False, options)
 
     def msmUnsafe(self, scalarPtr: ScalarPtr, pointPtr: PointPtr, N: int, verboseTiming: bool = False,

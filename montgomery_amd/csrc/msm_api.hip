@@ -177,6 +177,7 @@ int pick_window(bool te, uint64_t n, int glv_max_bits) {
 struct Plan {
   int c, K, L_log;
   uint32_t L;
+  bool no_glv;
 };
 
 int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
@@ -185,7 +186,10 @@ int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
   int c = (opts && opts->c > 0) ? opts->c : pick_window(te, n, glv_bits);
   if (c < 2 || c > 24) return MSM_ERR_ARG;
   // b = Scalar.maxBits (126 after GLV, src/wasm/glv.ts:216-226) or Scalar.sizeInBits (251, src/msm-basic.ts:56)
-  const int b = te ? 251 : glv_bits;
+  // b = Scalar.maxBits after GLV (src/wasm/glv.ts:216-226), or the bit length of q without it (src/msm-basic.ts:56)
+  pl.no_glv = !te && opts && opts->no_glv;
+  const int b = te ? 251 : pl.no_glv ? curve_info(ctx ? ctx->curve : MSM_CURVE_BLS12_377_G1).q_bits : glv_bits;
+  if (pl.no_glv && c < 4) return MSM_ERR_ARG;   // keeps K <= 64
   pl.c = c;
   pl.K = (b + 1 + c - 1) / c;  // K = ceil((b + 1) / c), src/msm-batched-affine.ts:90, src/msm-basic.ts:59
   pl.L_log = c - 1;
@@ -301,7 +305,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
                          pl.K, k_lo, kc);
     else
       W_LAUNCH(ctx, k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, cnt, d_scalars, (uint32_t)n, pl.c, pl.K,
-                         k_lo, kc);
+                         k_lo, kc, pl.no_glv ? 0 : 1);
   }
   HIPCHK(hipEventRecord(w.ev[1], s));
   if (one_level) {

@@ -180,7 +180,7 @@ MSM_DEV bool words8_ge(const uint32_t (&a)[8], const uint32_t* q) {
 // windows [k_lo, k_lo + k_cnt) of K_total are emitted (window groups / multi-GPU window shards)
 template <class CV>
 __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts, const uint32_t* scalars, uint32_t n,
-                                                int c, int k_total, int k_lo, int k_cnt) {
+                                                int c, int k_total, int k_lo, int k_cnt, int glv) {
   using F = typename CV::F;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -196,10 +196,26 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts,
   // inputs are specified < q (src/curve-random.ts:151-194); larger values are reduced, not rejected
   for (int it = 0; it < 16 && words8_ge(s, q); it++) bn_addsub<8, 8>(s, q, true);
 
-  GlvHalf h[2];
-  glv_decompose<typename CV::G>(h[0], h[1], s);
   const uint32_t L = 1u << (c - 1);
   const uint64_t two_n = 2ull * n;
+  if (!glv) {
+    // msmBasic / msmProjective window structure (src/msm-basic.ts:72-91): signed digits of the whole scalar on the
+    // first entry of the point; the endomorphism entry stays empty (digit 0 is never sorted)
+    uint32_t carry = 0;
+    for (int k = 0; k < k_total; k++) {
+      uint32_t l = bn_bits<8>(s, k * c, c) + carry;
+      if (l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
+      int kk = k - k_lo;
+      if (kk >= 0 && kk < k_cnt) {
+        dig[(uint64_t)kk * two_n + 2ull * i] = l | (carry << 31);
+        dig[(uint64_t)kk * two_n + 2ull * i + 1] = 0u;
+        if (counts && l) atomicAdd(&counts[(uint64_t)kk * L + (l - 1)], 1u);
+      }
+    }
+    return;
+  }
+  GlvHalf h[2];
+  glv_decompose<typename CV::G>(h[0], h[1], s);
 #pragma unroll
   for (int hh = 0; hh < 2; hh++) {
     uint32_t carry = 0;

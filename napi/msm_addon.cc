@@ -86,8 +86,8 @@ static napi_value SetPoints(napi_env env, napi_callback_info info) {  // pointsF
 }
 
 static napi_value Msm(napi_env env, napi_callback_info info) {  // msm / msmUnsafe, src/msm-batched-affine.ts:69-340
-  size_t argc = 4;
-  napi_value argv[4];
+  size_t argc = 5;   // (ctx, scalars, c, coordBytes, noGlv)
+  napi_value argv[5];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   msm_ctx* ctx = get_ctx(env, argv[0]);
   if (!ctx) return NULL;
@@ -103,6 +103,7 @@ static napi_value Msm(napi_env env, napi_callback_info info) {  // msm / msmUnsa
   int32_t coord = 48;
   if (argc > 2) napi_get_value_int32(env, argv[2], &opts.c);
   if (argc > 3) napi_get_value_int32(env, argv[3], &coord);
+  if (argc > 4) napi_get_value_int32(env, argv[4], &opts.no_glv);   // msmProjective, src/parallel.ts:69-87
   msm_result res;
   int rc = msm_run(ctx, data, len / 32, 0, &opts, &res);
   if (rc != MSM_OK) return throw_msm(env, ctx, rc, "msm");

@@ -230,5 +230,7 @@ def test_reference_shaped_api(cv):
     out = par.msmUnsafe(sp, pp, 50, True, {"c": 6})
     assert out["result"].as_tuple() == O.msm_batched_affine(sc, pts, B)
     assert out["log"][0][0]["K"] == 22
-    assert par.msmProjective(sp, pp, 50)["result"].as_tuple() == out["result"].as_tuple()
+    proj = par.msmProjective(sp, pp, 50, {"c": 8})
+    assert proj["result"].as_tuple() == out["result"].as_tuple()
+    assert proj["info"]["K"] == -(-(B.q.bit_length() + 1) // 8)
     mod.context.close()

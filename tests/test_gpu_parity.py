@@ -388,3 +388,27 @@ def test_skewed_buckets_tail_rounds(gpu_ctx, c_oracle):
         for c in (None, 5, 16):
             res, info = gpu_ctx.run(sb, c=c)
             assert res.as_tuple() == ref, (name, c, info)
+
+
+def test_msm_projective_window_structure(gpu_ctx):
+    """`msmProjective` (src/parallel.ts:69-87, src/msm-basic.ts:45-164): windows of the whole 253-bit scalar, no GLV.
+    BASELINE configs[0] shape: N = 2^14, c = 13 -> K = ceil(254 / 13) = 20."""
+    pts, ks = O.random_points_bls377("gpu/proj", 256)
+    G = (C.gx, C.gy)
+    for n, c, K in ((1, 13, 20), (50, 6, 43), (1 << 14, 13, 20), (1 << 14, None, None), (777, 19, 14)):
+        sc = O.prng_ints(f"gpu/proj/{n}/{c}", n, C.q)
+        gpu_ctx.set_points(O.points_to_bytes([pts[i & 255] for i in range(n)], 48))
+        res, info = gpu_ctx.run(O.scalars_to_bytes(sc), c=c, no_glv=True)
+        assert info["K"] == (K or -(-254 // info["c"])), info
+        assert res.as_tuple() == O.aff_scale(sum(s * ks[i & 255] for i, s in enumerate(sc)) % C.q, G, P_MOD), (n, c, info)
+        if n <= 50:
+            assert res.as_tuple() == O.msm_basic_projective(sc, [pts[i & 255] for i in range(n)], C, c=c)
+    # extremes: q - 1 uses the top window, scalars >= q are reduced first
+    for s in (C.q - 1, C.q + 7, (1 << 253) - 1, 1 << 252):
+        gpu_ctx.set_points(enc_pt(pts[3]))
+        res, _ = gpu_ctx.run(O.scalars_to_bytes([s % (1 << 256)]), c=9, no_glv=True)
+        assert res.as_tuple() == O.aff_scale(s % C.q, pts[3], P_MOD), hex(s)
+    from montgomery_amd import MsmError
+
+    with pytest.raises(MsmError):
+        gpu_ctx.run(O.scalars_to_bytes([1]), c=3, no_glv=True)
