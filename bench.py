@@ -181,7 +181,7 @@ def main():
             parts, box["info"] = ctx.window_sums(scal[i].data_ptr(), n, lo, hi, c=c, on_device=True)
             return parts
 
-        out = sharded_msm(my_window_sums, K, c, device=dev if args.dist_backend == "nccl" else "cpu")
+        out = sharded_msm(my_window_sums, K, c, device=dev if args.dist_backend == "nccl" else "cpu", curve=ctx.curve)
         res = None
         if out is not None:
             xy = out[1]

@@ -107,6 +107,8 @@ int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device
 /* S = sum_k 2^(c k) P_k over all K windows, then to affine (src/msm-batched-affine.ts:322-333,
  * src/curve-projective.ts:335-349).  Host arithmetic only: `ctx` may be NULL. */
 int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm_result* out);
+/* The same without a context: `curve` names the constants (Weierstrass curves only).  No GPU is touched. */
+int msm_combine_curve(int curve, const uint8_t* partials, int32_t K, int32_t c, msm_result* out);
 
 /* Window plan for n points: the c the library would pick and the resulting K. */
 int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_out, int32_t* K_out);

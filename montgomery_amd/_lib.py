@@ -25,7 +25,7 @@ OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_INV, OP_TO_MONT, OP_FROM_MONT = range(7)
 # every symbol include/msm_hip.h declares
 EXPORTS = (
     "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_set_points", "msm_run", "msm_window_sums",
-    "msm_combine", "msm_plan", "msm_generate_points", "msm_generate_scalars", "msm_get_points", "msm_test_fp",
+    "msm_combine", "msm_combine_curve", "msm_plan", "msm_generate_points", "msm_generate_scalars", "msm_get_points", "msm_test_fp",
     "msm_test_glv", "msm_test_batch_add", "msm_test_batch_inverse",
 )
 
@@ -77,6 +77,8 @@ def load() -> C.CDLL:
     lib.msm_run.argtypes = [vp, vp, u64, C.c_int, C.POINTER(MsmOpts), C.POINTER(MsmResult)]
     lib.msm_window_sums.argtypes = [vp, vp, u64, C.c_int, C.POINTER(MsmOpts), vp, C.POINTER(MsmResult)]
     lib.msm_combine.argtypes = [vp, vp, i32, i32, C.POINTER(MsmResult)]
+    lib.msm_combine_curve.argtypes = [i32, vp, i32, i32, C.POINTER(MsmResult)]
+    lib.msm_combine_curve.restype = i32
     lib.msm_plan.argtypes = [vp, u64, C.POINTER(MsmOpts), C.POINTER(i32), C.POINTER(i32)]
     lib.msm_generate_points.argtypes = [vp, u64, u64, vp]
     lib.msm_generate_scalars.argtypes = [vp, u64, u64, C.POINTER(vp), vp]

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -960,16 +961,38 @@ int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device
   return MSM_OK;
 }
 
-int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
-  // pure host arithmetic: ctx may be NULL (rank 0 of a sharded run only needs the curve constants)
-  if (!partials || !out || K <= 0 || c <= 0) return fail(ctx, MSM_ERR_ARG, "msm_combine: bad argument");
-  static msm_host::Curve6 hc_static;
-  static bool hc_ready = false;
-  if (!hc_ready) {
-    hc_static.F.init(Fp377::PW);
-    hc_ready = true;
+namespace {
+// host curve constants without a context (rank 0 of a sharded run may combine without touching a GPU)
+const msm_host::Curve6* static_host_curve(int curve) {
+  static msm_host::Curve6 hc[4];
+  static std::atomic<int> ready[4];
+  if (curve < 0 || curve > 3 || curve == MSM_CURVE_ED_ON_BLS12_377) return nullptr;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ready[curve].load()) {
+    hc[curve].F.init(curve_info(curve).pw);
+    ready[curve].store(1);
   }
-  const msm_host::Curve6& C = ctx ? ctx->hc : hc_static;
+  return &hc[curve];
+}
+int combine_impl(msm_ctx* ctx, const msm_host::Curve6& C, const uint8_t* partials, int32_t K, int32_t c, msm_result* out);
+}  // namespace
+
+int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
+  // pure host arithmetic: ctx may be NULL (then BLS12-377 G1; msm_combine_curve names the curve without a context)
+  if (!partials || !out || K <= 0 || c <= 0) return fail(ctx, MSM_ERR_ARG, "msm_combine: bad argument");
+  if (ctx && ctx->is_te()) return fail(ctx, MSM_ERR_ARG, "msm_combine: curve not supported yet");
+  return combine_impl(ctx, ctx ? ctx->hc : *static_host_curve(MSM_CURVE_BLS12_377_G1), partials, K, c, out);
+}
+
+int msm_combine_curve(int curve, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
+  const msm_host::Curve6* C = static_host_curve(curve);
+  if (!C || !partials || !out || K <= 0 || c <= 0) return MSM_ERR_ARG;
+  return combine_impl(nullptr, *C, partials, K, c, out);
+}
+
+namespace {
+int combine_impl(msm_ctx* ctx, const msm_host::Curve6& C, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
   std::vector<msm_host::Proj6> P(K);
   for (int k = 0; k < K; k++) {
     msm_host::Fe6 t[3];
@@ -991,6 +1014,7 @@ int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm
   out->K = K;
   return MSM_OK;
 }
+}  // namespace
 
 int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, msm_result* out) {
   if (!ctx || !out || (!scalars && n)) return fail(ctx, MSM_ERR_ARG, "msm_run: null argument");

@@ -27,14 +27,14 @@ def window_shards(K: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def combine_host(partials: bytes, K: int, c: int) -> Optional[Tuple[int, int]]:
+def combine_host(partials: bytes, K: int, c: int, curve: int = _lib.CURVE_BLS12_377_G1) -> Optional[Tuple[int, int]]:
     """S = sum_k 2^(ck) P_k -> canonical affine (x, y) or None; host arithmetic in libmsm_hip.so, no GPU needed."""
     lib = _lib.load()
     if len(partials) != PARTIAL_BYTES * K:
         raise MsmError(_lib.MSM_ERR_ARG, f"expected {PARTIAL_BYTES * K} bytes of window sums, got {len(partials)}")
     buf = (C.c_uint8 * len(partials)).from_buffer_copy(partials)
     res = MsmResult()
-    rc = lib.msm_combine(None, buf, K, c, C.byref(res))
+    rc = lib.msm_combine_curve(curve, buf, K, c, C.byref(res))
     if rc != _lib.MSM_OK:
         raise MsmError(rc, "msm_combine failed")
     if res.is_infinity:
@@ -42,7 +42,8 @@ def combine_host(partials: bytes, K: int, c: int) -> Optional[Tuple[int, int]]:
     return int.from_bytes(bytes(res.x), "little"), int.from_bytes(bytes(res.y), "little")
 
 
-def sharded_msm(window_sums: Callable[[int, int], bytes], K: int, c: int, device="cpu", group=None) -> Optional[Tuple[bool, Optional[Tuple[int, int]]]]:
+def sharded_msm(window_sums: Callable[[int, int], bytes], K: int, c: int, device="cpu", group=None,
+                curve: int = _lib.CURVE_BLS12_377_G1) -> Optional[Tuple[bool, Optional[Tuple[int, int]]]]:
     """Runs one window-sharded MSM on the current process group.
 
     window_sums(k_lo, k_hi) -> (k_hi - k_lo) * 144 bytes: this rank's partition sums
@@ -68,4 +69,4 @@ def sharded_msm(window_sums: Callable[[int, int], bytes], K: int, c: int, device
     g = gathered.cpu().numpy().tobytes()
     row = PARTIAL_BYTES * K
     allp = b"".join(g[r * row + PARTIAL_BYTES * a : r * row + PARTIAL_BYTES * b] for r, (a, b) in enumerate(shards))
-    return True, combine_host(allp, K, c)
+    return True, combine_host(allp, K, c, curve)

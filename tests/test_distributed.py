@@ -17,11 +17,11 @@ def _free_port():
     return p
 
 
-def _oracle_window_sums(scalars, points, c, K):
+def _oracle_window_sums(scalars, points, c, K, C=None):
     """P_k for every window k as 144-byte (X, Y, Z) records, from the oracle's spec arithmetic."""
     from oracle import msm_oracle as O
 
-    C = O.BLS12_377
+    C = C or O.BLS12_377
     g = O.glv_params(C.q, C.lam)
     sums = [None] * K
     for s, P in zip(scalars, points):
@@ -94,6 +94,25 @@ def test_combine_host_matches_oracle():
         K = -(-127 // c)
         allw = _oracle_window_sums(sc, pts, c, K)
         assert combine_host(b"".join(allw), K, c) == O.msm_batched_affine(sc, pts, c=c)
+
+
+def test_combine_host_other_curves():
+    """`msm_combine_curve`: rank 0 combines for BLS12-381 / Pallas without a context (host arithmetic only)."""
+    from montgomery_amd import _lib
+    from montgomery_amd.distributed import combine_host
+    from oracle import msm_oracle as O
+
+    for cid, B in ((_lib.CURVE_BLS12_381_G1, O.BLS12_381), (_lib.CURVE_PALLAS, O.PALLAS)):
+        pts, _ = O.random_points_bls377(f"dist/combine/{B.label}", 10, B)
+        sc = O.prng_ints(f"dist/combine/{B.label}/s", 10, B.q)
+        for c in (5, 16):
+            K = -(-128 // c)
+            allw = _oracle_window_sums(sc, pts, c, K, B)
+            assert combine_host(b"".join(allw), K, c, curve=cid) == O.msm_batched_affine(sc, pts, B, c=c)
+    from montgomery_amd import MsmError
+
+    with pytest.raises(MsmError):
+        combine_host(b"\0" * 144, 1, 4, curve=_lib.CURVE_ED_ON_BLS12_377)
 
 
 @pytest.mark.timeout(300)
