@@ -211,8 +211,13 @@ struct RoundGeom {
   uint64_t T;
 };
 
-RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out) {
+// gather: round 1 (random row reads: wants two waves per SIMD to cover the latency).  The other rounds read
+// coalesced, prefetched planes; a lone wave already gets ~88 % of a SIMD's issue rate, and every lane pays one field
+// inversion (~19 pair additions' worth) per round, so small rounds run better on half as many lanes with twice the
+// steps (2^18: 2.62 -> 2.45 ms; neutral at 2^20; round 1 at 2^22 would lose 60 %).
+RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather = false) {
   uint64_t target = (uint64_t)ctx->n_cu * 4 * 2 * 64;  // two waves per SIMD
+  if (!gather && n_out < target * 40) target /= 2;
   uint32_t max_steps = 512;
   if (const char* e = getenv("MSM_MAX_STEPS")) max_steps = (uint32_t)std::max(1, atoi(e));       // tuning knobs
   if (const char* e = getenv("MSM_TARGET_WAVES")) target = (uint64_t)ctx->n_cu * 4 * 64 * std::max(1, atoi(e));
@@ -463,7 +468,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   if (total_slots > 0) {
     for (uint32_t r = 1; r <= logG; r++) {
       uint64_t n_out = n_in / 2;
-      RoundGeom g = round_geom(ctx, n_out);
+      RoundGeom g = round_geom(ctx, n_out, r == 1 || te);   // no inversion on the Edwards path: always two waves
       if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * g.T * 4);
       BatchArgs a{};
       a.points = (const uint32_t*)ctx->rows.p;
@@ -496,7 +501,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     }
     for (int r = 1; r <= r_stop; r++) {
       uint64_t n_out = w.h_info[3 + r];
-      RoundGeom g = round_geom(ctx, n_out);
+      RoundGeom g = round_geom(ctx, n_out, te);
       if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * g.T * 4);
       BatchArgs a{};
       a.in = buf[cur ^ 1];
