@@ -11,7 +11,7 @@
   X(msm::k_batch_add<CV MSM_COMMA msm::MODE_GATHER>, (msm::BatchArgs))                                                   \
   X(msm::k_batch_add<CV MSM_COMMA msm::MODE_REGULAR>, (msm::BatchArgs))                                                  \
   X(msm::k_batch_add<CV MSM_COMMA msm::MODE_SEARCH>, (msm::BatchArgs))                                                   \
-  X(msm::k_bucket_finish<CV>, (uint32_t*, const uint4*, uint64_t, const uint32_t*, uint32_t))                            \
+  X(msm::k_bucket_finish<CV>, (uint32_t*, const uint4*, uint64_t, const uint32_t*, uint32_t, const uint32_t*))                     \
   X(msm::k_bucket_reduce<CV>, (uint32_t*, uint32_t*, const uint4*, uint64_t, const uint32_t*, const uint32_t*, uint32_t, \
                                uint32_t, uint32_t, uint32_t))                                                            \
   X(msm::k_window_sum<CV>, (uint32_t*, const uint32_t*, uint32_t))                                                       \

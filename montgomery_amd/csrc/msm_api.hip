@@ -86,13 +86,13 @@ struct msm_ctx {
   // window group runs under the ALU-bound accumulation of the other
   struct Workspace {
     DevBuf dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, columns2, rows_sum, bucket_proj, bufA, bufB,
-        scratch, columns, partials, part, dig2, idx2, block_hist2, blk_tab;
+        scratch, columns, partials, part, dig2, idx2, block_hist2, blk_tab, blk_tab2;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8];
     uint32_t* h_info = nullptr;   // pinned, 64 words
     uint32_t* h_part = nullptr;   // pinned, window sums read-back
-    DevBuf* all[22] = {&dig, &counts, &cursor, &tail_off, &info, &slots, &block_hist, &scan_partial, &desc, &columns2, &rows_sum,
-                       &bucket_proj, &bufA, &bufB, &scratch, &columns, &partials, &part, &dig2, &idx2, &block_hist2, &blk_tab};
+    DevBuf* all[23] = {&dig, &counts, &cursor, &tail_off, &info, &slots, &block_hist, &scan_partial, &desc, &columns2, &rows_sum,
+                       &bucket_proj, &bufA, &bufB, &scratch, &columns, &partials, &part, &dig2, &idx2, &block_hist2, &blk_tab, &blk_tab2};
   };
   static constexpr int N_WS = 2;
   Workspace ws[N_WS];
@@ -534,8 +534,20 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   const uint32_t* bucket_proj = nullptr;
   if (use_finish && total_slots > 0) {
     ctx->ensure(w.bucket_proj, nb * 3 * NL * 4);
+    // lanes of a wave should have equal trip counts: order the buckets by what they still hold
+    const uint32_t* perm = nullptr;
+    if (nb >= 4096) {
+      ctx->ensure(w.blk_tab2, (nb + 2 * FINISH_BINS) * 4);
+      uint32_t* hist = (uint32_t*)w.blk_tab2.p;
+      HIPCHK(hipMemsetAsync(hist, 0, 2 * FINISH_BINS * 4, s));
+      const uint32_t fgrid = (uint32_t)((nb + FINISH_THREADS - 1) / FINISH_THREADS);
+      hipLaunchKernelGGL(k_finish_hist, dim3(fgrid), dim3(FINISH_THREADS), 0, s, off_fin, (uint32_t)nb, hist);
+      hipLaunchKernelGGL(k_finish_perm, dim3(fgrid), dim3(FINISH_THREADS), 0, s, off_fin, (uint32_t)nb,
+                         (const uint32_t*)hist, hist + FINISH_BINS, hist + 2 * FINISH_BINS);
+      perm = hist + 2 * FINISH_BINS;
+    }
     W_LAUNCH(ctx, k_bucket_finish, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.bucket_proj.p, fin,
-                       fin_cap, off_fin, (uint32_t)nb);
+                       fin_cap, off_fin, (uint32_t)nb, perm);
     bucket_proj = (const uint32_t*)w.bucket_proj.p;
   }
   if (total_slots == 0) HIPCHK(hipEventRecord(w.ev[6], s));

@@ -561,10 +561,11 @@ MSM_DEV void proj_load_planar(Proj<F>& P, const uint32_t* base, uint64_t stride,
 
 template <class CV>
 __global__ void __launch_bounds__(256) k_bucket_finish(uint32_t* bucket_proj, const uint4* in, uint64_t in_cap,
-                                                       const uint32_t* off, uint32_t nb) {
+                                                       const uint32_t* off, uint32_t nb, const uint32_t* perm) {
   using F = typename CV::F;
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
+  if (perm) b = perm[b];   // buckets ordered by remaining count (k_finish_perm): equal trip counts inside a wave
   const uint32_t o0 = off[b], o1 = off[b + 1];
   Proj<F> acc;
   proj_set_zero<F>(acc);

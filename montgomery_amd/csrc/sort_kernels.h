@@ -374,4 +374,51 @@ __global__ void __launch_bounds__(SORT_THREADS) k_scatter_coarse(uint32_t* dig2,
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// k_finish_hist / k_finish_perm: order the buckets by the number of elements they still hold when the tree stops,
+// largest first, so that the 64 lanes of a k_bucket_finish wave run the same number of additions (a wave costs its
+// longest lane: with counts of 3..7 in natural order that is ~1.5x the mean).  Counting sort over <= 64 distinct
+// counts, block-private in LDS: one global atomic per distinct count per 1024 buckets.
+// ---------------------------------------------------------------------------------------------
+
+constexpr int FINISH_BINS = 64;
+
+MSM_DEV uint32_t finish_bin(const uint32_t* off, uint32_t b) {
+  uint32_t c = off[b + 1] - off[b];
+  return c < FINISH_BINS ? c : FINISH_BINS - 1;
+}
+
+constexpr int FINISH_THREADS = 1024;
+
+__global__ void __launch_bounds__(FINISH_THREADS) k_finish_hist(const uint32_t* off, uint32_t nb, uint32_t* hist) {
+  __shared__ uint32_t lh[FINISH_BINS];
+  if (threadIdx.x < FINISH_BINS) lh[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) atomicAdd(&lh[finish_bin(off, b)], 1u);
+  __syncthreads();
+  if (threadIdx.x < FINISH_BINS && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+// cursor: FINISH_BINS zeroed words; perm[j] = j-th bucket in descending order of count
+__global__ void __launch_bounds__(FINISH_THREADS) k_finish_perm(const uint32_t* off, uint32_t nb, const uint32_t* hist,
+                                                                uint32_t* cursor, uint32_t* perm) {
+  __shared__ uint32_t lcnt[FINISH_BINS], lbase[FINISH_BINS];
+  if (threadIdx.x < FINISH_BINS) lcnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = b < nb;
+  const uint32_t key = active ? finish_bin(off, b) : 0u;
+  uint32_t rank = 0;
+  if (active) rank = atomicAdd(&lcnt[key], 1u);
+  __syncthreads();
+  if (threadIdx.x < FINISH_BINS && lcnt[threadIdx.x]) {
+    uint32_t base = 0;
+    for (uint32_t k = FINISH_BINS - 1; k > threadIdx.x; k--) base += hist[k];   // larger counts first
+    lbase[threadIdx.x] = base + atomicAdd(&cursor[threadIdx.x], lcnt[threadIdx.x]);
+  }
+  __syncthreads();
+  if (active) perm[lbase[key] + rank] = b;
+}
+
 }  // namespace msm

@@ -22,7 +22,8 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   struct { const char* name; uint64_t m; } masks[] = {
       {"all 64 lanes", ~0ull}, {"lanes 0-62", ~0ull >> 1}, {"lanes 0-59", ~0ull >> 4}, {"lanes 0-47", ~0ull >> 16}, {"lanes 0-31", ~0ull >> 32},
-      {"lanes 0-15", 0xFFFFull}, {"lane 0", 1ull}, {"even lanes", 0x5555555555555555ull}, {"lanes 32-63", ~0ull << 32}, {"all but lane 5", ~(1ull << 5)}};
+      {"lanes 0-15", 0xFFFFull}, {"lanes 0-7", 0xFFull}, {"lanes 0-3", 0xFull}, {"lanes 0-1", 3ull}, {"lane 0", 1ull}, {"lane 63", 1ull << 63},
+      {"lanes 0,16,32,48", 0x0001000100010001ull}, {"even lanes", 0x5555555555555555ull}, {"lanes 32-63", ~0ull << 32}, {"all but lane 5", ~(1ull << 5)}};
   for (int waves : {256, 832, 2048})
     for (auto& mk : masks) {
       float ms = 0;
