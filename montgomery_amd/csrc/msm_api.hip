@@ -428,7 +428,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   // accumulation tree
   // Weierstrass: tail rounds run only until no bucket holds more than FINISH_MAX elements; k_bucket_finish ends it
   const uint32_t FINISH_MAX = 32;
-  const bool use_finish = !te;
+  const bool use_finish = true;
   int r_stop = RT;
   if (use_finish) {
     // a tail round is worth its launch + inversion latency (~0.25 ms) only while it still has a few million pairs;
@@ -533,7 +533,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   st.rounds = round;
   const uint32_t* bucket_proj = nullptr;
   if (use_finish && total_slots > 0) {
-    ctx->ensure(w.bucket_proj, nb * 3 * NL * 4);
+    ctx->ensure(w.bucket_proj, nb * (te ? 4 * te::TL : 3 * NL) * 4);
     // lanes of a wave should have equal trip counts: order the buckets by what they still hold
     const uint32_t* perm = nullptr;
     if (nb >= 4096) {
@@ -546,8 +546,12 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
                          (const uint32_t*)hist, hist + FINISH_BINS, hist + 2 * FINISH_BINS);
       perm = hist + 2 * FINISH_BINS;
     }
-    W_LAUNCH(ctx, k_bucket_finish, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.bucket_proj.p, fin,
-                       fin_cap, off_fin, (uint32_t)nb, perm);
+    if (te)
+      hipLaunchKernelGGL(te::k_te_bucket_finish, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.bucket_proj.p,
+                         fin, fin_cap, off_fin, (uint32_t)nb, perm);
+    else
+      W_LAUNCH(ctx, k_bucket_finish, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.bucket_proj.p, fin,
+                         fin_cap, off_fin, (uint32_t)nb, perm);
     bucket_proj = (const uint32_t*)w.bucket_proj.p;
   }
   if (total_slots == 0) HIPCHK(hipEventRecord(w.ev[6], s));
@@ -569,7 +573,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     uint32_t threads = nchunks * (uint32_t)kc;
     if (te) {
       hipLaunchKernelGGL(te::k_te_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, fin, fin_cap,
-                         off_fin, L, TC, nchunks, (uint32_t)kc);
+                         off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
       hipLaunchKernelGGL(te::k_te_window_sum, dim3(kc), dim3(te::TE_WS_THREADS), 0, s, (uint32_t*)w.partials.p,
                          (const uint32_t*)w.columns.p, nchunks);
     } else if (bit_sliced) {

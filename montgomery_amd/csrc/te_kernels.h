@@ -303,8 +303,29 @@ MSM_DEV void ext_load_raw(Ext& P, const uint32_t* src) {
   for (int l = 0; l < TL; l++) { P.X.l[l] = src[l]; P.Y.l[l] = src[TL + l]; P.Z.l[l] = src[2 * TL + l]; P.T.l[l] = src[3 * TL + l]; }
 }
 
+// k_te_bucket_finish: the unified addition needs no inversion, so the tree exists only for parallelism; once every
+// bucket is down to a few elements one lane per bucket sums them in sequence (replaces ~5 latency-bound tail rounds).
+// perm: buckets in descending order of remaining count (k_finish_perm), so a wave's lanes finish together.
+__global__ void __launch_bounds__(256) k_te_bucket_finish(uint32_t* bucket_ext, const uint4* in, uint64_t in_cap, const uint32_t* off,
+                                                          uint32_t nb, const uint32_t* perm) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  if (perm) b = perm[b];
+  const uint32_t o0 = off[b], o1 = off[b + 1];
+  Ext acc;
+  te_set_identity(acc);
+#pragma unroll 1
+  for (uint32_t o = o0; o < o1; o++) {
+    Ext Q;
+    load_ext(Q, in, in_cap, o);
+    te_add(acc, acc, Q);
+  }
+  ext_store_raw(bucket_ext + (uint64_t)b * (4 * TL), acc);
+}
+
 __global__ void __launch_bounds__(64) k_te_bucket_reduce(uint32_t* columns, const uint4* fin, uint64_t fin_cap, const uint32_t* off_fin,
-                                                          uint32_t L, uint32_t TC, uint32_t nchunks, uint32_t k_cnt) {
+                                                          const uint32_t* bucket_ext, uint32_t L, uint32_t TC, uint32_t nchunks,
+                                                          uint32_t k_cnt) {
   uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= nchunks * k_cnt) return;
   uint32_t kk = id / nchunks, ch = id - kk * nchunks;
@@ -316,11 +337,17 @@ __global__ void __launch_bounds__(64) k_te_bucket_reduce(uint32_t* columns, cons
 #pragma unroll 1
   for (uint32_t l = lend; l >= lstart; l--) {
     uint64_t b = (uint64_t)kk * L + (l - 1);
-    uint32_t o0 = off_fin[b], o1 = off_fin[b + 1];
-    if (o1 > o0) {
+    if (bucket_ext) {   // bucket sums from k_te_bucket_finish (the identity for an empty bucket)
       Ext Q;
-      load_ext(Q, fin, fin_cap, o0);
+      ext_load_raw(Q, bucket_ext + b * (4 * TL));
       te_add(row, row, Q);
+    } else {
+      uint32_t o0 = off_fin[b], o1 = off_fin[b + 1];
+      if (o1 > o0) {
+        Ext Q;
+        load_ext(Q, fin, fin_cap, o0);
+        te_add(row, row, Q);
+      }
     }
     te_add(tri, tri, row);
   }
