@@ -179,6 +179,7 @@ struct Plan {
   int c, K, L_log;
   uint32_t L;
   bool no_glv;
+  bool lone = false;   // one window, one group: nothing else shares the GPU (see round_geom)
 };
 
 int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
@@ -215,10 +216,14 @@ struct RoundGeom {
 // coalesced, prefetched planes; a lone wave already gets ~88 % of a SIMD's issue rate, and every lane pays one field
 // inversion (~19 pair additions' worth) per round, so small rounds run better on half as many lanes with twice the
 // steps (2^18: 2.62 -> 2.45 ms; neutral at 2^20; round 1 at 2^22 would lose 60 %).
-RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather = false) {
+// lone: the launch has the GPU to itself (a window group of one window with no second group beside it -- the
+// 8-GPU shard).  All waves of one resident batch then move through the memory-heavy forward sweep and the ALU-heavy
+// backward sweep in step; four batches of 128 steps instead of one of 512 stagger the phases (2^26, one window:
+// 31.5 -> 29.2 ms).  With two groups on two streams the other stream already fills the gaps and 512 is better.
+RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather = false, bool lone = false) {
   uint64_t target = (uint64_t)ctx->n_cu * 4 * 2 * 64;  // two waves per SIMD
   if (!gather && n_out < target * 40) target /= 2;
-  uint32_t max_steps = 512;
+  uint32_t max_steps = (lone && n_out >= target * 512) ? 128 : 512;
   if (const char* e = getenv("MSM_MAX_STEPS")) max_steps = (uint32_t)std::max(1, atoi(e));       // tuning knobs
   if (const char* e = getenv("MSM_TARGET_WAVES")) target = (uint64_t)ctx->n_cu * 4 * 64 * std::max(1, atoi(e));
   uint64_t steps = (n_out + target - 1) / target;
@@ -253,6 +258,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
                       int k_hi, uint32_t* h_partials_out, GroupStats& st) {
   hipStream_t s = w.stream;
   const int kc = k_hi - k_lo;
+  const bool lone = pl.lone;
   const uint32_t L = pl.L;
   const uint64_t nb = (uint64_t)kc * L;
   const bool te = ctx->is_te();
@@ -468,7 +474,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   if (total_slots > 0) {
     for (uint32_t r = 1; r <= logG; r++) {
       uint64_t n_out = n_in / 2;
-      RoundGeom g = round_geom(ctx, n_out, r == 1 || te);   // no inversion on the Edwards path: always two waves
+      RoundGeom g = round_geom(ctx, n_out, r == 1 || te, lone);   // no inversion on the Edwards path: always two waves
       if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * g.T * 4);
       BatchArgs a{};
       a.points = (const uint32_t*)ctx->rows.p;
@@ -770,7 +776,9 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
         if (gi >= (int)groups.size()) break;
         const int ka = groups[gi].first, kb = groups[gi].second;
         std::vector<uint32_t> part((size_t)(kb - ka) * pw);
-        run_window_group(ctx, ctx->ws[slot], d_scal, n, pl, ka, kb, part.data(), sts[slot]);
+        Plan pg = pl;
+        pg.lone = groups.size() == 1 && kb - ka == 1;
+        run_window_group(ctx, ctx->ws[slot], d_scal, n, pg, ka, kb, part.data(), sts[slot]);
         memcpy(&words[(size_t)(ka - k_lo) * pw], part.data(), part.size() * 4);
       }
     } catch (const HipFail& f) {
