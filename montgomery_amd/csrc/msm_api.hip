@@ -252,11 +252,28 @@ msm_host::Proj6 partial_to_host(const msm_ctx* ctx, const uint32_t* w) {
   return P;
 }
 
-// Partition sums P_k for windows [k_lo, k_hi) -> w.h_part[(k - k_lo) * 36 ...]
+// host projective point -> the packed device-Montgomery form the pipeline carries (x 2^6: 2^384 -> 2^390)
+void host_to_partial(const msm_ctx* ctx, const msm_host::Proj6& P, uint32_t* out36) {
+  const auto& C = ctx->hc;
+  const msm_host::Fe6* co[3] = {&P.X, &P.Y, &P.Z};
+  for (int j = 0; j < 3; j++) {
+    msm_host::Fe6 t = *co[j];
+    for (int d = 0; d < 6; d++) C.F.add(t, t, t);
+    msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
+    C.F.mul(t, t, one);
+    for (int q = 0; q < 6; q++) {
+      out36[12 * j + 2 * q] = (uint32_t)t.v[q];
+      out36[12 * j + 2 * q + 1] = (uint32_t)(t.v[q] >> 32);
+    }
+  }
+}
+
+// Partition sums P_k for windows [k_lo, k_hi) over the points [p_lo, p_lo + n) -> w.h_part[(k - k_lo) * 36 ...]
 // scalars: device pointer, n x 8 words.
-void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars, uint64_t n, const Plan& pl, int k_lo,
-                      int k_hi, uint32_t* h_partials_out, GroupStats& st) {
+void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars_all, uint64_t p_lo, uint64_t n, const Plan& pl,
+                      int k_lo, int k_hi, uint32_t* h_partials_out, GroupStats& st) {
   hipStream_t s = w.stream;
+  const uint32_t* d_scalars = d_scalars_all + p_lo * 8;
   const int kc = k_hi - k_lo;
   const bool lone = pl.lone;
   const uint32_t L = pl.L;
@@ -477,7 +494,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       RoundGeom g = round_geom(ctx, n_out, r == 1 || te, lone);   // no inversion on the Edwards path: always two waves
       if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * g.T * 4);
       BatchArgs a{};
-      a.points = (const uint32_t*)ctx->rows.p;
+      a.points = (const uint32_t*)ctx->rows.p + p_lo * (te ? (uint64_t)te::TE_ROW_WORDS : (uint64_t)ROW_WORDS);
       a.slots = (const uint32_t*)w.slots.p;
       a.in = buf[cur ^ 1];
       a.in_cap = cap[cur ^ 1];
@@ -632,18 +649,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       }
       for (uint32_t t = TC; t > 1; t >>= 1) acc = C.dbl(acc);   // TC is a power of two on this path
       acc = C.add(acc, partial_to_host(ctx, base + (size_t)nbits * 36));
-      // back to the packed device-Montgomery form the rest of the pipeline carries (x 2^6: 2^384 -> 2^390)
-      msm_host::Fe6* co[3] = {&acc.X, &acc.Y, &acc.Z};
-      for (int j = 0; j < 3; j++) {
-        msm_host::Fe6 t = *co[j];
-        for (int d = 0; d < 6; d++) C.F.add(t, t, t);
-        msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
-        C.F.mul(t, t, one);
-        for (int q = 0; q < 6; q++) {
-          h_partials_out[(size_t)kk * 36 + 12 * j + 2 * q] = (uint32_t)t.v[q];
-          h_partials_out[(size_t)kk * 36 + 12 * j + 2 * q + 1] = (uint32_t)(t.v[q] >> 32);
-        }
-      }
+      host_to_partial(ctx, acc, h_partials_out + (size_t)kk * 36);
     }
     float ms;
     HIPCHK(hipEventElapsedTime(&ms, w.ev[0], w.ev[1])); st.ms_digits += ms;
@@ -761,8 +767,22 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   int want_groups = (nwin >= 2 && n >= (1ull << 23)) ? 2 : 1;
   if (const char* e = getenv("MSM_GROUPS")) want_groups = std::max(1, atoi(e));
   wpg = std::max(1, std::min(wpg, (nwin + want_groups - 1) / want_groups));
-  std::vector<std::pair<int, int>> groups;
-  for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg)});
+  struct Group {
+    int ka, kb;
+    uint64_t p_lo, p_n;
+  };
+  std::vector<Group> groups;
+  // A single window (the 8-GPU shard) has no second window group to hide its sort and tails under: split it by
+  // points instead -- two half-size sub-MSMs of the same window on the two streams, their sums added on the host.
+  const bool split_points = nwin == 1 && want_groups == 1 && !ctx->is_te() && n >= (1ull << 24) && !getenv("MSM_GROUPS");
+  if (split_points) {
+    const uint64_t h = n / 2;
+    groups.push_back({k_lo, k_hi, 0, h});
+    groups.push_back({k_lo, k_hi, h, n - h});
+  } else {
+    for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg), 0, n});
+  }
+  std::vector<uint32_t> split_part[2];
   HIPCHK(hipStreamSynchronize(ctx->stream));   // staged scalars are in place before the group streams start
   std::atomic<int> next{0};
   GroupStats sts[msm_ctx::N_WS];
@@ -774,12 +794,13 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       for (;;) {
         int gi = next.fetch_add(1);
         if (gi >= (int)groups.size()) break;
-        const int ka = groups[gi].first, kb = groups[gi].second;
+        const int ka = groups[gi].ka, kb = groups[gi].kb;
         std::vector<uint32_t> part((size_t)(kb - ka) * pw);
         Plan pg = pl;
         pg.lone = groups.size() == 1 && kb - ka == 1;
-        run_window_group(ctx, ctx->ws[slot], d_scal, n, pg, ka, kb, part.data(), sts[slot]);
-        memcpy(&words[(size_t)(ka - k_lo) * pw], part.data(), part.size() * 4);
+        run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, part.data(), sts[slot]);
+        if (split_points) split_part[gi] = part;
+        else memcpy(&words[(size_t)(ka - k_lo) * pw], part.data(), part.size() * 4);
       }
     } catch (const HipFail& f) {
       fails[slot] = f;
@@ -794,8 +815,13 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     worker(0);
     t1.join();
   }
-  for (int i = 0; i < msm_ctx::N_WS; i++) {
+  for (int i = 0; i < msm_ctx::N_WS; i++)
     if (failed[i]) throw fails[i];
+  if (split_points) {
+    const msm_host::Proj6 sum = ctx->hc.add(partial_to_host(ctx, split_part[0].data()), partial_to_host(ctx, split_part[1].data()));
+    host_to_partial(ctx, sum, words.data());
+  }
+  for (int i = 0; i < msm_ctx::N_WS; i++) {
     st.n_pairs += sts[i].n_pairs;
     st.max_bucket = std::max(st.max_bucket, sts[i].max_bucket);
     st.rounds = std::max(st.rounds, sts[i].rounds);

@@ -412,3 +412,18 @@ def test_msm_projective_window_structure(gpu_ctx):
 
     with pytest.raises(MsmError):
         gpu_ctx.run(O.scalars_to_bytes([1]), c=3, no_glv=True)
+
+
+def test_single_window_shards_split_by_points(gpu_ctx):
+    """A shard of ONE window at n >= 2^24 (the 8-GPU case) runs as two half-size sub-MSMs over the point halves,
+    added on the host: all K one-window shards must still combine to the full MSM."""
+    n = 1 << 24
+    gpu_ctx.generate_points(n, seed=77)
+    dev, _ = gpu_ctx.generate_scalars(n, seed=78)
+    full, info = gpu_ctx.run_device(dev, n, c=16)
+    K = info["K"]
+    parts = b"".join(gpu_ctx.window_sums(dev, n, k, k + 1, c=16, on_device=True)[0] for k in range(K))
+    assert gpu_ctx.combine(parts, K, 16).as_tuple() == full.as_tuple()
+    # two-window shards (4-GPU case) take the ordinary path
+    parts2 = b"".join(gpu_ctx.window_sums(dev, n, k, k + 2, c=16, on_device=True)[0] for k in range(0, K, 2))
+    assert parts2 == parts or gpu_ctx.combine(parts2, K, 16).as_tuple() == full.as_tuple()
