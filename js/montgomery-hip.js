@@ -62,6 +62,14 @@ function createCurve(params, curveId, coordBytes, device, wireBytes) {
       scalarPtr.bytes = Buffer.from(Buffer.from(input.buffer, input.byteOffset, n * 32));
       scalarPtr.n = n;
     },
+    async randomPointsFast(n, options) {   // src/curve-random.ts:14-92; generated on the GPU, explicit seed
+      const pointPtr = { size: n * 2 * wireBytes, n: 0 };
+      pointPtr.n = hip.generatePoints(ctx, n, (options && options.seed) || 1);
+      return pointPtr;
+    },
+    async randomScalars(n, options) {      // src/curve-random.ts:151-194
+      return { size: n * 32, bytes: hip.generateScalars(ctx, n, (options && options.seed) || 1), n };
+    },
     async msm(scalarPtr, pointPtr, N, verboseTiming, options) {
       const c = (options && options.c) || 0;
       const r = hip.msm(ctx, scalarPtr.bytes.slice(0, 32 * N), c, coordBytes, options && options.noGlv ? 1 : 0);

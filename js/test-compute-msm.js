@@ -60,6 +60,35 @@ async function main() {
   }
   console.log("ed-on-bls12-377 ok");
   ed.close();
+
+  // --- the other Weierstrass curves of src/msm.test.ts:29-31 through their golden vectors (48-byte coordinates in the
+  //     fixture; Pallas takes 32-byte coordinates on the wire, src/concrete/pasta.params.ts:17)
+  for (const [params, file, wire] of [[M.bls12381Params, "bls381.json", 48], [M.pallasParams, "pallas.json", 32]]) {
+    const cv = M.Weierstrass.create(params);
+    const g = JSON.parse(fs.readFileSync(path.join(__dirname, "..", "tests", "golden", file), "utf8"));
+    for (const c of g.msm) {
+      const full = Buffer.from(c.points, "hex"), sc = Buffer.from(c.scalars, "hex");
+      const pts = Buffer.alloc(c.n * 2 * wire);
+      for (let i = 0; i < 2 * c.n; i++) full.copy(pts, i * wire, i * 48, i * 48 + wire);
+      const pp = cv.Parallel.getPointer(pts.length), sp = cv.Parallel.getScalarPointer(sc.length);
+      await cv.Parallel.pointsFromBytes(pp, pts, c.n);
+      await cv.Parallel.scalarsFromBytes(sp, sc, c.n);
+      const a = (await cv.Parallel.msm(sp, pp, c.n, false, { c: c.c || 0 })).result;
+      const b = (await cv.Parallel.msmProjective(sp, pp, c.n, { c: 8 })).result;   // src/parallel.ts:69-87
+      for (const res of [a, b]) {
+        if (c.result === null) assert(res.isZero, params.label + " " + c.name + " should be the identity");
+        else assert(!res.isZero && res.x === BigInt(c.result[0]) && res.y === BigInt(c.result[1]), params.label + " golden " + c.name);
+      }
+    }
+    // randomPointsFast / randomScalars (src/curve-random.ts), as src/msm.test.ts:49-50 uses them: msm == msmProjective
+    const n = 1 << 12;
+    const rp = await cv.Parallel.randomPointsFast(n, { seed: 5 }), rs = await cv.Parallel.randomScalars(n, { seed: 6 });
+    assert(rp.n === n && rs.bytes.length === 32 * n, "generators");
+    const m1 = (await cv.Parallel.msmUnsafe(rs, rp, n)).result, m2 = (await cv.Parallel.msmProjective(rs, rp, n)).result;
+    assert(!m1.isZero && m1.x === m2.x && m1.y === m2.y, params.label + ": msm == msmProjective on generated inputs");
+    console.log(params.label, "ok:", g.msm.length, "golden cases + generated 2^12");
+    cv.close();
+  }
   console.log("ALL OK");
 }
 main().catch((e) => { console.error(e); process.exit(1); });

@@ -8,7 +8,7 @@
 //
 // Exports: createContext(curve, device) -> external handle, destroyContext(h), setPoints(h, Buffer, check),
 //          msm(h, Buffer scalars, c) -> {x: Buffer, y: Buffer, isZero, c, K, phaseMs: Float64Array(8)},
-//          plan(h, n, c) -> {c, K}, lastError(h)
+//          plan(h, n, c) -> {c, K}, generatePoints(h, n, seed) -> n, generateScalars(h, n, seed) -> Buffer
 #include <node_api.h>
 #include <stdio.h>
 #include <string.h>
@@ -151,9 +151,46 @@ static napi_value Plan(napi_env env, napi_callback_info info) {  // windowSize, 
   return out;
 }
 
+// randomPointsFast, src/curve-random.ts:14-92: n resident points generated on the GPU
+static napi_value GeneratePoints(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  msm_ctx* ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  uint32_t n = 0, seed = 1;
+  napi_get_value_uint32(env, argv[1], &n);
+  if (argc > 2) napi_get_value_uint32(env, argv[2], &seed);
+  int rc = msm_generate_points(ctx, n, seed, NULL);
+  if (rc != MSM_OK) return throw_msm(env, ctx, rc, "generatePoints");
+  napi_value out;
+  NAPI_OK(napi_create_uint32(env, n, &out));
+  return out;
+}
+
+// randomScalars, src/curve-random.ts:151-194: n uniform scalars < q, returned as n x 32 little-endian bytes
+static napi_value GenerateScalars(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  msm_ctx* ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  uint32_t n = 0, seed = 1;
+  napi_get_value_uint32(env, argv[1], &n);
+  if (argc > 2) napi_get_value_uint32(env, argv[2], &seed);
+  void* data = NULL;
+  napi_value buf;
+  NAPI_OK(napi_create_buffer(env, (size_t)n * 32, &data, &buf));
+  void* dev = NULL;
+  int rc = msm_generate_scalars(ctx, n, seed, &dev, (uint8_t*)data);
+  if (rc != MSM_OK) return throw_msm(env, ctx, rc, "generateScalars");
+  return buf;
+}
+
 NAPI_MODULE_INIT() {
   struct { const char* name; napi_callback fn; } fns[] = {
-      {"createContext", CreateContext}, {"destroyContext", DestroyContext}, {"setPoints", SetPoints}, {"msm", Msm}, {"plan", Plan}};
+      {"createContext", CreateContext}, {"destroyContext", DestroyContext}, {"setPoints", SetPoints}, {"msm", Msm}, {"plan", Plan},
+      {"generatePoints", GeneratePoints}, {"generateScalars", GenerateScalars}};
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;
     if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
