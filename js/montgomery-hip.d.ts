@@ -1,0 +1,53 @@
+// Type declarations of js/montgomery-hip.js in the vocabulary of the reference's TypeScript sources
+// (src/parallel.ts:135-160, 251-289; scripts/zprize23/submission-bls377.ts:20-23).
+export type CurveParams = { label: string; modulus: bigint; order: bigint };
+
+export type PointPtr = { size: number; n: number };
+export type ScalarPtr = { size: number; bytes: Buffer | null; n: number };
+
+/** canonical affine result: what `Affine.toBigint(Projective.toAffine(result))` yields in the reference */
+export type AffineResult = { x: bigint; y: bigint; isZero: boolean };
+export type MsmOptions = { c?: number; useSafeAdditions?: boolean; noGlv?: boolean };
+export type MsmOutput = { result: AffineResult; log: unknown[][] };
+
+export interface Parallel {
+  getPointer(size: number): PointPtr;
+  getScalarPointer(size: number): ScalarPtr;
+  /** src/parallel.ts:97-116 (Weierstrass: x || y, packed field size each) / :215-229 (twisted Edwards) */
+  pointsFromBytes(pointPtr: PointPtr, input: Uint8Array, n: number): Promise<void>;
+  /** src/parallel.ts:119-133: n x 32 bytes little-endian */
+  scalarsFromBytes(scalarPtr: ScalarPtr, input: Uint8Array, n: number): Promise<void>;
+  /** src/curve-random.ts:14-92, generated on the GPU (explicit seed; the reference is unseeded) */
+  randomPointsFast(n: number, options?: { seed?: number }): Promise<PointPtr>;
+  /** src/curve-random.ts:151-194 */
+  randomScalars(n: number, options?: { seed?: number }): Promise<ScalarPtr>;
+  /** src/msm-batched-affine.ts:69-340 */
+  msm(scalarPtr: ScalarPtr, pointPtr: PointPtr, N: number, verboseTiming?: boolean, options?: MsmOptions): Promise<MsmOutput>;
+  /** src/msm-batched-affine.ts:587-598 (the GPU kernels always handle the edge cases) */
+  msmUnsafe(scalarPtr: ScalarPtr, pointPtr: PointPtr, N: number, verboseTiming?: boolean, options?: MsmOptions): Promise<MsmOutput>;
+  /** src/parallel.ts:69-87: window structure of msmBasic, no endomorphism split */
+  msmProjective(scalarPtr: ScalarPtr, pointPtr: PointPtr, N: number, options?: MsmOptions): Promise<MsmOutput>;
+}
+
+export interface Curve {
+  params: CurveParams;
+  Parallel: Parallel;
+  close(): void;
+}
+
+export const Weierstrass: { create(params: CurveParams, device?: number): Curve };
+export const TwistedEdwards: { create(params: CurveParams, device?: number): Curve };
+export const bls12377Params: CurveParams;
+export const bls12381Params: CurveParams;
+export const pallasParams: CurveParams;
+export const edOnBls12377Params: CurveParams;
+
+/** scripts/zprize23/submission-bls377.ts:20-65, submission.ts:19-60 */
+export function compute_msm(
+  curve: Curve,
+  coordBytes: number,
+  inputPoints: { x: bigint; y: bigint; isZero?: boolean }[] | Uint8Array,
+  inputScalars: bigint[] | Uint8Array
+): Promise<{ x: bigint; y: bigint }>;
+export function leBytesToBigint(buf: Uint8Array): bigint;
+export function bigintToLeBytes(x: bigint, n: number): Buffer;
