@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 PAIR_ALGO_BYTES = 288
 # 32x32->64 multiply-adds of one pair addition: 5 multiplications (325 each) + 1 squaring (247), 13 x 30-bit limbs
 PAIR_MADS = 5 * 325 + 247
+SORT_ALGO_BYTES = 12   # per (entry, window): digit read by k_hist, digit read by k_scatter_lds, payload write
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 INT_MAD_PEAK = 30.3e12         # v_mad_u64_u32 lane-ops/s measured on MI355X by tools/ubench_int.hip (profiles/r01_ubench_int.txt)
 # HBM bytes per pair addition of the regular tree rounds from the PMC passes committed in profiles/r01_pmc_2p24.json
@@ -228,6 +229,20 @@ def main():
                 "frac": xi["n_pairs"] * PAIR_ALGO_BYTES / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "int_mad_frac": xi["n_pairs"] * PAIR_MADS / (x_ms * 1e-3) / INT_MAD_PEAK,
                 "phase_ms": xi["phase_ms"],
+                # the counting sort (histogram + scans + scatter): 2 N K entries, each read twice as a 4-byte digit and
+                # written once as a 4-byte payload to a random slot of its bucket
+                "scatter": {
+                    "bound": "hbm",
+                    "algorithmic_bytes_per_entry": SORT_ALGO_BYTES,
+                    "entries": 2 * n * K,
+                    "ms": xi["phase_ms"]["sort"],
+                    "achieved": 2 * n * K * SORT_ALGO_BYTES / (xi["phase_ms"]["sort"] * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s",
+                    "frac": 2 * n * K * SORT_ALGO_BYTES / (xi["phase_ms"]["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "random 4-byte stores: every payload write dirties its own 64-byte sector, so the algorithmic "
+                            "rate understates the sectors moved; hidden under the accumulation of the other window group",
+                },
             }
         out = {
             "metric": f"{'BLS12-381' if is381 else 'BLS12-377'} G1 MSM throughput",
