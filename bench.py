@@ -62,27 +62,19 @@ def cpu_baseline(ctx, log2n_sample, seed):
 
 
 def bench_ed377(args, torch):
-    """BASELINE configs[3]: 2^20 Ed-on-BLS12-377 MSM (msmBasic path) on one GPU.  Points: 1024 valid subgroup
-    points tiled to N (the unified addition has no exceptional cases, repeats are harmless); scalars: fresh
-    250-bit values per step, resident in HBM."""
-    import numpy as np
-
+    """BASELINE configs[3]: 2^20 Ed-on-BLS12-377 MSM (msmBasic path) on one GPU.  Points: N distinct subgroup points
+    P_i = a_i G generated on the GPU (resident); scalars: uniform < q, fresh per step, resident in HBM."""
     from montgomery_amd import _lib
     from montgomery_amd.api import MsmContext
-    from oracle import msm_oracle as O   # input generation only (1024 base points)
 
     n = 1 << args.log2n
     ctx = MsmContext(_lib.CURVE_ED_ON_BLS12_377, device=0)
-    base, _ = O.random_points_ed377("bench/ed", 1024)
-    ctx.set_points(O.points_to_bytes(base, 32) * (n // 1024), check_curve=True)
+    ctx.generate_points(n, seed=20261002)
     c, K = ctx.plan(n, args.c or None)
     dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(7)
-    scal = []
-    for _ in range(args.steps + args.warmup):
-        a = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
-        a[:, 31] &= 0x03   # < 2^250 < q
-        scal.append(torch.from_numpy(a.reshape(-1)).to(dev))
+    scal = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(args.steps + args.warmup)]
+    for i, t in enumerate(scal):
+        ctx.generate_scalars(n, seed=1000 + i, into=t.data_ptr())
     torch.cuda.synchronize()
     for i in range(args.warmup):
         ctx.run_device(scal[i].data_ptr(), n, c=c)

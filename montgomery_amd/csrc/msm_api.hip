@@ -1287,9 +1287,9 @@ int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t
 
 int msm_generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
   if (!ctx) return MSM_ERR_ARG;
-  if (ctx->is_te()) return fail(ctx, MSM_ERR_ARG, "msm_generate_points: curve not supported yet");
   try {
     HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->is_te()) return msm_gen::generate_points_te(ctx, n, seed, a_out);
     return msm_gen::generate_points(ctx, n, seed, a_out);
   } catch (const HipFail& f) {
     return fail_hip(ctx, f);

@@ -158,4 +158,92 @@ inline int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_o
   return MSM_OK;
 }
 
+// Edwards curve: the same scheme over the unified extended addition (host: TeCurve6, device: k_te_gen_points)
+inline int generate_points_te(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
+  using namespace msm_host;
+  if (n >= (1ull << 30)) return MSM_ERR_ARG;
+  const TeCurve6& C = ctx->hte;
+  const Q256 qq = scalar_order(ctx);
+  const uint64_t* q = qq.v;
+  auto words8_to_host = [&](const uint32_t* w8) {   // device Montgomery (2^270) words -> host Montgomery
+    Fe6 t = {{0, 0, 0, 0, 0, 0}}, r;
+    for (int i = 0; i < 4; i++) t.v[i] = (uint64_t)w8[2 * i] | ((uint64_t)w8[2 * i + 1] << 32);
+    C.F.mul(r, t, ctx->k_te_to_host);
+    return r;
+  };
+  Ext6 G;
+  G.X = words8_to_host(msm::Fp253::GXW);
+  G.Y = words8_to_host(msm::Fp253::GYW);
+  G.Z = C.F.one;
+  C.F.mul(G.T, G.X, G.Y);
+  std::vector<uint8_t> wire((size_t)N_BASIS * TBL * 64);
+  std::vector<U256> tbl_scalar((size_t)N_BASIS * TBL);
+  Fe6 one_plain = {{1, 0, 0, 0, 0, 0}};
+  for (int j = 0; j < N_BASIS; j++) {
+    U256 b;
+    draw_scalar(b.v, seed ^ 0xba5e5ull, (uint64_t)j, q, qq.bits);
+    Ext6 B = C.zero();
+    for (int bit = 255; bit >= 0; bit--) {   // the unified addition doubles as well
+      B = C.add(B, B);
+      if ((b.v[bit / 64] >> (bit % 64)) & 1) B = C.add(B, G);
+    }
+    Ext6 acc = C.zero();
+    U256 sacc = {{0, 0, 0, 0}};
+    for (int t = 0; t < TBL; t++) {
+      acc = C.add(acc, B);
+      addmod_q(sacc, sacc, b, q);
+      tbl_scalar[(size_t)j * TBL + t] = sacc;
+      Fe6 zi, x, y;
+      C.F.inv(zi, acc.Z);
+      C.F.mul(x, acc.X, zi);
+      C.F.mul(y, acc.Y, zi);
+      C.F.mul(x, x, one_plain);
+      C.F.mul(y, y, one_plain);
+      uint8_t* w = &wire[((size_t)j * TBL + t) * 64];
+      for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 8; k++) {
+          w[8 * i + k] = (uint8_t)(x.v[i] >> (8 * k));
+          w[32 + 8 * i + k] = (uint8_t)(y.v[i] >> (8 * k));
+        }
+    }
+  }
+  DevBuf d_wire, d_tbl, d_pts;
+  ctx->ensure(d_wire, wire.size());
+  ctx->ensure(d_tbl, (size_t)N_BASIS * TBL * msm::te::TE_ROW_WORDS * 4);
+  ctx->ensure(d_pts, std::max<uint64_t>(n, 1) * 64);
+  HIPCHK(hipMemcpyAsync(d_wire.p, wire.data(), wire.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(msm::te::k_te_points_from_wire, dim3((N_BASIS * TBL + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t*)d_tbl.p,
+                     (const uint32_t*)d_wire.p, (uint64_t)N_BASIS * TBL, 1, (uint32_t*)ctx->errflag.p);
+  ctx->n_points = 0;
+  ctx->ensure(ctx->rows, std::max<uint64_t>(n, 1) * msm::te::TE_ROW_WORDS * 4);
+  if (n) {
+    const uint32_t grid = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(msm::te::k_te_gen_points, dim3(grid), dim3(256), 0, ctx->stream, (uint32_t*)d_pts.p, (const uint32_t*)d_tbl.p,
+                       n, seed);
+    hipLaunchKernelGGL(msm::te::k_te_points_from_wire, dim3(grid), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p,
+                       (const uint32_t*)d_pts.p, n, 0, (uint32_t*)ctx->errflag.p);
+  }
+  HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->errflag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  ctx->release(d_wire);
+  ctx->release(d_tbl);
+  ctx->release(d_pts);
+  if (ctx->h_info[0]) {
+    ctx->err = "msm_generate_points: table point failed validation";
+    return MSM_ERR_POINT;
+  }
+  ctx->n_points = n;
+  if (a_out) {
+    for (uint64_t i = 0; i < n; i++) {
+      U256 a = {{0, 0, 0, 0}};
+      for (int j = 0; j < N_BASIS; j++) addmod_q(a, a, tbl_scalar[(size_t)j * TBL + table_index(seed, i, j)], q);
+      for (int k = 0; k < 4; k++)
+        for (int bb = 0; bb < 8; bb++) a_out[i * 32 + 8 * k + bb] = (uint8_t)(a.v[k] >> (8 * bb));
+    }
+  }
+  return MSM_OK;
+}
+
 }  // namespace msm_gen

@@ -290,6 +290,40 @@ __global__ void __launch_bounds__(256) k_te_add(BatchArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_te_gen_points: synthetic inputs, P_i = sum_j T_j[idx_ij] over 5 basis tables (randomPointsFast,
+// src/curve-random.ts:14-92, with the discrete logs known to the host; see msm_gen.h).  Writes wire format.
+// ---------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_te_gen_points(uint32_t* wire_out, const uint32_t* tables, uint64_t n, uint64_t seed) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Ext acc;
+  te_set_identity(acc);
+#pragma unroll 1
+  for (int j = 0; j < msm_gen::N_BASIS; j++) {
+    const uint32_t t = msm_gen::table_index(seed, i, j);
+    AffRow R;
+    load_row(R, tables, (uint32_t)((j * msm_gen::TBL + t) << 1));
+    Ext Q;
+    Q.X = R.x; Q.Y = R.y; Q.T = R.t;
+    fe_set_one<FT>(Q.Z);
+    te_add(acc, acc, Q);
+  }
+  Fe<FT> zi, x, y, one;
+  fe_inv<FT>(zi, acc.Z);
+  fe_mul<FT>(x, acc.X, zi);
+  fe_mul<FT>(y, acc.Y, zi);
+  fe_set_zero<FT>(one);
+  one.l[0] = 1;
+  fe_mul<FT>(x, x, one);   // out of Montgomery form
+  fe_mul<FT>(y, y, one);
+  fe_reduce_4p<FT>(x);
+  fe_reduce_4p<FT>(y);
+  fe_store<FT>(wire_out + i * 16, x);
+  fe_store<FT>(wire_out + i * 16 + 8, y);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_te_bucket_reduce / k_te_window_sum: reduceBucketsChunk (src/msm-basic.ts:180-211) per chunk of TC
 // buckets, then the per-window sum of the chunk columns
 // ---------------------------------------------------------------------------------------------

@@ -145,6 +145,26 @@ def test_large_2p20_known_discrete_logs(ed_ctx):
     assert (res2.x, res2.y) == (res.x, res.y)
 
 
+@pytest.mark.parametrize("lg", [12, 20])
+def test_generated_points_known_discrete_logs(ed_ctx, lg):
+    """Device-generated inputs (randomPointsFast / randomScalars, src/curve-random.ts): P_i = a_i G with the a_i known to
+    the host, 2^20 DISTINCT points (what bench.py --curve ed377 runs on): sum s_i P_i = (sum s_i a_i) G."""
+    n = 1 << lg
+    a = O.scalars_from_bytes(ed_ctx.generate_points(n, seed=500 + lg, want_scalars=True))
+    G = O.te_from_affine((E.gx, E.gy), E)
+    for i in (0, 1, n // 2, n - 1):
+        assert ed_ctx.get_point(i) == O.te_to_affine(O.te_scale(a[i], G, E), E)
+    assert len({ed_ctx.get_point(i) for i in range(0, n, max(1, n // 64))}) == min(n, 64)
+    dev, sb = ed_ctx.generate_scalars(n, seed=600 + lg, to_host=True)
+    s = O.scalars_from_bytes(sb)
+    assert all(v < E.q for v in s) and max(s).bit_length() == E.q.bit_length()
+    res, info = ed_ctx.run_device(dev, n)
+    tot = sum(x * y for x, y in zip(a, s)) % E.q
+    assert (res.x, res.y) == O.te_to_affine(O.te_scale(tot, G, E), E), info
+    res2, _ = ed_ctx.run_device(dev, n, c=9)
+    assert (res2.x, res2.y) == (res.x, res.y)
+
+
 def test_reference_shaped_api():
     from montgomery_amd.api import ED_ON_BLS12_377_PARAMS, TwistedEdwards, compute_msm_ed
 
