@@ -47,3 +47,8 @@ napi: $(NAPI)
 $(NAPI): napi/msm_addon.cc include/msm_hip.h $(LIB)
 	g++ -O2 -std=c++14 -fPIC -shared -Iinclude -I/usr/include/node napi/msm_addon.cc -o $(NAPI) \
 	    -Lmontgomery_amd -lmsm_hip -Wl,-rpath,'$$ORIGIN'
+
+# plain-C host of the C ABI (no Python): examples/msm_demo [log2_n] [curve]
+demo: examples/msm_demo
+examples/msm_demo: examples/msm_demo.c include/msm_hip.h $(LIB)
+	gcc -O2 -Wall -Iinclude examples/msm_demo.c -Lmontgomery_amd -lmsm_hip -Wl,-rpath,'$$ORIGIN/../montgomery_amd' -o examples/msm_demo

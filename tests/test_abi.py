@@ -60,3 +60,23 @@ def test_product_does_not_import_oracle():
                     s = line.strip()
                     if s.startswith(("import ", "from ", "#include")):
                         assert "oracle" not in s, f"{f}: {s}"
+
+
+def test_plain_c_host_links_and_fails_loudly_without_gpu():
+    """examples/msm_demo.c links against the C ABI alone; on a box without a GPU it must stop with an error
+    (there is no CPU fallback), on a GPU box tests/test_napi.py::test_plain_c_host_of_the_abi runs it for real."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", root, "-s", "demo"])
+    out = subprocess.run([os.path.join(root, "examples", "msm_demo"), "10"], capture_output=True, text=True, timeout=120)
+    try:
+        import torch
+
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        assert out.returncode == 0, out.stdout + out.stderr
+    else:
+        assert out.returncode == 1 and "no CPU fallback" in out.stderr, out.stdout + out.stderr

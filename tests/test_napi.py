@@ -44,3 +44,17 @@ def test_js_facade_on_gpu(addon):
     out = subprocess.run([NODE, "js/test-compute-msm.js"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ALL OK" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", [0, 1, 2, 3])
+def test_plain_c_host_of_the_abi(curve):
+    """examples/msm_demo.c: a C program on the C ABI alone (what a cgo / JNI binding would do): generates inputs on
+    the GPU, checks that the MSM does not depend on the window size nor on one-window sharding + msm_combine_curve."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "examples", "msm_demo")
+    subprocess.check_call(["make", "-C", ROOT, "-s", "demo"])
+    out = subprocess.run([exe, "14", str(curve)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK: result independent" in out.stdout
