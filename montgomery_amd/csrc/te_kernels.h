@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) k_te_digits(uint32_t* dig, uint32_t* coun
   uint32_t q[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) q[j] = FRED_Q[j];
-  for (int it = 0; it < 40 && words8_ge(s, q); it++) bn_addsub<8, 8>(s, q, true);   // scalars >= q are reduced
+  for (int it = 0; it < 64 && words8_ge(s, q); it++) bn_addsub<8, 8>(s, q, true);   // scalars >= q are reduced (2^256 < 56 q)
   const uint32_t L = 1u << (c - 1);
   uint32_t carry = 0;
   for (int k = 0; k < k_total; k++) {

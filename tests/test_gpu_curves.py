@@ -164,6 +164,7 @@ def test_msm_ragged_windows_and_edges(cv):
     for s in (1, q - 1, q - 2, B.lam, B.lam + 1, (1 << 254) + 12345, (1 << 127) - 1, 1 << 127, 1 << 128):
         assert run_msm(ctx, [s], [pts[1]])[0] == O.aff_scale(s, pts[1], P_MOD), hex(s)
     assert run_msm(ctx, [q + 5], [pts[2]])[0] == O.aff_scale(5, pts[2], P_MOD)   # scalars >= q are reduced
+    assert run_msm(ctx, [(1 << 256) - 1], [pts[2]])[0] == O.aff_scale(((1 << 256) - 1) % q, pts[2], P_MOD)
     sc = O.prng_ints(f"gpu/edge/{cv.name}/mix", 48, q)
     mix = list(pts[:48])
     mix[3] = None

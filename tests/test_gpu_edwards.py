@@ -116,6 +116,16 @@ def test_ragged_and_edge_cases(ed_ctx):
     assert run(ed_ctx, [E.q + 9], [pts[1]])[0] == O.te_to_affine(O.te_scale(9, Pt, E), E)
 
 
+def test_scalars_beyond_q_are_reduced(ed_ctx):
+    """Any 256-bit scalar is accepted and reduced (2^256 < 56 q for this curve)."""
+    base, ks = O.random_points_ed377("gpu/ed/bigscalar", 4)
+    G = O.te_from_affine((E.gx, E.gy), E)
+    sc = [(1 << 256) - 1, 41 * E.q + 5, 54 * E.q + 123, E.q]
+    got, _ = run(ed_ctx, sc, base, 7)
+    tot = sum(s * k for s, k in zip(sc, ks)) % E.q
+    assert got == O.te_to_affine(O.te_scale(tot, G, E), E)
+
+
 def test_error_codes(ed_ctx):
     from montgomery_amd import MsmError
 

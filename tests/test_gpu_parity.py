@@ -209,6 +209,7 @@ def test_msm_edge_cases(gpu_ctx):
         assert run_msm(gpu_ctx, [s], [pts[1]])[0] == O.aff_scale(s, pts[1], P_MOD), hex(s)
     # scalars >= q are reduced
     assert run_msm(gpu_ctx, [q + 5], [pts[2]])[0] == O.aff_scale(5, pts[2], P_MOD)
+    assert run_msm(gpu_ctx, [(1 << 256) - 1], [pts[2]])[0] == O.aff_scale(((1 << 256) - 1) % q, pts[2], P_MOD)
     # identity among the inputs, repeated points, P and -P in one bucket
     sc = O.prng_ints("gpu/edge/mix", 48, q)
     mix = list(pts[:48])
