@@ -327,6 +327,109 @@ MSM_DEV void fe_inv_fermat(Fe<C>& r, const Fe<C>& a) {
   r = acc;
 }
 
+// wave-uniform "does any lane still have work" (device) / plain predicate (host unit tests)
+MSM_DEV bool fe_any_lane(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __any((int)p) != 0;
+#else
+  return p;
+#endif
+}
+
+// Kaliski's almost-inverse, the reference's algorithm (src/wasm/inverse.ts:136-218: `almostInverse`, then a
+// shift by the missing power of two) -- kept as the third variant for cross-checks and for the comparison in
+// a binary gcd with four data-dependent cases per step, which a 64-lane wave executes as all four.
+//   u = p, v = a, r = 0, s = 1;  while v > 0: (u even) u /= 2, s *= 2 | (v even) v /= 2, r *= 2 |
+//   (u > v) u = (u - v) / 2, r += s, s *= 2 | (else) v = (v - u) / 2, s += r, r *= 2;  k steps in total
+// leaves r = -a^-1 2^k mod p.  The input is a R (Montgomery form), so doubling p - r up to the exponent 2 log2 R
+// gives a^-1 R^-1 R^2 = a^-1 R directly: no table of powers of two, no final multiplication.
+template <class C>
+MSM_DEV void fe_inv_kaliski(Fe<C>& out, const Fe<C>& a_in) {
+  constexpr int N = C::NL;
+  Fe<C> a = a_in;
+  fe_reduce_4p<C>(a);   // canonical [0, p)
+  uint32_t u[N], v[N], r[N], s[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) { u[i] = C::P[i]; v[i] = a.l[i]; r[i] = 0; s[i] = 0; }
+  s[0] = 1;
+  auto shr1 = [](uint32_t (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] = (x[i] >> 1) | ((i + 1 < N ? (x[i + 1] & 1u) : 0u) << (LB - 1));
+  };
+  auto shl1 = [](uint32_t (&x)[N]) {
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) x[i] = ((x[i] << 1) & LMASK) | (i ? (x[i - 1] >> (LB - 1)) : 0u);
+  };
+  auto add = [](uint32_t (&x)[N], const uint32_t (&y)[N]) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { uint32_t t = x[i] + y[i] + c; x[i] = t & LMASK; c = t >> LB; }
+  };
+  auto sub = [](uint32_t (&x)[N], const uint32_t (&y)[N]) {   // x -= y, returns the borrow
+    uint32_t b = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { uint32_t t = x[i] - y[i] - b; x[i] = t & LMASK; b = (t >> 31) & 1u; }
+    return b;
+  };
+  auto gt = [](const uint32_t (&x)[N], const uint32_t (&y)[N]) {
+    bool g = false, l = false;
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+      if (!g && !l) { if (x[i] > y[i]) g = true; else if (x[i] < y[i]) l = true; }
+    }
+    return g;
+  };
+  int k = 0;
+#pragma unroll 1
+  for (int it = 0; it < 2 * LB * N; it++) {
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) nz |= v[i];
+    if (!fe_any_lane(nz != 0)) break;
+    if (nz == 0) continue;
+    if (!(u[0] & 1u)) { shr1(u); shl1(s); }
+    else if (!(v[0] & 1u)) { shr1(v); shl1(r); }
+    else if (gt(u, v)) { sub(u, v); shr1(u); add(r, s); shl1(s); }
+    else { sub(v, u); shr1(v); add(s, r); shl1(r); }
+    k++;
+  }
+  uint32_t pp[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) pp[i] = C::P[i];
+  // r < 2p: r mod p, then p - r (0 stays 0: a == 0 gives 0 like the other variants)
+  {
+    uint32_t t[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = r[i];
+    if (!sub(t, pp)) {
+#pragma unroll
+      for (int i = 0; i < N; i++) r[i] = t[i];
+    }
+    uint32_t nzr = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { t[i] = pp[i]; nzr |= r[i]; }
+    sub(t, r);
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = nzr ? t[i] : 0u;
+  }
+  // up to the exponent 2 log2 R
+#pragma unroll 1
+  for (int e = 0; e < 2 * LB * N; e++) {
+    if (!fe_any_lane(k + e < 2 * LB * N)) break;
+    if (k + e >= 2 * LB * N) continue;
+    shl1(r);
+    uint32_t t[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = r[i];
+    if (!sub(t, pp)) {
+#pragma unroll
+      for (int i = 0; i < N; i++) r[i] = t[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) out.l[i] = r[i];
+}
+
 // Division-step inverse (Bernstein-Yang "safegcd", half-delta variant) on signed 30-bit limbs.
 // Plays the role of the reference's Kaliski almost-inverse (src/wasm/inverse.ts:136-218): a binary
 // gcd whose per-step decisions only look at the low bits -- but branch-free, so the 64 lanes of a
@@ -419,15 +522,6 @@ MSM_DEV void fe_signed_negate(int32_t (&v)[N], int32_t mask) {  // v = mask ? -v
     int32_t t = ((v[i] ^ mask) - mask) + c;
     if (i + 1 < N) { c = t >> LB; v[i] = t & (int32_t)LMASK; } else { v[i] = t; }
   }
-}
-
-// wave-uniform "does any lane still have work" (device) / plain predicate (host unit tests)
-MSM_DEV bool fe_any_lane(bool p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __any((int)p) != 0;
-#else
-  return p;
-#endif
 }
 
 // r = a^-1 in Montgomery form (a in Montgomery form, any value < 2p; a == 0 mod p gives 0).

@@ -468,6 +468,8 @@ __global__ void __launch_bounds__(256) k_te_test_fp(uint32_t* out, const uint32_
     case OP_ADD: fe_add<FT>(r, x, y); break;
     case OP_SUB: fe_sub_p<FT>(r, x, y); break;
     case OP_INV: fe_inv<FT>(r, x); break;
+    case OP_INV_FERMAT: fe_inv_fermat<FT>(r, x); break;
+    case OP_INV_KALISKI: fe_inv_kaliski<FT>(r, x); break;
     case OP_TO_MONT: {
       Fe<FT> r2;
       TE_CONST(r2, R2);

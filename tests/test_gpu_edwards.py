@@ -58,8 +58,11 @@ def test_fp253_operators(ed_ctx):
     assert all(fb(out, i) == (vals[i] - vals[n - 1 - i]) % P_MOD for i in range(n))
     nz = [v for v in vals if v]
     mont = ed_ctx.test_fp(_lib.OP_TO_MONT, b"".join(tb(v) for v in nz))
-    back = ed_ctx.test_fp(_lib.OP_FROM_MONT, ed_ctx.test_fp(_lib.OP_INV, mont))
+    inv = ed_ctx.test_fp(_lib.OP_INV, mont)
+    back = ed_ctx.test_fp(_lib.OP_FROM_MONT, inv)
     assert all(fb(back, i) == pow(v, -1, P_MOD) for i, v in enumerate(nz))
+    assert ed_ctx.test_fp(_lib.OP_INV_FERMAT, mont[: 32 * 64]) == inv[: 32 * 64]
+    assert ed_ctx.test_fp(_lib.OP_INV_KALISKI, mont[: 32 * 64]) == inv[: 32 * 64]
 
 
 def test_golden_vectors(ed_ctx):

@@ -97,6 +97,20 @@ def test_fp_montgomery_roundtrip_and_inverse(gpu_ctx):
     assert all(fb(back, i) == pow(v, -1, P_MOD) for i, v in enumerate(vals))
 
 
+def test_fp_inverse_variants_agree(gpu_ctx):
+    """division steps (the product's `fe_inv`), Fermat, and Kaliski's almost-inverse -- the reference's
+    own algorithm, src/wasm/inverse.ts:136-218 -- give the same Montgomery-form inverse on the GPU."""
+    from montgomery_amd import _lib
+
+    vals = [v for v in field_inputs() if v][:300]
+    mont = gpu_ctx.test_fp(_lib.OP_TO_MONT, b"".join(tb(v) for v in vals))
+    ref = gpu_ctx.test_fp(_lib.OP_INV, mont)
+    assert gpu_ctx.test_fp(_lib.OP_INV_FERMAT, mont) == ref
+    assert gpu_ctx.test_fp(_lib.OP_INV_KALISKI, mont) == ref
+    back = gpu_ctx.test_fp(_lib.OP_FROM_MONT, ref)
+    assert all(fb(back, i) == pow(v, -1, P_MOD) for i, v in enumerate(vals))
+
+
 def test_fp_golden(gpu_ctx):
     from montgomery_amd import _lib
 

@@ -52,8 +52,8 @@ def test_mul_sqr_add_sub(lib, field):
 
 
 @pytest.mark.parametrize("field", [0, 1, 2, 3])
-def test_inverse_divsteps_and_fermat(lib, field):
-    """fe_inv (division steps) == fe_inv_fermat == a^-1 R^2 for Montgomery-form input a R."""
+def test_inverse_divsteps_fermat_kaliski(lib, field):
+    """fe_inv (division steps) == fe_inv_fermat == fe_inv_kaliski == a^-1 R^2 for Montgomery-form input a R."""
     p, _, nl = FIELDS[field]
     R = 1 << (30 * nl)
     vals = [1, 2, p - 1, p - 2, (p + 1) // 2, 3, 1 << 200, (1 << 252) - 1] + O.prng_ints(f"host/inv{field}", 400, p)
@@ -65,7 +65,10 @@ def test_inverse_divsteps_and_fermat(lib, field):
         assert fp_op(lib, field, 4, a) == exp, hex(a)
     for a in vals[:40]:
         assert fp_op(lib, field, 5, a % p) == pow(a % p, -1, p) * R * R % p
-    assert fp_op(lib, field, 4, 0) == 0
+    # the reference's own algorithm, Kaliski's almost-inverse (src/wasm/inverse.ts:136-218), as the third variant
+    for a in vals[:120]:
+        assert fp_op(lib, field, 6, a % p) == pow(a % p, -1, p) * R * R % p, hex(a)
+    assert fp_op(lib, field, 4, 0) == 0 and fp_op(lib, field, 6, 0) == 0
 
 
 @pytest.mark.parametrize("curve", [0, 2, 3])

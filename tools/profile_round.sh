@@ -13,7 +13,7 @@ python bench.py --steps 10 --warmup 2 --log2n 20 --no-cpu-baseline > $OUT/bench_
 python bench.py --curve ed377 --steps 10 --warmup 2 --log2n 20 > $OUT/bench_ed377_2p20.json 2> $OUT/bench_ed.err
 python bench.py --curve bls12-381 --steps 10 --warmup 2 > $OUT/bench_bls381_2p26.json 2> $OUT/bench_381.err
 python bench.py --curve bls12-381 --steps 10 --warmup 2 --log2n 20 > $OUT/bench_bls381_2p20.json 2>> $OUT/bench_381.err
-for u in ubench_exec ubench_occ ubench_bt; do [ -x tools/$u ] && ./tools/$u > $OUT/$u.txt 2>&1; done
+for u in ubench_exec ubench_occ ubench_bt ubench_inv; do [ -x tools/$u ] && ./tools/$u > $OUT/$u.txt 2>&1; done
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace26 -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/trace26.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace20 -- python3 $REPO/bench.py --steps 5 --warmup 1 --log2n 20 --no-cpu-baseline > $OUT/trace20.log 2>&1
