@@ -8,6 +8,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def build_if_missing(target: str, path: str) -> None:
+    """`make target` only when its product is absent.  The test process may already have libmsm_hip.so loaded: a
+    timestamp-triggered relink of the library underneath it must never happen as a side effect of a test."""
+    import subprocess
+
+    if not os.path.exists(os.path.join(ROOT, path)):
+        subprocess.check_call(["make", "-C", ROOT, "-s", target])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -68,7 +68,10 @@ def test_plain_c_host_links_and_fails_loudly_without_gpu():
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.check_call(["make", "-C", root, "-s", "demo"])
+    from conftest import build_if_missing
+
+    build_if_missing("all", "montgomery_amd/libmsm_hip.so")
+    build_if_missing("demo", "examples/msm_demo")
     out = subprocess.run([os.path.join(root, "examples", "msm_demo"), "10"], capture_output=True, text=True, timeout=120)
     try:
         import torch

@@ -21,7 +21,7 @@ FIELDS = {
 
 @pytest.fixture(scope="module")
 def lib():
-    subprocess.check_call(["make", "-C", ROOT, "-s", "hosttest"])
+    subprocess.check_call(["make", "-C", ROOT, "-s", "hosttest"])   # own shim library, never loaded by anything else
     lib = C.CDLL(LIB)
     lib.host_fp_op.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.host_glv.argtypes = [C.c_int, C.c_void_p, C.c_void_p]

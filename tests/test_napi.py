@@ -14,7 +14,10 @@ NODE = shutil.which("node")
 def addon():
     if NODE is None or not os.path.exists("/usr/include/node/node_api.h"):
         pytest.skip("node / node_api.h not present")
-    subprocess.check_call(["make", "-C", ROOT, "-s", "all", "napi"])
+    from conftest import build_if_missing
+
+    build_if_missing("all", "montgomery_amd/libmsm_hip.so")
+    build_if_missing("napi", "montgomery_amd/msm_hip.node")
     return os.path.join(ROOT, "montgomery_amd", "msm_hip.node")
 
 
@@ -54,7 +57,9 @@ def test_plain_c_host_of_the_abi(curve):
     import subprocess
 
     exe = os.path.join(ROOT, "examples", "msm_demo")
-    subprocess.check_call(["make", "-C", ROOT, "-s", "demo"])
+    from conftest import build_if_missing
+
+    build_if_missing("demo", "examples/msm_demo")
     out = subprocess.run([exe, "14", str(curve)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK: result independent" in out.stdout
