@@ -136,13 +136,14 @@ enum { MSM_OP_MUL = 0, MSM_OP_SQR = 1, MSM_OP_ADD = 2, MSM_OP_SUB = 3, MSM_OP_IN
  * src/field-msm.ts:86-123. */
 int msm_test_fp(msm_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, uint64_t n);
 /* `batchInverse` (src/wasm/inverse.ts:220-271): n Montgomery-form elements (48-byte words, non-zero) inverted with
- * one field inversion per `per_lane` consecutive elements (Montgomery's trick); BLS12-377 base field. */
+ * one field inversion per `per_lane` consecutive elements (Montgomery's trick); base field of the Weierstrass curves. */
 int msm_test_batch_inverse(msm_ctx* ctx, const uint8_t* xs, uint8_t* out, uint64_t n, uint32_t per_lane);
 /* GLV `decompose` (src/wasm/glv.ts:68-169) of n 32-byte scalars: out = n x 40 bytes
  * |s0| (16 B LE) || |s1| (16 B LE) || neg0 (u32) || neg1 (u32). */
 int msm_test_glv(msm_ctx* ctx, const uint8_t* scalars, uint8_t* out, uint64_t n);
 /* affine pair additions G_i + H_i through the batched-affine kernel (batchAddNew,
- * src/curve-affine.ts:376-458): inputs n x 96-byte wire points, output n x 96 bytes. */
+ * src/curve-affine.ts:376-458): inputs n x 96-byte wire points, output n x 96 bytes.  Ed-on-BLS12-377: the
+ * unified extended addition of the gather round (src/curve-twisted-edwards.ts:84-165), n x 64 bytes each way. */
 int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t* out, uint64_t n);
 
 #ifdef __cplusplus

@@ -1222,7 +1222,73 @@ int msm_test_glv(msm_ctx* ctx, const uint8_t* scalars, uint8_t* out, uint64_t n)
 
 int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t* out, uint64_t n) {
   if (!ctx || !g || !h || !out || n == 0) return fail(ctx, MSM_ERR_ARG, "msm_test_batch_add: bad argument");
-  if (ctx->is_te()) return fail(ctx, MSM_ERR_ARG, "msm_test_batch_add: curve not supported yet");
+  if (ctx->is_te()) {
+    // unified extended addition of the gather round (te_add_rows, src/curve-twisted-edwards.ts:84-165): n pairs of
+    // 64-byte affine points in, n affine sums out
+    try {
+      HIPCHK(hipSetDevice(ctx->device));
+      DevBuf rows, wire, slots, outb;
+      ctx->ensure(wire, 2 * n * 64);
+      ctx->ensure(rows, 2 * n * te::TE_ROW_WORDS * 4);
+      ctx->ensure(slots, 2 * n * 4);
+      ctx->ensure(outb, n * 128);
+      std::vector<uint8_t> inter(2 * n * 64);
+      std::vector<uint32_t> sl(2 * n);
+      for (uint64_t i = 0; i < n; i++) {
+        memcpy(&inter[(2 * i) * 64], g + i * 64, 64);
+        memcpy(&inter[(2 * i + 1) * 64], h + i * 64, 64);
+        sl[2 * i] = (uint32_t)((2 * i) << 1);
+        sl[2 * i + 1] = (uint32_t)((2 * i + 1) << 1);
+      }
+      HIPCHK(hipMemcpyAsync(wire.p, inter.data(), inter.size(), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(slots.p, sl.data(), sl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
+      hipLaunchKernelGGL(te::k_te_points_from_wire, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream,
+                         (uint32_t*)rows.p, (const uint32_t*)wire.p, 2 * n, 0, (uint32_t*)ctx->errflag.p);
+      BatchArgs a{};
+      a.points = (const uint32_t*)rows.p;
+      a.slots = (const uint32_t*)slots.p;
+      a.out = (uint4*)outb.p;
+      a.out_cap = n;
+      a.n_out = n;
+      a.steps = 1;
+      hipLaunchKernelGGL(te::k_te_add<MODE_GATHER>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+      std::vector<uint32_t> planes(n * 32);
+      HIPCHK(hipMemcpyAsync(planes.data(), outb.p, n * 128, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipGetLastError());
+      const auto& C = ctx->hte;
+      msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
+      for (uint64_t e = 0; e < n; e++) {
+        msm_host::Fe6 co[3];   // X, Y, Z
+        for (int j = 0; j < 3; j++) {
+          msm_host::Fe6 t = {{0, 0, 0, 0, 0, 0}};
+          for (int pl = 0; pl < 2; pl++)
+            for (int q = 0; q < 2; q++) {
+              const uint32_t* w = &planes[((uint64_t)(2 * j + pl) * n + e) * 4 + 2 * q];
+              t.v[2 * pl + q] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+            }
+          if (msm_host::Field6::ge(t, C.F.p)) C.F.sub_raw(t, t, C.F.p);
+          C.F.mul(co[j], t, ctx->k_te_to_host);
+        }
+        msm_host::Fe6 zi, x, y;
+        C.F.inv(zi, co[2]);
+        C.F.mul(x, co[0], zi);
+        C.F.mul(y, co[1], zi);
+        C.F.mul(x, x, one);
+        C.F.mul(y, y, one);
+        uint8_t xb[48], yb[48];
+        fe6_to_bytes(xb, x);
+        fe6_to_bytes(yb, y);
+        memcpy(out + e * 64, xb, 32);
+        memcpy(out + e * 64 + 32, yb, 32);
+      }
+      for (DevBuf* b : {&rows, &wire, &slots, &outb}) ctx->release(*b);
+    } catch (const HipFail& f) {
+      return fail_hip(ctx, f);
+    }
+    return MSM_OK;
+  }
   try {
     HIPCHK(hipSetDevice(ctx->device));
     // rows for 2n points: pair e = (row 2e, row 2e + 1), gathered through identity payload slots

@@ -65,6 +65,20 @@ def test_fp253_operators(ed_ctx):
     assert ed_ctx.test_fp(_lib.OP_INV_KALISKI, mont[: 32 * 64]) == inv[: 32 * 64]
 
 
+def test_unified_addition_operator(ed_ctx):
+    """`addOrSubtract` of src/curve-twisted-edwards.ts:84-165 (add-2008-hwcd-3, also used for doubling :215-217) as the
+    gather round runs it, against the oracle: random pairs, P + P, P + (-P), P + identity, identity + identity."""
+    pts, _ = O.random_points_ed377("gpu/ed/add", 120)
+    neg = lambda P: ((E.p - P[0]) % E.p, P[1])
+    ident = (0, 1)
+    gs = pts[:60] + [pts[0], pts[1], pts[2], ident, ident]
+    hs = pts[60:] + [pts[0], neg(pts[1]), ident, pts[3], ident]
+    out = ed_ctx.test_batch_add(O.points_to_bytes(gs, 32), O.points_to_bytes(hs, 32))
+    for i, (g, h) in enumerate(zip(gs, hs)):
+        exp = O.te_to_affine(O.te_add(O.te_from_affine(g, E), O.te_from_affine(h, E), E), E)
+        assert (fb(out, 2 * i), fb(out, 2 * i + 1)) == exp, i
+
+
 def test_golden_vectors(ed_ctx):
     H = lambda x: int(x, 16)
     for c in json.load(open(os.path.join(GOLD, "msm_ed377.json")))["cases"]:
