@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
   printf("\n");
   int ok = memcmp(a.x, b.x, 48) == 0 && memcmp(a.y, b.y, 48) == 0 && a.is_infinity == b.is_infinity;
 
-  if (curve != MSM_CURVE_ED_ON_BLS12_377) { /* window shards: one window at a time, then the host combine */
+  { /* window shards: one window at a time, then the host combine */
     int32_t cc = 0, K = 0;
     memset(&opts, 0, sizeof opts);
     if ((rc = msm_plan(ctx, n, &opts, &cc, &K))) die(ctx, "msm_plan", rc);

@@ -100,14 +100,15 @@ int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const 
 /* Window-sharded form for multi-GPU runs: computes the partition sums P_k for k in [k_lo, k_hi)
  * only (src/msm-batched-affine.ts:42 "P_k = sum_l l * B_(k,l)") and writes them as
  * (k_hi - k_lo) x 144 bytes: X || Y || Z homogeneous projective, 48-byte little-endian canonical
- * integers.  Ranks exchange these with one all-gather; msm_combine finishes. */
+ * integers (twisted Edwards: the extended point without T, which msm_combine rebuilds from T Z = X Y).
+ * Ranks exchange these with one all-gather; msm_combine finishes. */
 int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts,
                     uint8_t* partials_out, msm_result* stats);
 
 /* S = sum_k 2^(c k) P_k over all K windows, then to affine (src/msm-batched-affine.ts:322-333,
  * src/curve-projective.ts:335-349).  Host arithmetic only: `ctx` may be NULL. */
 int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm_result* out);
-/* The same without a context: `curve` names the constants (Weierstrass curves only).  No GPU is touched. */
+/* The same without a context: `curve` names the constants.  No GPU is touched. */
 int msm_combine_curve(int curve, const uint8_t* partials, int32_t K, int32_t c, msm_result* out);
 
 /* Window plan for n points: the c the library would pick and the resulting K. */

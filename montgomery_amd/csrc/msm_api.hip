@@ -707,19 +707,8 @@ void horner_to_affine(const msm_host::Curve6& C, const std::vector<msm_host::Pro
 }
 
 // twisted Edwards tail: S = sum_k 2^(ck) P_k with unified additions (src/msm-basic.ts:142-158), then x = X/Z, y = Y/Z
-void te_horner_to_affine(const msm_ctx* ctx, const std::vector<uint32_t>& words, int K, int c, msm_result* out) {
-  const auto& C = ctx->hte;
-  std::vector<msm_host::Ext6> P(K);
-  for (int k = 0; k < K; k++) {
-    const uint32_t* w = &words[(size_t)k * 32];
-    msm_host::Fe6* dst[4] = {&P[k].X, &P[k].Y, &P[k].Z, &P[k].T};
-    for (int j = 0; j < 4; j++) {
-      msm_host::Fe6 t = {{0, 0, 0, 0, 0, 0}};
-      for (int i = 0; i < 4; i++) t.v[i] = (uint64_t)w[8 * j + 2 * i] | ((uint64_t)w[8 * j + 2 * i + 1] << 32);
-      if (msm_host::Field6::ge(t, C.F.p)) C.F.sub_raw(t, t, C.F.p);   // device values are < 2p
-      C.F.mul(*dst[j], t, ctx->k_te_to_host);
-    }
-  }
+void te_horner_points(const msm_host::TeCurve6& C, const std::vector<msm_host::Ext6>& P, int c, msm_result* out) {
+  const int K = (int)P.size();
   msm_host::Ext6 acc = P[K - 1];
   for (int k = K - 2; k >= 0; k--) {
     for (int j = 0; j < c; j++) acc = C.add(acc, acc);
@@ -736,6 +725,26 @@ void te_horner_to_affine(const msm_ctx* ctx, const std::vector<uint32_t>& words,
   fe6_to_bytes(out->x, x);
   fe6_to_bytes(out->y, y);
   out->is_infinity = 0;
+}
+
+// device window sum (X, Y, Z, T: 8 words each, Montgomery radix 2^270, < 2p) -> host extended point
+msm_host::Ext6 te_partial_to_host(const msm_ctx* ctx, const uint32_t* w) {
+  const auto& C = ctx->hte;
+  msm_host::Ext6 P;
+  msm_host::Fe6* dst[4] = {&P.X, &P.Y, &P.Z, &P.T};
+  for (int j = 0; j < 4; j++) {
+    msm_host::Fe6 t = {{0, 0, 0, 0, 0, 0}};
+    for (int i = 0; i < 4; i++) t.v[i] = (uint64_t)w[8 * j + 2 * i] | ((uint64_t)w[8 * j + 2 * i + 1] << 32);
+    if (msm_host::Field6::ge(t, C.F.p)) C.F.sub_raw(t, t, C.F.p);   // device values are < 2p
+    C.F.mul(*dst[j], t, ctx->k_te_to_host);
+  }
+  return P;
+}
+
+void te_horner_to_affine(const msm_ctx* ctx, const std::vector<uint32_t>& words, int K, int c, msm_result* out) {
+  std::vector<msm_host::Ext6> P(K);
+  for (int k = 0; k < K; k++) P[k] = te_partial_to_host(ctx, &words[(size_t)k * 32]);
+  te_horner_points(ctx->hte, P, c, out);
 }
 
 int stage_scalars(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const uint32_t** d_out) {
@@ -979,7 +988,6 @@ int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_ou
 int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, uint8_t* partials_out,
                     msm_result* stats) {
   if (!ctx || !partials_out || (!scalars && n)) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: null argument");
-  if (ctx->is_te()) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: curve not supported yet");
   if (n > ctx->n_points) return fail(ctx, MSM_ERR_NO_POINTS, "msm_window_sums: %llu scalars but %llu resident points",
                                      (unsigned long long)n, (unsigned long long)ctx->n_points);
   Plan pl;
@@ -991,6 +999,20 @@ int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device
   try {
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<uint32_t> words;
+    if (ctx->is_te()) {
+      // extended point (X : Y : Z : T) sent as X || Y || Z; the receiver rebuilds T (msm_combine: T Z = X Y)
+      if (n) window_sums_impl(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
+      const auto& C = ctx->hte;
+      msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}}, t;
+      for (int k = 0; k < k_hi - k_lo; k++) {
+        const msm_host::Ext6 P = n ? te_partial_to_host(ctx, &words[(size_t)k * 32]) : C.zero();
+        C.F.mul(t, P.X, one); fe6_to_bytes(partials_out + (size_t)k * 144, t);
+        C.F.mul(t, P.Y, one); fe6_to_bytes(partials_out + (size_t)k * 144 + 48, t);
+        C.F.mul(t, P.Z, one); fe6_to_bytes(partials_out + (size_t)k * 144 + 96, t);
+      }
+      if (stats) { stats->c = pl.c; stats->K = pl.K; }
+      return MSM_OK;
+    }
     if (n == 0) {
       words.assign((size_t)(k_hi - k_lo) * 36, 0);
     } else {
@@ -1033,16 +1055,57 @@ const msm_host::Curve6* static_host_curve(int curve) {
 int combine_impl(msm_ctx* ctx, const msm_host::Curve6& C, const uint8_t* partials, int32_t K, int32_t c, msm_result* out);
 }  // namespace
 
+namespace {
+// twisted Edwards: (X : Y : Z) in, T rebuilt as (X Z : Y Z : Z^2 : X Y), then the unified-addition Horner
+int te_combine_impl(const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
+  static msm_host::TeCurve6 C;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    uint32_t pw[12] = {0};
+    for (int i = 0; i < 8; i++) pw[i] = Fp253::PW[i];
+    C.init(pw, 3021);
+  });
+  std::vector<msm_host::Ext6> P(K);
+  for (int k = 0; k < K; k++) {
+    msm_host::Fe6 t[3];
+    for (int j = 0; j < 3; j++) {
+      const uint8_t* b = partials + (size_t)k * 144 + 48 * j;
+      for (int i = 0; i < 6; i++) {
+        uint64_t v = 0;
+        for (int q = 0; q < 8; q++) v |= (uint64_t)b[8 * i + q] << (8 * q);
+        t[j].v[i] = v;
+      }
+      if (msm_host::Field6::ge(t[j], C.F.p)) return MSM_ERR_ARG;
+      C.F.mul(t[j], t[j], C.F.r2);
+    }
+    C.F.mul(P[k].X, t[0], t[2]);
+    C.F.mul(P[k].Y, t[1], t[2]);
+    C.F.mul(P[k].Z, t[2], t[2]);
+    C.F.mul(P[k].T, t[0], t[1]);
+  }
+  memset(out, 0, sizeof(*out));
+  te_horner_points(C, P, c, out);
+  out->c = c;
+  out->K = K;
+  return MSM_OK;
+}
+}  // namespace
+
 int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
   // pure host arithmetic: ctx may be NULL (then BLS12-377 G1; msm_combine_curve names the curve without a context)
   if (!partials || !out || K <= 0 || c <= 0) return fail(ctx, MSM_ERR_ARG, "msm_combine: bad argument");
-  if (ctx && ctx->is_te()) return fail(ctx, MSM_ERR_ARG, "msm_combine: curve not supported yet");
+  if (ctx && ctx->is_te()) {
+    int rc = te_combine_impl(partials, K, c, out);
+    return rc ? fail(ctx, rc, "msm_combine: coordinate >= p") : MSM_OK;
+  }
   return combine_impl(ctx, ctx ? ctx->hc : *static_host_curve(MSM_CURVE_BLS12_377_G1), partials, K, c, out);
 }
 
 int msm_combine_curve(int curve, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
+  if (!partials || !out || K <= 0 || c <= 0) return MSM_ERR_ARG;
+  if (curve == MSM_CURVE_ED_ON_BLS12_377) return te_combine_impl(partials, K, c, out);
   const msm_host::Curve6* C = static_host_curve(curve);
-  if (!C || !partials || !out || K <= 0 || c <= 0) return MSM_ERR_ARG;
+  if (!C) return MSM_ERR_ARG;
   return combine_impl(nullptr, *C, partials, K, c, out);
 }
 

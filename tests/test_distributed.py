@@ -112,7 +112,33 @@ def test_combine_host_other_curves():
     from montgomery_amd import MsmError
 
     with pytest.raises(MsmError):
-        combine_host(b"\0" * 144, 1, 4, curve=_lib.CURVE_ED_ON_BLS12_377)
+        combine_host(b"\0" * 144, 1, 4, curve=9)
+
+
+def test_combine_host_edwards():
+    """Twisted Edwards shards travel as (X : Y : Z); the combine rebuilds T = X Y / Z projectively and runs the
+    unified-addition Horner (src/msm-basic.ts:142-158)."""
+    from montgomery_amd import _lib
+    from montgomery_amd.distributed import combine_host
+    from oracle import msm_oracle as O
+
+    E = O.ED_ON_BLS12_377
+    pts, _ = O.random_points_ed377("dist/ed", 9)
+    sc = O.prng_ints("dist/ed/s", 9, E.q)
+    for c in (4, 14):
+        K = -(-(E.q.bit_length() + 1) // c)
+        sums = [O.te_from_affine((0, 1), E)] * K
+        for s, P in zip(sc, pts):
+            for k, (l, neg) in enumerate(O.signed_digits(s, c, K)):
+                if l:
+                    T = O.te_scale(l, O.te_from_affine(P, E), E)
+                    sums[k] = O.te_add(sums[k], O.te_neg(T, E) if neg else T, E)
+        parts = b""
+        for k, S in enumerate(sums):
+            x, y = O.te_to_affine(S, E)
+            lam = 7 + k   # any projective representative
+            parts += b"".join((v * lam % E.p).to_bytes(48, "little") for v in (x, y, 1))
+        assert combine_host(parts, K, c, curve=_lib.CURVE_ED_ON_BLS12_377) == O.msm_basic_te(sc, pts, c=c)
 
 
 @pytest.mark.timeout(300)

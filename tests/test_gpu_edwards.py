@@ -192,6 +192,18 @@ def test_generated_points_known_discrete_logs(ed_ctx, lg):
     assert (res2.x, res2.y) == (res.x, res.y)
 
 
+def test_window_shards_combine(ed_ctx):
+    """Window shards of the Edwards MSM (msm_window_sums) recombine to the full result (msm_combine)."""
+    pts, _ = O.random_points_ed377("gpu/ed/shard", 200)
+    sc = O.prng_ints("gpu/ed/shard/s", 200, E.q)
+    full, info = run(ed_ctx, sc, pts, 9)
+    K = info["K"]
+    sb = O.scalars_to_bytes(sc)
+    parts = b"".join(ed_ctx.window_sums(sb, 200, lo, min(K, lo + 5), c=9)[0] for lo in range(0, K, 5))
+    res = ed_ctx.combine(parts, K, 9)
+    assert (res.x, res.y) == full == O.msm_basic_te(sc, pts, c=9)
+
+
 def test_reference_shaped_api():
     from montgomery_amd.api import ED_ON_BLS12_377_PARAMS, TwistedEdwards, compute_msm_ed
 
