@@ -113,7 +113,7 @@ struct msm_ctx {
     b.cap = want;
   }
   void release(DevBuf& b) {
-    if (b.p) hipFree(b.p);
+    if (b.p) (void)hipFree(b.p);   // teardown paths: nothing useful to do with an error here
     b.p = nullptr;
     b.cap = 0;
   }
@@ -918,20 +918,20 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
 
 void msm_ctx_destroy(msm_ctx* ctx) {
   if (!ctx) return;
-  hipSetDevice(ctx->device);
-  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->errflag, &ctx->misc}) ctx->release(*b);
   for (auto& w : ctx->ws) {
-    if (w.stream) hipStreamSynchronize(w.stream);
+    if (w.stream) (void)hipStreamSynchronize(w.stream);
     for (DevBuf* b : w.all) ctx->release(*b);
-    if (w.h_info) hipHostFree(w.h_info);
-    if (w.h_part) hipHostFree(w.h_part);
-    for (auto& e : w.ev) hipEventDestroy(e);
-    if (w.stream) hipStreamDestroy(w.stream);
+    if (w.h_info) (void)hipHostFree(w.h_info);
+    if (w.h_part) (void)hipHostFree(w.h_part);
+    for (auto& e : w.ev) (void)hipEventDestroy(e);
+    if (w.stream) (void)hipStreamDestroy(w.stream);
   }
-  if (ctx->h_info) hipHostFree(ctx->h_info);
-  for (auto& e : ctx->ev) hipEventDestroy(e);
-  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  if (ctx->h_info) (void)hipHostFree(ctx->h_info);
+  for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 

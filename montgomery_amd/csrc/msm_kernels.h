@@ -181,7 +181,6 @@ MSM_DEV bool words8_ge(const uint32_t (&a)[8], const uint32_t* q) {
 template <class CV>
 __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts, const uint32_t* scalars, uint32_t n,
                                                 int c, int k_total, int k_lo, int k_cnt, int glv) {
-  using F = typename CV::F;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -933,7 +932,6 @@ __global__ void __launch_bounds__(256) k_test_batch_inverse(uint32_t* out, const
 // out: n x 10 words: |s0| (4), |s1| (4), neg0, neg1
 template <class CV>
 __global__ void __launch_bounds__(256) k_test_glv(uint32_t* out, const uint32_t* scalars, uint32_t n) {
-  using F = typename CV::F;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
