@@ -137,7 +137,7 @@ enum { MSM_OP_MUL = 0, MSM_OP_SQR = 1, MSM_OP_ADD = 2, MSM_OP_SUB = 3, MSM_OP_IN
  * src/field-msm.ts:86-123. */
 int msm_test_fp(msm_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, uint64_t n);
 /* `batchInverse` (src/wasm/inverse.ts:220-271): n Montgomery-form elements (48-byte words, non-zero) inverted with
- * one field inversion per `per_lane` consecutive elements (Montgomery's trick); base field of the Weierstrass curves. */
+ * one field inversion per `per_lane` consecutive elements (Montgomery's trick). */
 int msm_test_batch_inverse(msm_ctx* ctx, const uint8_t* xs, uint8_t* out, uint64_t n, uint32_t per_lane);
 /* GLV `decompose` (src/wasm/glv.ts:68-169) of n 32-byte scalars: out = n x 40 bytes
  * |s0| (16 B LE) || |s1| (16 B LE) || neg0 (u32) || neg1 (u32). */

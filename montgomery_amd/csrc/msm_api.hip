@@ -1246,16 +1246,20 @@ int msm_test_fp(msm_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_
 
 int msm_test_batch_inverse(msm_ctx* ctx, const uint8_t* xs, uint8_t* out, uint64_t n, uint32_t per_lane) {
   if (!ctx || !xs || !out || per_lane == 0) return fail(ctx, MSM_ERR_ARG, "msm_test_batch_inverse: bad argument");
-  if (ctx->is_te()) return fail(ctx, MSM_ERR_ARG, "msm_test_batch_inverse: BLS12-377 base field only");
   try {
     HIPCHK(hipSetDevice(ctx->device));
-    ctx->ensure(ctx->misc, n * 96 + 64);
+    const size_t nb = ctx->is_te() ? 32 : 48;
+    ctx->ensure(ctx->misc, n * 2 * nb + 64);
     uint8_t* d = (uint8_t*)ctx->misc.p;
-    HIPCHK(hipMemcpyAsync(d, xs, n * 48, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d, xs, n * nb, hipMemcpyHostToDevice, ctx->stream));
     uint64_t lanes = (n + per_lane - 1) / per_lane;
-    W_LAUNCH(ctx, k_test_batch_inverse, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (uint32_t*)(d + n * 48), (const uint32_t*)d, (uint32_t)n, per_lane);
-    HIPCHK(hipMemcpyAsync(out, d + n * 48, n * 48, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->is_te())
+      hipLaunchKernelGGL((k_test_batch_inverse<te::CvEdField>), dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, ctx->stream,
+                         (uint32_t*)(d + n * nb), (const uint32_t*)d, (uint32_t)n, per_lane);
+    else
+      W_LAUNCH(ctx, k_test_batch_inverse, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, ctx->stream,
+                         (uint32_t*)(d + n * nb), (const uint32_t*)d, (uint32_t)n, per_lane);
+    HIPCHK(hipMemcpyAsync(out, d + n * nb, n * nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
   } catch (const HipFail& f) {

@@ -913,19 +913,19 @@ __global__ void __launch_bounds__(256) k_test_batch_inverse(uint32_t* out, const
   fe_set_one<F>(acc);
   for (uint64_t i = beg; i < end; i++) {            // out[i] temporarily holds the prefix product before x_i
     fe_reduce_2p<F>(acc);
-    fe_store<F>(out + i * NW, acc);
-    fe_load<F>(x, xs + i * NW);
+    fe_store<F>(out + i * F::NW, acc);
+    fe_load<F>(x, xs + i * F::NW);
     fe_mul<F>(acc, acc, x);
   }
   Fe<F> inv, pre, r;
   fe_inv<F>(inv, acc);
   for (uint64_t i = end; i-- > beg;) {
-    fe_load<F>(pre, out + i * NW);
-    fe_load<F>(x, xs + i * NW);
+    fe_load<F>(pre, out + i * F::NW);
+    fe_load<F>(x, xs + i * F::NW);
     fe_mul<F>(r, inv, pre);
     fe_mul<F>(inv, inv, x);
     fe_reduce_2p<F>(r);
-    fe_store<F>(out + i * NW, r);
+    fe_store<F>(out + i * F::NW, r);
   }
 }
 

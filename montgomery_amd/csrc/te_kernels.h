@@ -25,6 +25,7 @@ namespace msm {
 namespace te {
 
 using FT = Fp253;
+struct CvEdField { using F = Fp253; };   // for the field-only test kernels of msm_kernels.h (k_test_batch_inverse)
 constexpr int TL = FT::NL;   // 9
 constexpr int TW = FT::NW;   // 8
 constexpr int TE_ROW_WORDS = 32;

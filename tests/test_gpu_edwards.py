@@ -61,6 +61,8 @@ def test_fp253_operators(ed_ctx):
     inv = ed_ctx.test_fp(_lib.OP_INV, mont)
     back = ed_ctx.test_fp(_lib.OP_FROM_MONT, inv)
     assert all(fb(back, i) == pow(v, -1, P_MOD) for i, v in enumerate(nz))
+    for per_lane in (1, 7, 100):   # batchInverse, src/wasm/inverse.ts:220-271
+        assert ed_ctx.test_batch_inverse(mont, per_lane) == inv, per_lane
     assert ed_ctx.test_fp(_lib.OP_INV_FERMAT, mont[: 32 * 64]) == inv[: 32 * 64]
     assert ed_ctx.test_fp(_lib.OP_INV_KALISKI, mont[: 32 * 64]) == inv[: 32 * 64]
 
