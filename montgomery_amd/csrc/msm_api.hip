@@ -151,25 +151,24 @@ int fail_hip(msm_ctx* ctx, const HipFail& f) {
   return fail(ctx, MSM_ERR_HIP, "HIP error %d (%s) at msm_api.hip:%d: %s", (int)f.e, hipGetErrorString(f.e), f.line, f.what);
 }
 
-// GPU-tuned window size (the reference's table, src/msm-common.ts:25-41, was tuned for 16 CPU
-// threads and copies points; here the trade is 2N*K pair additions against K*2^(c-1) buckets to
-// reduce, with histogram/scatter counters that must stay cache friendly).
+// GPU-tuned window size (the reference's table, src/msm-common.ts:25-41, was tuned for 16 CPU threads and copies
+// points).  Weierstrass + GLV (b + 1 = 127 or 128 bits): measured over N = 2^4 .. 2^26 (tools/small_sizes.py), c = 16
+// (K = 8, no degenerate top window, one window's counters fit the LDS) wins from N = 2^12 up -- by 20 % over c = 13
+// at 2^14 .. 2^18, where a smaller window mostly buys more rounds of fixed latency -- and c = 8 below.
+// Twisted Edwards (b + 1 = 252, no inversion per round): a cost model over the window sizes whose top window is not
+// degenerate, ~9 multiplications per pair addition against ~64 per bucket; its picks are within 3 % of the best
+// measured ones.
 int pick_window(bool te, uint64_t n, int glv_max_bits) {
-  // candidates whose top window is not degenerate (bits left for the last digit close to c):
-  //   Weierstrass + GLV, b + 1 = 127: c = 16 (K = 8, 15 bits), 13 (K = 10, 10 bits), 10, 8, 5, 4
-  //   twisted Edwards, b + 1 = 252:   c = 16 (K = 16, 12 bits), 14 (K = 18), 12 (K = 21), 9, 7, 6, 4 (exact)
-  // cost model in field multiplications: ~8 per pair addition (9 extended), ~64 per bucket (two projective
-  // additions on poorly filled lanes).  c <= 16 keeps one window's counters inside the 160 KB LDS for the sort.
-  static const int cand_w[] = {4, 5, 8, 10, 13, 16};
+  if (!te) return n >= 4096 ? 16 : 8;
   static const int cand_te[] = {4, 6, 7, 9, 12, 14, 16};
-  const int b1 = te ? 252 : glv_max_bits + 1;
-  const double entries = te ? (double)n : 2.0 * (double)n;
+  const int b1 = 252;
+  (void)glv_max_bits;
   int best = 4;
   double best_cost = 1e300;
-  for (int i = 0; i < (te ? 7 : 6); i++) {
-    int c = te ? cand_te[i] : cand_w[i];
+  for (int i = 0; i < 7; i++) {
+    int c = cand_te[i];
     int K = (b1 + c - 1) / c;
-    double cost = entries * K * 8.0 + (double)K * (double)(1u << (c - 1)) * 64.0;
+    double cost = (double)n * K * 8.0 + (double)K * (double)(1u << (c - 1)) * 64.0;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;
