@@ -288,7 +288,8 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   // Big buckets (>= 1024 entries) take G = mean / 16: half the pads (1/32 instead of 1/16 of all slots are identity
   // pairs that occupy a lane for nothing) for twice the k_bucket_finish work, which is negligible there.
   uint64_t mean = std::max<uint64_t>(1, two_n / L);
-  const uint64_t per_bucket_left = mean >= 1024 ? 16 : 8;
+  uint64_t per_bucket_left = mean >= 1024 ? 16 : 8;
+  if (const char* e = getenv("MSM_PBL")) per_bucket_left = std::max(1, atoi(e));
   uint32_t logG = 1;
   while (logG < 10 && (1ull << (logG + 1)) * per_bucket_left <= mean) logG++;
 
@@ -449,7 +450,10 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
 
   // accumulation tree
   // Weierstrass: tail rounds run only until no bucket holds more than FINISH_MAX elements; k_bucket_finish ends it
-  const uint32_t FINISH_MAX = 32;
+  uint32_t FINISH_MAX = 32;
+  if (const char* e = getenv("MSM_FINISH_MAX")) FINISH_MAX = (uint32_t)std::max(1, atoi(e));
+  uint32_t tail_min_pairs = 1u << 21;
+  if (const char* e = getenv("MSM_TAIL_MIN")) tail_min_pairs = (uint32_t)std::max(1, atoi(e));
   const bool use_finish = true;
   int r_stop = RT;
   if (use_finish) {
@@ -458,7 +462,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     uint32_t cap_elems = (max_bucket + (1u << logG) - 1) >> logG;   // largest bucket after the regular rounds
     r_stop = 0;
     while (r_stop < RT &&
-           (((cap_elems + (1u << r_stop) - 1) >> r_stop) > FINISH_MAX || w.h_info[3 + r_stop + 1] >= (1u << 21)))
+           (((cap_elems + (1u << r_stop) - 1) >> r_stop) > FINISH_MAX || w.h_info[3 + r_stop + 1] >= tail_min_pairs))
       r_stop++;
   }
   // outputs alternate between two buffers: size each for the largest round it receives
@@ -583,6 +587,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   // buckets per lane: enough lanes to fill the chip, but never more than 16 buckets deep (2 additions each)
   uint32_t TC = 2;
   while (TC < 16 && nb / TC > 65536) TC *= 2;
+  if (const char* e = getenv("MSM_TC")) TC = (uint32_t)std::max(1, atoi(e));
   TC = std::min<uint32_t>(TC, L);
   uint32_t nchunks = (L + TC - 1) / TC;
   // bit-sliced weighting (Weierstrass path, enough chunks to matter, TC a power of two)

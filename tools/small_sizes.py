@@ -4,7 +4,8 @@ sys.path.insert(0, "/root/repo")
 from montgomery_amd.api import MsmContext
 curve = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 ctx = MsmContext(curve)
-cands = (4, 6, 8, 10, 11, 13, 16) if curve != 1 else (4, 6, 7, 9, 12, 14, 16)
+import os
+cands = tuple(int(x) for x in os.environ['CANDS'].split(',')) if os.environ.get('CANDS') else ((4, 6, 8, 10, 11, 13, 16) if curve != 1 else (4, 6, 7, 9, 12, 14, 16))
 for lg in (4, 6, 8, 10, 12, 13, 14, 15, 16, 17, 18, 19):
     n = 1 << lg
     ctx.generate_points(n, seed=7)
