@@ -313,7 +313,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   if (lds_sort) {
     // big inputs: finer slices also keep the round-1 gathers of neighbouring lanes inside one Infinity-Cache-sized
     // range of point rows (measured: 193 -> 183 ms at 2^26); small inputs: fewer, larger blocks (less fixed cost)
-    uint64_t mult = two_n >= (1ull << 24) ? 8 : 2;
+    uint64_t mult = two_n >= (1ull << 27) ? 8 : two_n >= (1ull << 24) ? 4 : 2;   // measured 2^21 .. 2^26
     if (const char* e = getenv("MSM_SORTB_MULT")) mult = std::max(1, atoi(e));
     uint64_t want = std::max<uint64_t>(1, (mult * ctx->n_cu + kc - 1) / kc);
     uint64_t maxb = std::max<uint64_t>(1, two_n / 8192);
@@ -775,9 +775,9 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   // workspaces/streams overlap one group's sort and bucket reduction with the other's accumulation
   int wpg = std::min(windows_per_group(ctx, n, pl), 128);
   const int nwin = k_hi - k_lo;
-  // measured on MI355X: two groups win ~7 % at 2^26 (198 vs 213 ms); below ~2^23 the fixed per-group latencies
-  // (read-backs, bucket reduction depth) cost more than the overlap returns
-  int want_groups = (nwin >= 2 && n >= (1ull << 23)) ? 2 : 1;
+  // measured on MI355X: two groups win 14 % at 2^23 / 2^24, 3 % at 2^22, nothing at 2^21 -- below that the fixed
+  // per-group latencies (read-backs, bucket reduction depth) cost more than the overlap returns
+  int want_groups = (nwin >= 2 && n >= (1ull << 22)) ? 2 : 1;
   if (const char* e = getenv("MSM_GROUPS")) want_groups = std::max(1, atoi(e));
   wpg = std::max(1, std::min(wpg, (nwin + want_groups - 1) / want_groups));
   struct Group {
