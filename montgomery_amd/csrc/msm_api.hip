@@ -214,14 +214,16 @@ struct RoundGeom {
 // gather: round 1 (random row reads: wants two waves per SIMD to cover the latency).  The other rounds read
 // coalesced, prefetched planes; a lone wave already gets ~88 % of a SIMD's issue rate, and every lane pays one field
 // inversion (~19 pair additions' worth) per round, so small rounds run better on half as many lanes with twice the
-// steps (2^18: 2.62 -> 2.45 ms; neutral at 2^20; round 1 at 2^22 would lose 60 %).
+// steps (2^18: 2.62 -> 2.45 ms; neutral at 2^20, 1 % at 2^22; round 1 at 2^22 would lose 60 %).
 // lone: the launch has the GPU to itself (a window group of one window with no second group beside it -- the
 // 8-GPU shard).  All waves of one resident batch then move through the memory-heavy forward sweep and the ALU-heavy
 // backward sweep in step; four batches of 128 steps instead of one of 512 stagger the phases (2^26, one window:
 // 31.5 -> 29.2 ms).  With two groups on two streams the other stream already fills the gaps and 512 is better.
 RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather = false, bool lone = false) {
   uint64_t target = (uint64_t)ctx->n_cu * 4 * 2 * 64;  // two waves per SIMD
-  if (!gather && n_out < target * 40) target /= 2;
+  uint64_t half_below = 200;  // steps at full width below which a non-gather round runs on one wave per SIMD
+  if (const char* e = getenv("MSM_HALF_BELOW")) half_below = (uint64_t)std::max(0, atoi(e));
+  if (!gather && n_out < target * half_below) target /= 2;
   uint32_t max_steps = (lone && n_out >= target * 512) ? 128 : 512;
   if (const char* e = getenv("MSM_MAX_STEPS")) max_steps = (uint32_t)std::max(1, atoi(e));       // tuning knobs
   if (const char* e = getenv("MSM_TARGET_WAVES")) target = (uint64_t)ctx->n_cu * 4 * 64 * std::max(1, atoi(e));
