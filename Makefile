@@ -8,7 +8,7 @@ HIPFLAGS := -O3 -pthread -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unus
 BUILD := build
 CURVES := CvBls377 CvBls381 CvPallas
 CURVE_OBJS := $(CURVES:%=$(BUILD)/kernels_%.o)
-KHDRS := $(CSRC)/msm_kernels.h $(CSRC)/msm_gen_kernels.h $(CSRC)/kernel_inst.h $(CSRC)/field.h $(CSRC)/packed.h $(CSRC)/curve.h \
+KHDRS := $(CSRC)/msm_kernels.h $(CSRC)/batch_add.h $(CSRC)/msm_gen_kernels.h $(CSRC)/kernel_inst.h $(CSRC)/field.h $(CSRC)/packed.h $(CSRC)/curve.h \
          $(CSRC)/glv.h $(CSRC)/constants_gen.h
 
 # the curve-templated kernels compile once per curve, in parallel with the host pipeline
@@ -52,3 +52,12 @@ $(NAPI): napi/msm_addon.cc include/msm_hip.h $(LIB)
 demo: examples/msm_demo
 examples/msm_demo: examples/msm_demo.c include/msm_hip.h $(LIB)
 	gcc -O2 -Wall -Iinclude examples/msm_demo.c -Lmontgomery_amd -lmsm_hip -Wl,-rpath,'$$ORIGIN/../montgomery_amd' -o examples/msm_demo
+
+# A/B experiment builds of the extension: make ab NAME=w2 EXTRA="-DMSM_BA_WAVES=2"  ->  ab_builds/libmsm_w2.so
+# (timed against each other by tools/ab_time.py through MSM_HIP_LIB; ab_builds/ is not tracked)
+ab:
+	@mkdir -p ab_builds/$(NAME)
+	for c in $(CURVES); do $(HIPCC) $(HIPFLAGS) $(EXTRA) -DMSM_CURVE_TU=$$c -c $(CSRC)/kernels_curve.hip -o ab_builds/$(NAME)/kernels_$$c.o & done; \
+	$(HIPCC) $(HIPFLAGS) $(EXTRA) -c $(CSRC)/msm_api.hip -o ab_builds/$(NAME)/msm_api.o; wait
+	$(HIPCC) --offload-arch=$(ARCH) -shared -pthread ab_builds/$(NAME)/*.o -o ab_builds/libmsm_$(NAME).so
+	rm -rf ab_builds/$(NAME)

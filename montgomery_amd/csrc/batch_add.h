@@ -1,0 +1,454 @@
+// k_batch_add: one round of the bucket accumulation tree -- batched-affine pair additions with one shared field
+// inversion per lane (Montgomery's trick).  Reference: batchAddNew / batchAddUnsafeNew, src/curve-affine.ts:376-522
+// (denominators and prefix products :484-505, shared inversion src/wasm/inverse.ts:220-271, back-substitution
+// :506-516), addAffine src/wasm/curve.ts:32-58, Affine.double src/curve-affine.ts:90-109; the round structure is
+// src/msm-batched-affine.ts:243-282.
+//
+//   output element e = input element 2e + input element 2e+1   (affine; every edge case handled)
+//   lane t owns the pairs e = t + i*T, i < steps, and shares ONE fe_inv among them:
+//     forward sweep : pre_i = den_0 ... den_(i-1) to the scratch, acc *= den_i           (1 M per pair)
+//     backward sweep: d = inv * pre_i (= 1 / den_i), inv *= den_i, m = num * d, x3 = m^2 - x1 - x2,
+//                     y3 = m (x1 - x3) - y1                                              (4 M + 1 S per pair)
+//
+// Shape of the code (round 2): the kernel is issue-bound on the vector ALU, whose cost per wave-instruction depends
+// on the instruction class AND on the resident waves per SIMD (tools/ubench_int2.hip, profiles/r02_ubench_int.txt):
+// v_mad_u64_u32 5.6 / 5.3 cycles at 2 / 4 waves, carry-chain and three-source instructions the same, plain two-source
+// 32-bit instructions 3.8 / 2.8.  Hence
+//   * the lane state is kept small enough for more resident waves (launch bounds below): no register double buffer of
+//     the next pair; loads are issued as soon as their registers die and the other waves of the SIMD cover the latency;
+//   * all lanes run the common case (two finite points, different x) straight-line; identity operands, P + P and
+//     P - P are patched in wave-uniform side branches that almost no wave enters;
+//   * linear operations stay on packed 32-bit words with carry chains and lazily reduced results
+//     (a - b + p instead of a conditional add), multiplication results are only reduced when the rare excess
+//     over p actually occurs (a product is < p (1 + 2^-11));
+//   * addresses are a uniform base (SALU) plus a per-lane 32-bit offset.
+#pragma once
+#include "curve.h"
+#include "packed.h"
+
+namespace msm {
+
+enum : int { MODE_GATHER = 0, MODE_REGULAR = 1, MODE_SEARCH = 2 };
+
+struct BatchArgs {
+  const uint32_t* points;   // MODE_GATHER: point rows
+  const uint32_t* slots;    // MODE_GATHER: payload slots, pair e = slots[2e], slots[2e+1]
+  const uint4* in;          // MODE_REGULAR / MODE_SEARCH: input planes
+  uint64_t in_cap;
+  uint4* out;               // output planes
+  uint64_t out_cap;
+  uint32_t* scratch;        // prefix products: per step 3 uint4 planes + 1 dword plane of T lanes each (52 B per pair)
+  uint64_t n_out;           // number of output elements
+  uint32_t steps;
+  const uint32_t* desc;     // MODE_SEARCH: operand descriptors from k_tail_desc
+};
+
+constexpr int BA_THREADS = 256;
+// Phase fence: hipcc's scheduler otherwise interleaves independent multiplications of one step (inv * den with num * d,
+// the unpacking of the next operands with the running product), which doubles the live accumulators and costs a
+// resident wave.  Nothing crosses it.
+#define BA_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef BA_X_NOMUL   // experiment: memory traffic only (results are garbage)
+#define BA_MUL(r, x, y) fe_add<F>(r, x, y)
+#define BA_SQR(r, x) fe_add<F>(r, x, x)
+#define BA_INV(r, x) r = x
+#else
+#define BA_MUL(r, x, y) fe_mul<F>(r, x, y)
+#define BA_SQR(r, x) fe_sqr<F>(r, x)
+#define BA_INV(r, x) fe_inv<F>(r, x)
+#endif
+#ifndef MSM_BA_WAVES
+#define MSM_BA_WAVES 2      // resident waves per SIMD the register allocation is held to (2: 256 VGPRs, 3: 168 + LDS parking)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// packed-word helpers.  gfx9 allows ONE scalar or literal operand per VALU instruction and the carry-in of a chain is
+// one, so the modulus cannot ride the chains as a literal: it enters through a plain v_and with the borrow mask
+// (pk_set_p_masked, packed.h).
+// ---------------------------------------------------------------------------------------------------------------
+
+// y -> p - y where `flip` (gather mode: the sign bit of the payload), else unchanged:  (y ^ m) + ((p + 1) & m).
+// A zero y becomes p (congruent); such a value is reduced before it is stored or compared.
+template <class F>
+__device__ __forceinline__ void pk_cond_neg(Pk& y, bool flip) {
+  const uint32_t m = flip ? 0xFFFFFFFFu : 0u;
+  Pk t;
+#pragma unroll
+  for (int j = 0; j < NW; j++) {
+    y.w[j] ^= m;
+    t.w[j] = (j == 0 ? F::PW[0] + 1u : F::PW[j]) & m;   // p is odd: p + 1 changes word 0 only
+  }
+  pk_add(y, y, t);
+}
+
+// the (rare) excess of a Montgomery product over p: r < p (1 + 2^-11) -> [0, p).  One compare on the top word decides
+// for the whole wave; the subtraction itself runs for a wave in ~30 (2^-11 x 64 lanes).
+template <class F>
+__device__ __forceinline__ void pk_reduce_product(Pk& r) {
+  if (__any(r.w[11] >= F::PW[11])) pk_cond_sub_p<F>(r);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// memory access: planes ("piece" c of element e at uint4 index c * cap + e) and point rows
+// ---------------------------------------------------------------------------------------------------------------
+
+// 48-byte coordinate = 3 pieces, `stride` bytes apart, starting at byte `off` (32-bit, per lane) from the uniform `base`
+__device__ __forceinline__ void ba_load3(Pk& w, const char* base, uint32_t off, uint64_t stride) {
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const uint4 v = *reinterpret_cast<const uint4*>(base + (uint64_t)j * stride + off);
+    w.w[4 * j] = v.x; w.w[4 * j + 1] = v.y; w.w[4 * j + 2] = v.z; w.w[4 * j + 3] = v.w;
+  }
+}
+__device__ __forceinline__ void ba_load3_wide(Pk& w, const char* p) {   // per-lane 64-bit address, consecutive pieces
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const uint4 v = reinterpret_cast<const uint4*>(p)[j];
+    w.w[4 * j] = v.x; w.w[4 * j + 1] = v.y; w.w[4 * j + 2] = v.z; w.w[4 * j + 3] = v.w;
+  }
+}
+__device__ __forceinline__ void ba_store3(char* base, uint32_t off, uint64_t stride, const Pk& w) {
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+    *reinterpret_cast<uint4*>(base + (uint64_t)j * stride + off) = make_uint4(w.w[4 * j], w.w[4 * j + 1], w.w[4 * j + 2], w.w[4 * j + 3]);
+}
+
+// where the two operands of one pair live
+template <int MODE>
+struct PairLoc;
+template <>
+struct PairLoc<MODE_REGULAR> {   // elements 2e, 2e + 1: uniform base of the step + 32 t bytes
+  const char* base;
+  __device__ __forceinline__ bool absentA() const { return false; }
+  __device__ __forceinline__ bool absentB() const { return false; }
+};
+template <>
+struct PairLoc<MODE_SEARCH> {    // elements idx, idx + 1 from the descriptor
+  uint64_t a;                    // byte offset of element idx inside a plane
+  bool b_absent, skip;
+  __device__ __forceinline__ bool absentA() const { return skip; }
+  __device__ __forceinline__ bool absentB() const { return b_absent; }
+};
+template <>
+struct PairLoc<MODE_GATHER> {    // two point rows named by the slot payloads
+  const char* pa;                // 128-byte line [x | y | pad] of the operand (row 0 when absent)
+  const char* pb;
+  uint32_t flags;                // 1: A absent, 2: B absent, 4: negate A, 8: negate B
+  __device__ __forceinline__ bool absentA() const { return flags & 1u; }
+  __device__ __forceinline__ bool absentB() const { return flags & 2u; }
+};
+
+template <int MODE>
+__device__ __forceinline__ void ba_locate(PairLoc<MODE>& L, const BatchArgs& a, uint32_t i, uint64_t T, uint32_t t, bool active);
+
+template <>
+__device__ __forceinline__ void ba_locate<MODE_REGULAR>(PairLoc<MODE_REGULAR>& L, const BatchArgs& a, uint32_t i, uint64_t T, uint32_t,
+                                                         bool) {
+  L.base = reinterpret_cast<const char*>(a.in + 2ull * i * T);
+}
+template <>
+__device__ __forceinline__ void ba_locate<MODE_SEARCH>(PairLoc<MODE_SEARCH>& L, const BatchArgs& a, uint32_t i, uint64_t T, uint32_t t,
+                                                        bool active) {
+  const uint32_t d = active ? a.desc[(uint64_t)i * T + t] : 0u;
+  L.a = (uint64_t)(d >> 1) * 16;
+  L.b_absent = (d & 1u) == 0;
+  L.skip = !active;
+}
+template <>
+__device__ __forceinline__ void ba_locate<MODE_GATHER>(PairLoc<MODE_GATHER>& L, const BatchArgs& a, uint32_t i, uint64_t T, uint32_t t,
+                                                        bool active) {
+  uint2 pp = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  if (active) pp = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.slots) + 8ull * i * T + 8u * t);
+  const bool aa = pp.x == 0xFFFFFFFFu, bb = pp.y == 0xFFFFFFFFu;
+  // absent operands read row 0 (valid memory) and are then ignored: no divergent loads
+#ifdef BA_X_ROWMASK   // experiment: all gathers inside a 256 MB window of the table (wrong sums, timing of perfect locality)
+  pp.x &= (BA_X_ROWMASK << 2) | 3u; pp.y &= (BA_X_ROWMASK << 2) | 3u;
+#endif
+  const uint64_t oa = aa ? 0 : (uint64_t)(pp.x >> 2) * 256 + ((pp.x & 2u) ? 128 : 0);
+  const uint64_t ob = bb ? 0 : (uint64_t)(pp.y >> 2) * 256 + ((pp.y & 2u) ? 128 : 0);
+  L.pa = reinterpret_cast<const char*>(a.points) + oa;
+  L.pb = reinterpret_cast<const char*>(a.points) + ob;
+  L.flags = (aa ? 1u : 0u) | (bb ? 2u : 0u) | ((pp.x & 1u) ? 4u : 0u) | ((pp.y & 1u) ? 8u : 0u);
+}
+
+template <int MODE>
+__device__ __forceinline__ void ba_load_x(Pk& x1, Pk& x2, const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t) {
+  if constexpr (MODE == MODE_GATHER) {
+    ba_load3_wide(x1, L.pa);
+    ba_load3_wide(x2, L.pb);
+  } else if constexpr (MODE == MODE_REGULAR) {
+    ba_load3(x1, L.base, 32u * t, a.in_cap * 16);
+    ba_load3(x2, L.base + 16, 32u * t, a.in_cap * 16);
+  } else {
+    const char* p = reinterpret_cast<const char*>(a.in) + L.a;
+    const uint64_t s = a.in_cap * 16;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const uint4 v = *reinterpret_cast<const uint4*>(p + j * s), u = *reinterpret_cast<const uint4*>(p + j * s + (L.b_absent ? 0 : 16));
+      x1.w[4 * j] = v.x; x1.w[4 * j + 1] = v.y; x1.w[4 * j + 2] = v.z; x1.w[4 * j + 3] = v.w;
+      x2.w[4 * j] = u.x; x2.w[4 * j + 1] = u.y; x2.w[4 * j + 2] = u.z; x2.w[4 * j + 3] = u.w;
+    }
+  }
+}
+
+// y coordinates; gather mode applies the sign bit of the payload: y -> p - y (a zero y becomes p: congruent, and
+// only ever stored after ba_canonical_y)
+template <class F, int MODE>
+__device__ __forceinline__ void ba_load_y(Pk& y1, Pk& y2, const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t) {
+  if constexpr (MODE == MODE_GATHER) {
+    ba_load3_wide(y1, L.pa + 48);
+    ba_load3_wide(y2, L.pb + 48);
+    pk_cond_neg<F>(y1, L.flags & 4u);
+    pk_cond_neg<F>(y2, L.flags & 8u);
+  } else if constexpr (MODE == MODE_REGULAR) {
+    const char* b = L.base + 3 * a.in_cap * 16;
+    ba_load3(y1, b, 32u * t, a.in_cap * 16);
+    ba_load3(y2, b + 16, 32u * t, a.in_cap * 16);
+  } else {
+    const uint64_t s = a.in_cap * 16;
+    const char* p = reinterpret_cast<const char*>(a.in) + L.a + 3 * s;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const uint4 v = *reinterpret_cast<const uint4*>(p + j * s), u = *reinterpret_cast<const uint4*>(p + j * s + (L.b_absent ? 0 : 16));
+      y1.w[4 * j] = v.x; y1.w[4 * j + 1] = v.y; y1.w[4 * j + 2] = v.z; y1.w[4 * j + 3] = v.w;
+      y2.w[4 * j] = u.x; y2.w[4 * j + 1] = u.y; y2.w[4 * j + 2] = u.z; y2.w[4 * j + 3] = u.w;
+    }
+  }
+}
+
+// prefix product of one (step, lane): 13 limbs as 3 uint4 + 1 dword, each in its own plane of T lanes
+__device__ __forceinline__ void ba_store_pre(const BatchArgs& a, uint32_t i, uint64_t T, uint32_t t, const uint32_t (&l)[NL]) {
+  char* sb = reinterpret_cast<char*>(a.scratch) + (uint64_t)i * T * 52;
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+    *reinterpret_cast<uint4*>(sb + (uint64_t)j * T * 16 + 16u * t) = make_uint4(l[4 * j], l[4 * j + 1], l[4 * j + 2], l[4 * j + 3]);
+  *reinterpret_cast<uint32_t*>(sb + 48ull * T + 4u * t) = l[12];
+}
+__device__ __forceinline__ void ba_load_pre(uint32_t (&l)[NL], const BatchArgs& a, uint32_t i, uint64_t T, uint32_t t) {
+  const char* sb = reinterpret_cast<const char*>(a.scratch) + (uint64_t)i * T * 52;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const uint4 v = *reinterpret_cast<const uint4*>(sb + (uint64_t)j * T * 16 + 16u * t);
+    l[4 * j] = v.x; l[4 * j + 1] = v.y; l[4 * j + 2] = v.z; l[4 * j + 3] = v.w;
+  }
+  l[12] = *reinterpret_cast<const uint32_t*>(sb + 48ull * T + 4u * t);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the denominator of one pair and what kind of pair it is
+// ---------------------------------------------------------------------------------------------------------------
+
+// bit 0: output is the identity, bit 1: output is operand A, bit 2: output is operand B, bit 3: doubling, bit 4: lane idle
+enum : uint32_t { BA_ZERO = 1, BA_COPY_A = 2, BA_COPY_B = 4, BA_DOUBLE = 8, BA_SKIP = 16 };
+
+// Common case first: den = x2 - x1 + p for every lane, straight-line.  Lanes with an identity operand, an idle lane or
+// equal x get den = 1 (P + P: den = 2 y) in a branch that a wave takes only if one of its lanes needs it.
+// Forward and backward sweep call this with the same inputs, so both see the same den.  HAVE_Y: the caller already
+// holds the pair's y coordinates (backward sweep); otherwise they are loaded in the rare equal-x case only.
+template <class F, int MODE, bool HAVE_Y>
+__device__ __forceinline__ uint32_t ba_denominator(Fe<F>& den, const Pk& x1, const Pk& x2, const Pk* y1p, const Pk* y2p,
+                                                    const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t, bool active) {
+  bool same_x_out;
+  Pk dx;
+  {
+    Pk pm;
+    const uint32_t borrow = pk_sub(dx, x2, x1);
+    const bool z = pk_is_zero(dx);           // x1, x2 canonical (or the identity's all-ones): equal iff the words are
+    pk_set_p_masked<F>(pm, borrow);
+    pk_add(dx, dx, pm);                      // (x2 - x1) mod p
+    pk_unpack<F>(den, dx);
+    same_x_out = z;
+  }
+  const bool inf1 = L.absentA() || x1.w[NW - 1] == INF_WORD, inf2 = L.absentB() || x2.w[NW - 1] == INF_WORD;
+  const bool same_x = same_x_out;
+  uint32_t kind = 0;
+  if (__any(!active || inf1 || inf2 || same_x)) {
+    if (!active) kind = BA_SKIP | BA_ZERO;
+    else if (inf1 && inf2) kind = BA_ZERO;
+    else if (inf2) kind = BA_COPY_A;
+    else if (inf1) kind = BA_COPY_B;
+    else if (same_x) {
+      Pk y1, y2;
+      if (HAVE_Y) { y1 = *y1p; y2 = *y2p; }
+      else ba_load_y<F, MODE>(y1, y2, L, a, t);
+      pk_cond_sub_p<F>(y1);   // gather mode: a negated zero is p
+      pk_cond_sub_p<F>(y2);
+      kind = (pk_equal(y1, y2) && !pk_is_zero(y1)) ? BA_DOUBLE : BA_ZERO;
+      if (kind == BA_DOUBLE) {
+        Fe<F> yl;
+        pk_unpack<F>(yl, y1);
+        fe_add<F>(den, yl, yl);
+      }
+    }
+    if (kind & ~BA_DOUBLE) fe_set_one<F>(den);
+  }
+  return kind;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------------------------
+
+template <class CV, int MODE>
+__global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArgs a) {
+  using F = typename CV::F;
+  const uint64_t T = (uint64_t)gridDim.x * BA_THREADS;
+  const uint32_t t = blockIdx.x * BA_THREADS + threadIdx.x;
+  const uint32_t steps = a.steps;
+  // lane t owns the pairs e = t + i * T; all lanes walk all `steps` steps (a uniform loop: the step's bases stay in
+  // SGPRs), lanes past the end of the round idle through it with den = 1 and no stores
+  auto is_active = [&](uint32_t i) { return (uint64_t)i * T + t < a.n_out; };
+
+  Fe<F> acc;
+  fe_set_one<F>(acc);
+
+  // ---- forward sweep: prefix products of the denominators ---------------------------------------
+  {
+    PairLoc<MODE> L;
+    Pk x1, x2;
+    ba_locate<MODE>(L, a, 0, T, t, is_active(0));
+    ba_load_x<MODE>(x1, x2, L, a, t);
+#pragma unroll 1
+    for (uint32_t i = 0; i < steps; i++) {
+      Fe<F> den;
+      ba_denominator<F, MODE, false>(den, x1, x2, nullptr, nullptr, L, a, t, is_active(i));
+      if (i + 1 < steps) {   // the next pair's x: its registers are free now, the multiplication covers the latency
+        ba_locate<MODE>(L, a, i + 1, T, t, is_active(i + 1));
+        ba_load_x<MODE>(x1, x2, L, a, t);
+      }
+      ba_store_pre(a, i, T, t, acc.l);
+      BA_FENCE();
+      BA_MUL(acc, acc, den);
+      BA_FENCE();
+    }
+  }
+
+  Fe<F> inv;
+  BA_INV(inv, acc);
+
+  // ---- backward sweep ------------------------------------------------------------------------
+  // Order inside one step (what is live where decides the register allocation, hence the resident waves):
+  //   d = inv * pre | den, num (all rare cases here, while little else is live) | x1, x2, y1 parked in LDS |
+  //   inv *= den | m = num * d | m^2 | x1, x2 back: x3 = m^2 - x1 - x2 | next prefix product requested |
+  //   y1 back: y3 = m (x1 - x3) - y1 | loads of the next pair | stores
+  // The three coordinates that are only needed again after three multiplications wait in the LDS (each lane its own
+  // 144 bytes, no barrier): 36 registers that the allocator would otherwise spill to scratch memory to stay under the
+  // launch bound.
+  {
+#if MSM_BA_WAVES >= 3
+    __shared__ uint4 park[9 * BA_THREADS];
+    auto park_put = [&](int slot, const Pk& v) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) park[(slot * 3 + j) * BA_THREADS + threadIdx.x] = make_uint4(v.w[4 * j], v.w[4 * j + 1], v.w[4 * j + 2], v.w[4 * j + 3]);
+    };
+    auto park_get = [&](Pk& v, int slot) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const uint4 q = park[(slot * 3 + j) * BA_THREADS + threadIdx.x];
+        v.w[4 * j] = q.x; v.w[4 * j + 1] = q.y; v.w[4 * j + 2] = q.z; v.w[4 * j + 3] = q.w;
+      }
+    };
+#else   // two waves per SIMD: 256 registers per lane, everything stays in registers
+    auto park_put = [&](int, const Pk&) {};
+    auto park_get = [&](Pk&, int) {};
+#endif
+    PairLoc<MODE> L, Ln;
+    Pk x1, x2, y1, y2, nx1, nx2;
+    Fe<F> pre, npre;
+    ba_locate<MODE>(L, a, steps - 1, T, t, is_active(steps - 1));
+    ba_load_x<MODE>(x1, x2, L, a, t);
+    ba_load_pre(pre.l, a, steps - 1, T, t);
+    ba_load_y<F, MODE>(y1, y2, L, a, t);
+    Ln = L;
+#pragma unroll 1
+    for (int i = (int)steps - 1; i >= 0; i--) {
+      const bool active = is_active((uint32_t)i);
+      Fe<F> d, den, num;
+      BA_MUL(d, inv, pre);                         // 1 / den_i
+      BA_FENCE();
+      const uint32_t kind = ba_denominator<F, MODE, true>(den, x1, x2, &y1, &y2, L, a, t, active);
+      {
+        Pk dy;
+        pk_sub_mod<F>(dy, y2, y1);                    // (y2 - y1) mod p (gather mode may hold y = p: the result stays in [0, p])
+        pk_unpack<F>(num, dy);
+      }
+      if (__any(kind & BA_DOUBLE)) {                  // P + P: num = 3 x^2
+        if (kind & BA_DOUBLE) {
+          Fe<F> xl, sq;
+          pk_unpack<F>(xl, x1);
+          fe_mul<F>(sq, xl, xl);
+          fe_add<F>(num, sq, sq);
+          fe_add<F>(num, num, sq);
+        }
+      }
+      park_put(0, x1);
+      park_put(1, x2);
+      park_put(2, y1);
+      asm volatile("" ::: "memory");                  // the parked values are re-read, not kept in registers
+      BA_FENCE();
+      BA_MUL(inv, inv, den);                       // strip den_i from the running inverse
+      BA_FENCE();
+      // The next pair's x and prefix product are requested here, three multiplications before they are needed:
+      // 37 registers that are free from now on (the widest point of the step, inv * den with d and num waiting, is behind)
+      if (i > 0) {
+        ba_locate<MODE>(Ln, a, (uint32_t)i - 1, T, t, is_active((uint32_t)i - 1));
+        ba_load_x<MODE>(nx1, nx2, Ln, a, t);
+        ba_load_pre(npre.l, a, (uint32_t)i - 1, T, t);
+      }
+      BA_FENCE();
+      Fe<F> m;
+      BA_MUL(m, num, d);
+      BA_FENCE();
+      Pk x3, y3;
+      {
+        Fe<F> mm;
+        BA_SQR(mm, m);
+        pk_pack<F>(x3, mm);                           // < p (1 + 2^-11)
+      }
+      BA_FENCE();
+      park_get(x1, 0);
+      park_get(x2, 1);
+      pk_sub_mod<F>(x3, x3, x1);                      // m^2 - x1 - x2, every step in [0, p (1 + 2^-11))
+      pk_sub_mod<F>(x3, x3, x2);
+      pk_reduce_product<F>(x3);
+      {
+        Pk tw;
+        Fe<F> tt, y3l;
+        pk_sub_mod<F>(tw, x1, x3);
+        pk_unpack<F>(tt, tw);
+        BA_FENCE();
+        BA_MUL(y3l, m, tt);
+        pk_pack<F>(y3, y3l);
+      }
+      BA_FENCE();
+      // y3 = m (x1 - x3) - y1; gather mode may hold y1 = p (a negated zero): reduce it first in that rare case
+      park_get(y1, 2);
+      if (MODE == MODE_GATHER) pk_reduce_product<F>(y1);
+      pk_sub_mod<F>(y3, y3, y1);
+      pk_reduce_product<F>(y3);
+      if (__any(kind & ~BA_DOUBLE)) {                 // identity operands, P - P, idle lanes: patch the output
+        park_get(x1, 0);
+        park_get(x2, 1);
+        ba_load_y<F, MODE>(y1, y2, L, a, t);
+        if (MODE == MODE_GATHER) { pk_reduce_product<F>(y1); pk_reduce_product<F>(y2); }
+        const bool ca = kind & BA_COPY_A, cb = kind & BA_COPY_B, z = kind & BA_ZERO;
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+          x3.w[j] = z ? INF_WORD : ca ? x1.w[j] : cb ? x2.w[j] : x3.w[j];
+          y3.w[j] = z ? 0u : ca ? y1.w[j] : cb ? y2.w[j] : y3.w[j];
+        }
+      }
+      asm volatile("" ::: "memory");
+      BA_FENCE();
+      if (i > 0) ba_load_y<F, MODE>(y1, y2, Ln, a, t);   // the next pair's y: in flight during the stores and d = inv * pre
+      if (!(kind & BA_SKIP)) {
+        char* ob = reinterpret_cast<char*>(a.out + (uint64_t)i * T);
+        ba_store3(ob, 16u * t, a.out_cap * 16, x3);
+        ba_store3(ob + 3 * a.out_cap * 16, 16u * t, a.out_cap * 16, y3);
+      }
+      x1 = nx1; x2 = nx2; pre = npre; L = Ln;
+    }
+  }
+}
+
+}  // namespace msm

@@ -207,16 +207,96 @@ MSM_DEV void fe_select(Fe<C>& r, bool c, const Fe<C>& a, const Fe<C>& b) {  // r
 
 // ---------------------------------------------------------------- Montgomery product
 
-// Interleaved (CIOS-style) Montgomery multiplication on 30-bit limbs with 64-bit column
-// accumulators.  Row i adds a_i*b and m_i*p, then shifts one limb.  p == 1 mod 2^30 for both
-// primes, so m_i = -t_0 mod 2^30 needs no multiply and the j = 0 product is known.
-// One carry sweep after row CARRY_ROW keeps every accumulator < 2^64
-// (at most 14 products of < 2^60 before it, 12 + a small carry after it).
+// Can every 64-bit column accumulator of the interleaved product (SQR: of the interleaved square) hold its worst
+// case -- all limbs 2^30 - 1, every quotient digit 2^30 - 1 -- when the only overflow guard is a sweep after row
+// `guard_row` (-1: none)?  Evaluated at compile time per field: BLS12-377, its scalar field and Pallas need no guard
+// at all (their column sums peak at 2^63.99), BLS12-381 needs one.
+template <class C, bool SQR>
+constexpr bool fe_acc_fits(int guard_row) {
+  constexpr int N = C::NL;
+  typedef unsigned __int128 u128;
+  const u128 M = LMASK, LIM = (u128)1 << 64;
+  u128 w[N] = {};
+  for (int i = 0; i < N; i++) {
+    for (int j = SQR ? i : 0; j < N; j++) w[j] += (SQR && j > i) ? M * (2 * M) : M * M;
+    for (int j = 0; j < N; j++)
+      if (w[j] >= LIM) return false;
+    if (w[0] + M * C::P[0] >= LIM) return false;
+    const u128 carry = ((w[0] + M * C::P[0]) >> LB) + 1;
+    for (int j = 1; j < N; j++) w[j] += M * C::P[j];
+    w[1] += carry;
+    for (int j = 0; j < N; j++)
+      if (w[j] >= LIM) return false;
+    for (int j = 0; j + 1 < N; j++) w[j] = w[j + 1];
+    w[N - 1] = 0;
+    if (i == guard_row)
+      for (int j = 0; j + 1 < N; j++) { w[j + 1] += (w[j] >> 32) * 4; w[j] &= 0xffffffffu; }
+  }
+  return true;
+}
+// row after which the guard sweep runs: -1 = no guard needed, -2 = no single sweep suffices
+template <class C, bool SQR>
+constexpr int fe_guard_row() {
+  if (fe_acc_fits<C, SQR>(-1)) return -1;
+  for (int d = 0; d < C::NL; d++) {
+    if (C::NL / 2 - d >= 0 && fe_acc_fits<C, SQR>(C::NL / 2 - d)) return C::NL / 2 - d;
+    if (C::NL / 2 + d < C::NL && fe_acc_fits<C, SQR>(C::NL / 2 + d)) return C::NL / 2 + d;
+  }
+  return -2;
+}
+
+// one reduction row of the interleaved product: add m * p with m chosen so that column 0 vanishes, push its carry
+// into column 1.  p == 1 mod 2^30 (BLS12-377 base and scalar fields, Pallas): m = -t0 mod 2^30 needs no multiply
+// and m * P[0] = m is a MAD by 1.
+template <class C>
+MSM_DEV void fe_reduce_row(uint64_t (&t)[C::NL]) {
+  constexpr int N = C::NL;
+  constexpr bool UNIT = (C::MU == LMASK) && (C::P[0] == 1);
+  uint64_t carry;
+  uint32_t m;
+  if (UNIT) {
+    m = (0u - (uint32_t)t[0]) & LMASK;
+    carry = fe_mad_const<1>(m, t[0]) >> LB;   // t[0] + m is a multiple of 2^30
+  } else {
+    m = ((uint32_t)t[0] * C::MU) & LMASK;
+    carry = (t[0] + (uint64_t)m * C::P[0]) >> LB;
+  }
+#pragma unroll
+  for (int j = 1; j < N; j++) t[j] += (uint64_t)m * C::P[j];
+  t[1] += carry;
+#pragma unroll
+  for (int j = 0; j + 1 < N; j++) t[j] = t[j + 1];
+  t[N - 1] = 0;
+}
+
+// overflow guard, not a normalisation: move each accumulator's high word up one column (x 2^32 = 4 x 2^30), one MAD +
+// one clear per column; the low words stay as they are (< 2^32)
+template <int N>
+MSM_DEV void fe_guard_sweep(uint64_t (&t)[N]) {
+#pragma unroll
+  for (int j = 0; j + 1 < N; j++) {
+    t[j + 1] = fe_mad_const<4>((uint32_t)(t[j] >> 32), t[j + 1]);
+    t[j] = (uint32_t)t[j];
+  }
+}
+
+template <int N>
+MSM_DEV void fe_carry_out(uint32_t (&r)[N], uint64_t (&t)[N]) {
+#pragma unroll
+  for (int j = 0; j + 1 < N; j++) {
+    t[j + 1] += t[j] >> LB;
+    r[j] = (uint32_t)t[j] & LMASK;
+  }
+  r[N - 1] = (uint32_t)t[N - 1];
+}
+
+// Interleaved (CIOS-style) Montgomery multiplication on 30-bit limbs with 64-bit column accumulators.  Row i adds
+// a_i * b and m_i * p, then shifts one limb.  Operands: normalised limbs (< 2^30), a * b < 2^12 p^2; result < p + a b / R.
 template <class C>
 MSM_DEV void fe_mul(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) {
   constexpr int N = C::NL;
-  // fast path: p == 1 mod 2^30 (BLS12-377 base and scalar fields): m = -t0, and m * P[0] = m needs no multiply
-  constexpr bool UNIT = (C::MU == LMASK) && (C::P[0] == 1);
+  constexpr int GUARD = fe_guard_row<C, false>();
+  static_assert(GUARD != -2, "no single guard sweep keeps the accumulators below 2^64");
   uint64_t t[N];
 #pragma unroll
   for (int j = 0; j < N; j++) t[j] = 0;
@@ -224,90 +304,35 @@ MSM_DEV void fe_mul(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) {
   for (int i = 0; i < N; i++) {
 #pragma unroll
     for (int j = 0; j < N; j++) t[j] += (uint64_t)a.l[i] * b.l[j];
-    uint64_t carry;
-    uint32_t m;
-    if (UNIT) {
-      uint32_t lo = (uint32_t)t[0] & LMASK;
-      m = (0u - lo) & LMASK;
-      carry = fe_mad_const<1>(m, t[0]) >> LB;   // t[0] + m*P[0] = t[0] + m is a multiple of 2^30
-    } else {
-      m = ((uint32_t)t[0] * C::MU) & LMASK;
-      carry = (t[0] + (uint64_t)m * C::P[0]) >> LB;
-    }
-#pragma unroll
-    for (int j = 1; j < N; j++) t[j] += (uint64_t)m * C::P[j];
-    t[1] += carry;
-#pragma unroll
-    for (int j = 0; j + 1 < N; j++) t[j] = t[j + 1];
-    t[N - 1] = 0;
-    if (N > 7 && i == N / 2) {
-      // overflow guard, not a normalisation: move each accumulator's high word up one column (x 2^32 = 4 x 2^30),
-      // one MAD + one clear per column; the low words stay as they are (< 2^32)
-#pragma unroll
-      for (int j = 0; j + 1 < N; j++) {
-        t[j + 1] = fe_mad_const<4>((uint32_t)(t[j] >> 32), t[j + 1]);
-        t[j] = (uint32_t)t[j];
-      }
-    }
+    fe_reduce_row<C>(t);
+    if (i == GUARD) fe_guard_sweep<N>(t);
   }
-#pragma unroll
-  for (int j = 0; j + 1 < N; j++) {
-    t[j + 1] += t[j] >> LB;
-    r.l[j] = (uint32_t)t[j] & LMASK;
-  }
-  r.l[N - 1] = (uint32_t)t[N - 1];
+  fe_carry_out<N>(r.l, t);
 }
 
+// Interleaved squaring: row i adds a_i^2 at column 2i and 2 a_i a_j (j > i) at column i + j -- positions i .. N-1 of
+// the shifted window -- so 13 accumulators suffice (the separate 2N-column square needed 26) and column i is complete
+// when reduction row i retires it: every term a_k a_(i-k) comes from a row k <= i / 2.
 template <class C>
 MSM_DEV void fe_sqr(Fe<C>& r, const Fe<C>& a) {
   constexpr int N = C::NL;
-  // column-wise square with doubled cross terms folded into the same interleaved reduction:
-  // row i contributes a_i^2 at column 2i and 2*a_i*a_j (j > i) at column i+j.  We run it as
-  // rows over a "doubled" operand so the reduction interleave stays identical to fe_mul.
+  constexpr int GUARD = fe_guard_row<C, true>();
+  static_assert(GUARD != -2, "no single guard sweep keeps the accumulators below 2^64");
   uint32_t a2[N];
 #pragma unroll
   for (int j = 0; j < N; j++) a2[j] = a.l[j] << 1;  // < 2^31
-  uint64_t t[2 * N];
+  uint64_t t[N];
 #pragma unroll
-  for (int j = 0; j < 2 * N; j++) t[j] = 0;
-  // full product first (no overflow: column sums < 7 * 2^61 + 2^60 < 2^64)
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    t[2 * i] += (uint64_t)a.l[i] * a.l[i];
-#pragma unroll
-    for (int j = i + 1; j < N; j++) t[i + j] += (uint64_t)a.l[i] * a2[j];
-  }
-  // overflow guard before the reduction rows are added (not a normalisation): every accumulator's high word moves
-  // up one column (x 2^32 = 4 x 2^30) with one MAD, leaving < 2^32 behind
-#pragma unroll
-  for (int j = 0; j + 1 < 2 * N; j++) {
-    t[j + 1] = fe_mad_const<4>((uint32_t)(t[j] >> 32), t[j + 1]);
-    t[j] = (uint32_t)t[j];
-  }
-  // reduction: N rows of m_i * p
-  constexpr bool UNIT = (C::MU == LMASK) && (C::P[0] == 1);
+  for (int j = 0; j < N; j++) t[j] = 0;
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    uint32_t m;
-    uint64_t carry;
-    if (UNIT) {
-      uint32_t lo = (uint32_t)t[i] & LMASK;
-      m = (0u - lo) & LMASK;
-      carry = fe_mad_const<1>(m, t[i]) >> LB;
-    } else {
-      m = ((uint32_t)t[i] * C::MU) & LMASK;
-      carry = (t[i] + (uint64_t)m * C::P[0]) >> LB;
-    }
+    t[i] += (uint64_t)a.l[i] * a.l[i];
 #pragma unroll
-    for (int j = 1; j < N; j++) t[i + j] += (uint64_t)m * C::P[j];
-    t[i + 1] += carry;
+    for (int j = i + 1; j < N; j++) t[j] += (uint64_t)a.l[i] * a2[j];
+    fe_reduce_row<C>(t);
+    if (i == GUARD) fe_guard_sweep<N>(t);
   }
-#pragma unroll
-  for (int j = N; j + 1 < 2 * N; j++) {
-    t[j + 1] += t[j] >> LB;
-    r.l[j - N] = (uint32_t)t[j] & LMASK;
-  }
-  r.l[N - 1] = (uint32_t)t[2 * N - 1];
+  fe_carry_out<N>(r.l, t);
 }
 
 // ---------------------------------------------------------------- inversion

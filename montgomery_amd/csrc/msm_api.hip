@@ -220,8 +220,8 @@ struct RoundGeom {
 // backward sweep in step; four batches of 128 steps instead of one of 512 stagger the phases (2^26, one window:
 // 31.5 -> 29.2 ms).  With two groups on two streams the other stream already fills the gaps and 512 is better.
 RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather = false, bool lone = false) {
-  uint64_t target = (uint64_t)ctx->n_cu * 4 * 2 * 64;  // two waves per SIMD
-  uint64_t half_below = 200;  // steps at full width below which a non-gather round runs on one wave per SIMD
+  uint64_t target = (uint64_t)ctx->n_cu * 4 * MSM_BA_WAVES * 64;  // as many lanes as the kernel's launch bounds keep resident
+  uint64_t half_below = 0;  // steps at full width below which a non-gather round runs on half as many lanes (to be retuned)
   if (const char* e = getenv("MSM_HALF_BELOW")) half_below = (uint64_t)std::max(0, atoi(e));
   if (!gather && n_out < target * half_below) target /= 2;
   uint32_t max_steps = (lone && n_out >= target * 512) ? 128 : 512;
@@ -483,8 +483,10 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       which ^= 1;
     }
   }
-  ctx->ensure(w.bufA, capA * elem_bytes);
-  ctx->ensure(w.bufB, capB * elem_bytes);
+  // idle lanes of a round's last step read (and ignore) up to 2 T elements past its end: keep that inside the allocation
+  const size_t tree_slack = (size_t)ctx->n_cu * 4 * 8 * 64 * 2 * 16;
+  ctx->ensure(w.bufA, capA * elem_bytes + tree_slack);
+  ctx->ensure(w.bufB, capB * elem_bytes + tree_slack);
   uint4* buf[2] = {(uint4*)w.bufA.p, (uint4*)w.bufB.p};
   uint64_t cap[2] = {capA, capB};
   int cur = 0;  // buffer that receives the next round's output
@@ -508,10 +510,6 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       a.scratch = (uint32_t*)w.scratch.p;
       a.n_out = n_out;
       a.steps = g.steps;
-      {
-        static const int wm = getenv("MSM_WAVE_MAJOR") ? atoi(getenv("MSM_WAVE_MAJOR")) : 0;   // experiment knob
-        a.wave_major = (r == 1) ? (wm & 1) : ((wm >> 1) & 1);
-      }
       if (r == 1) {
         if (te) hipLaunchKernelGGL(te::k_te_add<MODE_GATHER>, dim3(g.grid), dim3(256), 0, s, a);
         else W_LAUNCH_MODE(ctx, k_batch_add, MODE_GATHER, dim3(g.grid), dim3(256), 0, s, a);
@@ -539,17 +537,16 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       a.scratch = (uint32_t*)w.scratch.p;
       a.n_out = n_out;
       a.steps = g.steps;
-      a.off_in = (const uint32_t*)w.tail_off.p + (uint64_t)(r - 1) * (nb + 1);
-      a.off_out = (const uint32_t*)w.tail_off.p + (uint64_t)r * (nb + 1);
-      a.nb = (uint32_t)nb;
       if (n_out) {
+        const uint32_t* off_in = (const uint32_t*)w.tail_off.p + (uint64_t)(r - 1) * (nb + 1);
+        const uint32_t* off_out = (const uint32_t*)w.tail_off.p + (uint64_t)r * (nb + 1);
         ctx->ensure(w.desc, n_out * 4);
-        hipLaunchKernelGGL(k_tail_desc, dim3((uint32_t)((n_out + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.desc.p, a.off_in,
-                           a.off_out, (uint32_t)nb, (uint32_t)n_out);
+        hipLaunchKernelGGL(k_tail_desc, dim3((uint32_t)((n_out + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.desc.p, off_in,
+                           off_out, (uint32_t)nb, (uint32_t)n_out);
         a.desc = (const uint32_t*)w.desc.p;
+        if (te) hipLaunchKernelGGL(te::k_te_add<MODE_SEARCH>, dim3(g.grid), dim3(256), 0, s, a);
+        else W_LAUNCH_MODE(ctx, k_batch_add, MODE_SEARCH, dim3(g.grid), dim3(256), 0, s, a);
       }
-      if (te) hipLaunchKernelGGL(te::k_te_add<MODE_SEARCH>, dim3(g.grid), dim3(256), 0, s, a);
-      else W_LAUNCH_MODE(ctx, k_batch_add, MODE_SEARCH, dim3(g.grid), dim3(256), 0, s, a);
       st.n_pairs += n_out;
       fin = buf[cur];
       fin_cap = cap[cur];

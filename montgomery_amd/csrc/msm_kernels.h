@@ -45,6 +45,10 @@ constexpr int ROW_Y = 12;       // word offset of y inside a line
 constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t INF_WORD = 0xFFFFFFFFu;
 
+}  // namespace msm
+#include "batch_add.h"   // k_batch_add: the accumulation tree round
+namespace msm {
+
 // ---------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------
@@ -227,291 +231,6 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts,
         dig[(uint64_t)kk * two_n + 2ull * i + hh] = l | (neg << 31);
         if (counts && l) atomicAdd(&counts[(uint64_t)kk * L + (l - 1)], 1u);  // only on the global-atomic sort path
       }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_batch_add: one tree round of the bucket accumulation.
-//   output element e = input element 2e + input element 2e+1 (affine, edge cases included),
-//   each lane walks `steps` pairs e = i*T + t and shares ONE field inversion among them
-//   (Montgomery's trick: src/curve-affine.ts:484-516, src/wasm/inverse.ts:220-271).
-// ---------------------------------------------------------------------------------------------
-
-enum : int { MODE_GATHER = 0, MODE_REGULAR = 1, MODE_SEARCH = 2 };
-
-struct BatchArgs {
-  const uint32_t* points;   // MODE_GATHER: point rows
-  const uint32_t* slots;    // MODE_GATHER: payload slots, pair e = slots[2e], slots[2e+1]
-  const uint4* in;          // MODE_REGULAR / MODE_SEARCH: input planes
-  uint64_t in_cap;
-  uint4* out;               // output planes
-  uint64_t out_cap;
-  uint32_t* scratch;        // prefix products
-  uint64_t n_out;           // number of output elements
-  uint32_t steps;
-  const uint32_t* off_in;   // MODE_SEARCH: bucket offsets of the input / output round
-  const uint32_t* off_out;
-  uint32_t nb;
-  const uint32_t* desc;     // MODE_SEARCH: operand descriptors from k_tail_desc (replaces the search when set)
-  uint32_t wave_major;      // element -> lane mapping, see k_batch_add
-};
-
-// One operand of a pair: where it lives and how to read it.
-struct Side {
-  uint64_t idx;      // element index (planes) or word offset of the point row (gather); always a valid address
-  uint32_t xoff;     // gather: word offset of the 128-byte line inside the row (0 or ROW_HALF)
-  bool neg;          // gather: negate y
-  bool absent;       // no such element: identity
-};
-
-template <int MODE>
-MSM_DEV void sides_from_payload(uint2 pp, Side& A, Side& B) {
-  A.absent = pp.x == SLOT_EMPTY;
-  B.absent = pp.y == SLOT_EMPTY;
-  // absent operands read row 0 (valid memory) and are then ignored: no divergent loads
-  A.idx = A.absent ? 0 : (uint64_t)(pp.x >> 2) * ROW_WORDS; A.xoff = (!A.absent && (pp.x & 2u)) ? (uint32_t)ROW_HALF : 0u; A.neg = pp.x & 1u;
-  B.idx = B.absent ? 0 : (uint64_t)(pp.y >> 2) * ROW_WORDS; B.xoff = (!B.absent && (pp.y & 2u)) ? (uint32_t)ROW_HALF : 0u; B.neg = pp.y & 1u;
-}
-
-template <int MODE>
-MSM_DEV void locate(const BatchArgs& a, uint64_t e, Side& A, Side& B) {
-  A.xoff = B.xoff = 0; A.neg = B.neg = false; A.absent = B.absent = false;
-  if (MODE == MODE_GATHER) {
-    sides_from_payload<MODE>(reinterpret_cast<const uint2*>(a.slots)[e], A, B);
-  } else if (MODE == MODE_REGULAR) {
-    A.idx = 2 * e; B.idx = 2 * e + 1;
-  } else if (a.desc) {
-    const uint32_t d = a.desc[e];
-    A.idx = d >> 1;
-    B.absent = (d & 1u) == 0;
-    B.idx = B.absent ? A.idx : A.idx + 1;
-  } else {
-    uint32_t lo = 0, hi = a.nb;
-    const uint32_t e32 = (uint32_t)e;
-    while (hi - lo > 1) {
-      uint32_t mid = (lo + hi) >> 1;
-      if (a.off_out[mid] <= e32) lo = mid; else hi = mid;
-    }
-    uint32_t j = e32 - a.off_out[lo];
-    uint32_t ibeg = a.off_in[lo], iend = a.off_in[lo + 1];
-    A.idx = (uint64_t)ibeg + 2ull * j;
-    B.idx = A.idx + 1;
-    B.absent = B.idx >= iend;
-    if (B.absent) B.idx = A.idx;
-  }
-}
-
-// raw (packed) coordinate loads: operands stay in the packed word form (packed.h) and only the values that feed
-// multiplications are unpacked; the loads of the NEXT pair are in flight while the current one is computed
-template <int MODE>
-MSM_DEV void load_x_raw(const BatchArgs& a, const Side& s, Pk& w) {
-  if (MODE == MODE_GATHER) load_words12(w.w, a.points + s.idx + s.xoff);
-  else load_planes3(w.w, a.in, a.in_cap, 0, s.idx);
-}
-template <int MODE>
-MSM_DEV void load_y_raw(const BatchArgs& a, const Side& s, Pk& w) {
-  if (MODE == MODE_GATHER) load_words12(w.w, a.points + s.idx + s.xoff + ROW_Y);
-  else load_planes3(w.w, a.in, a.in_cap, 3, s.idx);
-}
-
-// gather mode: apply the sign bit of the payload, y -> p - y (0 stays 0)
-template <class F, int MODE>
-MSM_DEV void finish_y(const Side& s, Pk& y) {
-  if (MODE != MODE_GATHER) return;
-  Pk pp, t;
-  pk_set_p_masked<F>(pp, 0xFFFFFFFFu);
-  pk_sub(t, pp, y);
-  const bool flip = s.neg && !pk_is_zero(y);
-#pragma unroll
-  for (int i = 0; i < NW; i++) y.w[i] = flip ? t.w[i] : y.w[i];
-}
-
-enum : int { KIND_ADD = 0, KIND_DOUBLE = 1, KIND_COPY_A = 2, KIND_COPY_B = 3, KIND_ZERO = 4 };
-
-MSM_DEV void store_point_pk(uint4* out, uint64_t cap, uint64_t e, const Pk& x, const Pk& y) {
-  store_planes3(out, cap, 0, e, x.w);
-  store_planes3(out, cap, 3, e, y.w);
-}
-
-MSM_DEV void store_identity(uint4* out, uint64_t cap, uint64_t e) {
-  uint32_t w[NW];
-#pragma unroll
-  for (int j = 0; j < NW; j++) w[j] = INF_WORD;
-  store_planes3(out, cap, 0, e, w);
-#pragma unroll
-  for (int j = 0; j < NW; j++) w[j] = 0;
-  store_planes3(out, cap, 3, e, w);
-}
-
-// what one lane needs to start working on a pair; filled one step ahead of its use
-template <int MODE>
-struct PairFetch {
-  Side A, B;
-  Pk ax, bx;
-};
-
-template <int MODE>
-MSM_DEV void copy_fetch(PairFetch<MODE>& d, const PairFetch<MODE>& s) {  // element-wise: keeps everything in VGPRs
-  d.A.idx = s.A.idx; d.A.xoff = s.A.xoff; d.A.neg = s.A.neg; d.A.absent = s.A.absent;
-  d.B.idx = s.B.idx; d.B.xoff = s.B.xoff; d.B.neg = s.B.neg; d.B.absent = s.B.absent;
-#pragma unroll
-  for (int j = 0; j < NW; j++) { d.ax.w[j] = s.ax.w[j]; d.bx.w[j] = s.bx.w[j]; }
-}
-
-template <int MODE>
-MSM_DEV void fetch_pair_x(const BatchArgs& a, uint64_t e, PairFetch<MODE>& pf) {
-  locate<MODE>(a, e, pf.A, pf.B);
-  load_x_raw<MODE>(a, pf.A, pf.ax);
-  load_x_raw<MODE>(a, pf.B, pf.bx);
-}
-
-// classification + denominator from the packed x coordinates (y only for the rare equal-x case).
-// den comes back in limb form, ready for the multiplier.
-template <class F, int MODE>
-MSM_DEV int classify(const BatchArgs& a, const PairFetch<MODE>& pf, bool& inf1, bool& inf2, Fe<F>& den) {
-  inf1 = pf.A.absent || pf.ax.w[NW - 1] == INF_WORD;
-  inf2 = pf.B.absent || pf.bx.w[NW - 1] == INF_WORD;
-  fe_set_one<F>(den);
-  if (inf2) return KIND_COPY_A;
-  if (inf1) return KIND_COPY_B;
-  Pk dx;
-  pk_sub_mod<F>(dx, pf.bx, pf.ax);          // x2 - x1 mod p, canonical
-  if (pk_is_zero(dx)) {
-    Pk y1, y2;
-    load_y_raw<MODE>(a, pf.A, y1);
-    finish_y<F, MODE>(pf.A, y1);
-    load_y_raw<MODE>(a, pf.B, y2);
-    finish_y<F, MODE>(pf.B, y2);
-    if (pk_equal(y1, y2) && !pk_is_zero(y1)) {
-      Fe<F> yl;
-      pk_unpack<F>(yl, y1);
-      fe_add<F>(den, yl, yl);
-      return KIND_DOUBLE;
-    }
-    return KIND_ZERO;
-  }
-  pk_unpack<F>(den, dx);
-  return KIND_ADD;
-}
-
-template <class CV, int MODE>
-__global__ void __launch_bounds__(256) k_batch_add(BatchArgs a) {
-  using F = typename CV::F;
-  const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // lane t owns the pairs e = e0 + i * es, i < steps.  Interleaved (default): e0 = t, es = T -- at any moment the
-  // grid works on one contiguous span of T pairs.  Wave-contiguous (a.wave_major): every wave walks its own run
-  // of steps * 64 consecutive pairs, so concurrently running waves sit at the same relative position of many
-  // different buckets -- i.e. in the same region of the index-ordered point table.
-  const uint64_t e0 = a.wave_major ? ((t >> 6) * a.steps << 6) + (t & 63) : t;
-  const uint64_t es = a.wave_major ? 64 : T;
-  if (e0 >= a.n_out) return;   // whole lane idle
-  // number of pairs this lane owns
-  const uint32_t my_steps = (uint32_t)min((uint64_t)a.steps, (a.n_out - e0 + es - 1) / es);
-
-  Fe<F> acc;
-  fe_set_one<F>(acc);
-
-  // ---- forward sweep: prefix products of the denominators -------------------------------------
-  {
-    PairFetch<MODE> nxt;
-    fetch_pair_x<MODE>(a, e0, nxt);
-#pragma unroll 1
-    for (uint32_t i = 0; i < my_steps; i++) {
-      PairFetch<MODE> cur;
-      copy_fetch<MODE>(cur, nxt);
-      if (i + 1 < my_steps) fetch_pair_x<MODE>(a, e0 + (uint64_t)(i + 1) * es, nxt);   // in flight during the multiply
-      Fe<F> den;
-      bool inf1, inf2;
-      classify<F, MODE>(a, cur, inf1, inf2, den);
-      uint32_t* sp = a.scratch + ((uint64_t)i * NL) * T + t;
-#pragma unroll
-      for (int l = 0; l < NL; l++) sp[(uint64_t)l * T] = acc.l[l];
-      fe_mul<F>(acc, acc, den);
-    }
-  }
-
-  Fe<F> inv;
-  fe_inv<F>(inv, acc);
-
-  // ---- backward sweep ------------------------------------------------------------------------
-  {
-    PairFetch<MODE> nxt;
-    uint32_t npre[NL];
-    {
-      const uint32_t i = my_steps - 1;
-      fetch_pair_x<MODE>(a, e0 + (uint64_t)i * es, nxt);
-      const uint32_t* sp = a.scratch + ((uint64_t)i * NL) * T + t;
-#pragma unroll
-      for (int l = 0; l < NL; l++) npre[l] = sp[(uint64_t)l * T];
-    }
-#pragma unroll 1
-    for (int i = (int)my_steps - 1; i >= 0; i--) {
-      const uint64_t e = e0 + (uint64_t)i * es;
-      PairFetch<MODE> cur;
-      copy_fetch<MODE>(cur, nxt);
-      Fe<F> pre;
-#pragma unroll
-      for (int l = 0; l < NL; l++) pre.l[l] = npre[l];
-      // this pair's y coordinates: issued now, consumed after two multiplications
-      Pk y1, y2;
-      load_y_raw<MODE>(a, cur.A, y1);
-      load_y_raw<MODE>(a, cur.B, y2);
-      // next pair's x coordinates and prefix product: in flight during this pair's arithmetic
-      if (i > 0) {
-        fetch_pair_x<MODE>(a, e0 + (uint64_t)(i - 1) * es, nxt);
-        const uint32_t* sp = a.scratch + ((uint64_t)(i - 1) * NL) * T + t;
-#pragma unroll
-        for (int l = 0; l < NL; l++) npre[l] = sp[(uint64_t)l * T];
-      }
-      Fe<F> den, d;
-      bool inf1, inf2;
-      int kind = classify<F, MODE>(a, cur, inf1, inf2, den);
-      fe_mul<F>(d, inv, pre);     // 1 / den_i
-      fe_mul<F>(inv, inv, den);   // strip den_i from the running inverse
-
-      finish_y<F, MODE>(cur.A, y1);
-      finish_y<F, MODE>(cur.B, y2);
-      if (kind == KIND_ZERO || (kind == KIND_COPY_A && inf1)) {
-        store_identity(a.out, a.out_cap, e);
-        continue;
-      }
-      if (kind == KIND_COPY_A) {
-        store_point_pk(a.out, a.out_cap, e, cur.ax, y1);
-        continue;
-      }
-      if (kind == KIND_COPY_B) {
-        store_point_pk(a.out, a.out_cap, e, cur.bx, y2);
-        continue;
-      }
-      Fe<F> num, m, mm, tt, y3l;
-      if (kind == KIND_DOUBLE) {
-        Fe<F> x1l;
-        pk_unpack<F>(x1l, cur.ax);
-        fe_sqr<F>(tt, x1l);
-        fe_add<F>(num, tt, tt);
-        fe_add<F>(num, num, tt);   // 3 x^2
-      } else {
-        Pk dy;
-        pk_sub_mod<F>(dy, y2, y1);
-        pk_unpack<F>(num, dy);
-      }
-      fe_mul<F>(m, num, d);
-      fe_sqr<F>(mm, m);
-      // x3 = m^2 - x1 - x2, on words: m^2 < p + eps, every step stays in [0, p + eps), one final conditional subtraction
-      Pk x3, tw, y3;
-      pk_pack<F>(x3, mm);
-      pk_sub_mod<F>(x3, x3, cur.ax);
-      pk_sub_mod<F>(x3, x3, cur.bx);
-      pk_cond_sub_p<F>(x3);
-      pk_sub_mod<F>(tw, cur.ax, x3);   // x1 - x3
-      pk_unpack<F>(tt, tw);
-      fe_mul<F>(y3l, m, tt);
-      pk_pack<F>(y3, y3l);
-      pk_sub_mod<F>(y3, y3, y1);
-      pk_cond_sub_p<F>(y3);
-      store_point_pk(a.out, a.out_cap, e, x3, y3);
     }
   }
 }

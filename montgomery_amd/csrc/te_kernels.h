@@ -265,21 +265,10 @@ __global__ void __launch_bounds__(256) k_te_add(BatchArgs a) {
       bool has_b = true;
       if (MODE == MODE_REGULAR) {
         ia = 2 * e; ib = 2 * e + 1;
-      } else if (a.desc) {
+      } else {   // MODE_SEARCH: operand descriptors from k_tail_desc
         const uint32_t d = a.desc[e];
         ia = d >> 1; ib = ia + 1;
         has_b = (d & 1u) != 0;
-      } else {
-        uint32_t lo = 0, hi = a.nb;
-        const uint32_t e32 = (uint32_t)e;
-        while (hi - lo > 1) {
-          uint32_t mid = (lo + hi) >> 1;
-          if (a.off_out[mid] <= e32) lo = mid; else hi = mid;
-        }
-        uint32_t j = e32 - a.off_out[lo];
-        ia = (uint64_t)a.off_in[lo] + 2ull * j;
-        ib = ia + 1;
-        has_b = ib < a.off_in[lo + 1];
       }
       Ext P, Q;
       load_ext(P, a.in, a.in_cap, ia);

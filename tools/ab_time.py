@@ -13,10 +13,11 @@ cc = int(os.environ.get('MSM_C', '0')) or None
 ctx = MsmContext()
 ctx.generate_points(n, seed=7)
 dev, _ = ctx.generate_scalars(n, seed=9)
+serial = bool(int(os.environ.get('AB_SERIAL', '0')))
 ctx.run_device(dev, n, c=cc)
 best = None
 for i in range(4):
-    t = time.perf_counter(); r, info = ctx.run_device(dev, n, c=cc); dt = time.perf_counter() - t
+    t = time.perf_counter(); r, info = ctx.run_device(dev, n, c=cc, serial=serial); dt = time.perf_counter() - t
     if best is None or dt < best[0]: best = (dt, info)
 print(json.dumps({"ms": best[0] * 1e3, "x": hex(r.x)[:18], "phase": {k: round(v, 2) for k, v in best[1]["phase_ms"].items()}, "c": best[1]["c"]}))
 ''' % ROOT
