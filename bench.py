@@ -10,13 +10,18 @@ same MSM sharded by scalar window -- every rank holds all points and scalars, co
 sums P_k of its windows, ONE RCCL all-gather of K x 144 bytes, rank 0 does the Horner combination
 (SURVEY.md section 8e).  Total work is fixed as N grows: scaling = "strong".
 
-Prints ONE JSON line on rank 0 with the driver's contract plus `roofline` (dominant kernel
-k_batch_add, HIP-event timed inside the library on its own stream) and `cpu_baseline` (the C port
-of the oracle on the host cores, bounded sample).
+Prints ONE JSON line on rank 0 with the driver's contract plus
+  `roofline`      dominant kernel k_batch_add, HIP-event timed inside the library on its own stream,
+  `cpu_baseline`  the C port of the oracle on ALL host cores, bounded sample,
+  `verified`      the result of the LAST timed step checked outside the timed region against the known
+                  discrete logs of the generated points: sum s_i P_i == (sum s_i a_i mod q) G
+                  (the reference compares every size it benchmarks, scripts/msm-weierstrass.ts:97-107),
+  `median_ms` / `std_ms` over the timed steps (scripts/evaluate-util.ts:3-20) and `pcie_inclusive`.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,15 +34,33 @@ PAIR_ALGO_BYTES = 288
 PAIR_MADS = 5 * 325 + 247
 SORT_ALGO_BYTES = 12   # per (entry, window): digit read by k_hist, digit read by k_scatter_lds, payload write
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-INT_MAD_PEAK = 30.3e12         # v_mad_u64_u32 lane-ops/s measured on MI355X by tools/ubench_int.hip (profiles/r01_ubench_int.txt)
-# HBM bytes per pair addition of the regular tree rounds from the PMC passes committed in profiles/r01_pmc_2p24.json
-# (separate --pmc FETCH_SIZE / WRITE_SIZE runs at 2^24): FETCH_SIZE 169 B x 2 (gfx950 halves wide coalesced reads)
-# + WRITE_SIZE 147 B.  Round 1 (random 64-byte-sector gathers) reads 381 B uncorrected + writes 148 B per pair.
-PAIR_TRAFFIC_BYTES_PMC = 2 * 169 + 147
+# v_mad_u64_u32 lane-ops/s, measured by tools/ubench_int2.hip (profiles/r02_ubench_int.txt): 33.4e12 with eight resident
+# waves per SIMD (4.6 real cycles per wave-instruction at 2.35 GHz); 28.2e12 at the two waves per SIMD k_batch_add runs with
+INT_MAD_PEAK = 33.4e12
+INT_MAD_AT_2_WAVES = 28.2e12
+# HBM bytes per pair addition from the PMC passes committed in profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE runs at
+# 2^24, regular rounds; FETCH_SIZE doubled: gfx950 halves wide coalesced reads) -- see profiles/README.md
+PAIR_TRAFFIC_BYTES_PMC = 488
+MAX_SCALAR_SETS = 8            # distinct 2^n x 32-byte scalar sets kept in HBM; steps cycle through them
+
+
+def expected_from_logs(curve_name, a_host, s_host, n):
+    """(sum s_i a_i mod q) G through the checker: C oracle for the dot product, Python oracle for the one scalar
+    multiplication.  Returns the affine point (None = identity)."""
+    from oracle import c_oracle
+    from oracle import msm_oracle as O
+
+    if curve_name == "ed377":
+        C = O.ED_ON_BLS12_377
+        k = c_oracle.dot_mod(a_host, s_host, n, C.q)
+        return O.te_to_affine(O.te_scale(k, O.te_from_affine((C.gx, C.gy), C), C), C)
+    C = {"bls12-377": O.BLS12_377, "bls12-381": O.BLS12_381}[curve_name]
+    k = c_oracle.dot_mod(a_host, s_host, n, C.q)
+    return O.aff_scale(k, (C.gx, C.gy), C.p)
 
 
 def cpu_baseline(ctx, log2n_sample, seed):
-    """Times oracle/msm_oracle.c (kind "port") on the host cores over the first 2^log2n_sample
+    """Times oracle/msm_oracle.c (kind "port") on all host cores over the first 2^log2n_sample
     resident points.  The reference's WASM path cannot run here."""
     from oracle import c_oracle
 
@@ -54,11 +77,18 @@ def cpu_baseline(ctx, log2n_sample, seed):
     return {
         "value": n / dt,
         "unit": "points/s",
-        "cores": threads,
+        "cores": os.cpu_count(),
+        "threads": threads,
         "kind": "port",
         "sample": f"one 2^{log2n_sample}-point BLS12-377 G1 MSM (first 2^{log2n_sample} of the resident points, reference window table), "
-                  f"{dt:.2f} s, OpenMP over windows; GPU result on the same inputs checked equal",
+                  f"{dt:.2f} s on {threads} OpenMP threads (entries split across threads for slicing / sorting, buckets for the "
+                  f"accumulation and reduction, as the reference's SPMD threads); GPU result on the same inputs checked equal",
     }
+
+
+def step_stats(step_ms):
+    return {"median_ms": statistics.median(step_ms), "std_ms": statistics.stdev(step_ms) if len(step_ms) > 1 else 0.0,
+            "min_ms": min(step_ms), "max_ms": max(step_ms)}
 
 
 def bench_ed377(args, torch):
@@ -69,23 +99,29 @@ def bench_ed377(args, torch):
 
     n = 1 << args.log2n
     ctx = MsmContext(_lib.CURVE_ED_ON_BLS12_377, device=0)
-    ctx.generate_points(n, seed=20261002)
+    a_host = ctx.generate_points(n, seed=20261002, want_scalars=True, raw=True)
     c, K = ctx.plan(n, args.c or None)
     dev = torch.device("cuda", 0)
-    scal = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(args.steps + args.warmup)]
+    n_sets = min(args.steps + args.warmup, MAX_SCALAR_SETS)
+    scal = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(n_sets)]
     for i, t in enumerate(scal):
         ctx.generate_scalars(n, seed=1000 + i, into=t.data_ptr())
     torch.cuda.synchronize()
     for i in range(args.warmup):
-        ctx.run_device(scal[i].data_ptr(), n, c=c)
+        ctx.run_device(scal[i % n_sets].data_ptr(), n, c=c)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    infos = []
+    infos, step_ms, last, last_set = [], [], None, 0
     for i in range(args.steps):
-        _, info = ctx.run_device(scal[args.warmup + i].data_ptr(), n, c=c)
+        last_set = (args.warmup + i) % n_sets
+        ts = time.perf_counter()
+        last, info = ctx.run_device(scal[last_set].data_ptr(), n, c=c)
+        step_ms.append((time.perf_counter() - ts) * 1e3)
         infos.append(info)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    _, s_host = ctx.generate_scalars(n, seed=1000 + last_set, to_host=True, raw=True)
+    verified = (last.x, last.y) == expected_from_logs("ed377", a_host, s_host, n)
     acc_ms = sum(x["phase_ms"]["accumulate"] for x in infos)
     pairs = sum(x["n_pairs"] for x in infos)
     # one unified extended addition: two 128-byte nodes in, one out; 9 multiplications of 9 limbs (2*81 - 9 MADs)
@@ -97,6 +133,8 @@ def bench_ed377(args, torch):
         "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"ed-on-bls12-377-msm-2^{args.log2n}", "log2_n": args.log2n, "window_bits": c, "windows": K,
                    "parallelism": "single-gpu"},
+        "verified": bool(verified),
+        **step_stats(step_ms),
         "roofline": {"kernel": "k_te_add (bucket tree, unified extended additions)", "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_pair_add": algo_bytes,
@@ -106,6 +144,8 @@ def bench_ed377(args, torch):
     }
     print(json.dumps(out), flush=True)
     ctx.close()
+    if not verified:
+        sys.exit("bench: the Edwards MSM result failed the known-discrete-log check")
 
 
 def main():
@@ -115,8 +155,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=26)
     ap.add_argument("--c", type=int, default=0)
-    ap.add_argument("--cpu-log2n", type=int, default=22)
+    ap.add_argument("--cpu-log2n", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the known-discrete-log check of the last timed result")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (functional check of the sharded path on one GPU)")
     ap.add_argument("--curve", choices=["bls12-377", "bls12-381", "ed377"], default="bls12-377",
                     help="ed377 = BASELINE configs[3]: twisted Edwards msmBasic path (single GPU, use --log2n 20); "
@@ -154,24 +195,28 @@ def main():
     from montgomery_amd import _lib as _abi
 
     is381 = args.curve == "bls12-381"
+    verify = not args.no_verify
     ctx = MsmContext(_abi.CURVE_BLS12_381_G1 if is381 else _abi.CURVE_BLS12_377_G1, device=local_rank)
-    ctx.generate_points(n, seed=20261002)   # identical on every rank
+    # identical points on every rank; rank 0 keeps their discrete logs for the check of the result
+    a_host = ctx.generate_points(n, seed=20261002, want_scalars=(verify and rank == 0), raw=True)
     c, K = ctx.plan(n, args.c or None)
     shards = window_shards(K, world)
 
     dev = torch.device("cuda", local_rank)
-    n_bufs = args.steps + args.warmup
-    # fresh scalars per step, generated on the GPU before the timed region (resident in HBM)
-    scal = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(n_bufs)]
+    # fresh scalars per step, generated on the GPU before the timed region (resident in HBM); at most MAX_SCALAR_SETS
+    # distinct sets (2 GB each at 2^26), the steps cycle through them
+    n_sets = min(args.steps + args.warmup, MAX_SCALAR_SETS)
+    scal = [torch.empty(n * 32, dtype=torch.uint8, device=dev) for _ in range(n_sets)]
     for i, t in enumerate(scal):
         ctx.generate_scalars(n, seed=1000 + i, into=t.data_ptr())
+
     def step(i):
         if world == 1:
-            return ctx.run_device(scal[i].data_ptr(), n, c=c)
+            return ctx.run_device(scal[i % n_sets].data_ptr(), n, c=c)
         box = {}
 
         def my_window_sums(lo, hi):
-            parts, box["info"] = ctx.window_sums(scal[i].data_ptr(), n, lo, hi, c=c, on_device=True)
+            parts, box["info"] = ctx.window_sums(scal[i % n_sets].data_ptr(), n, lo, hi, c=c, on_device=True)
             return parts
 
         out = sharded_msm(my_window_sums, K, c, device=dev if args.dist_backend == "nccl" else "cpu", curve=ctx.curve)
@@ -190,10 +235,13 @@ def main():
         step(i)
     sync()
     t0 = time.perf_counter()
-    infos = []
-    last = None
+    infos, step_ms = [], []
+    last, last_set = None, 0
     for i in range(args.steps):
-        last, info = step(args.warmup + i)
+        last_set = (args.warmup + i) % n_sets
+        ts = time.perf_counter()
+        last, info = step(args.warmup + i)    # msm_run / the all-gather are synchronous: per-step wall time is meaningful
+        step_ms.append((time.perf_counter() - ts) * 1e3)
         infos.append(info)
     sync()
     dt = time.perf_counter() - t0
@@ -206,12 +254,20 @@ def main():
         infos = [x for x in infos if x]
         acc_ms = sum(x["phase_ms"]["accumulate"] for x in infos)
         pairs = sum(x["n_pairs"] for x in infos)
-        launches = sum(x["rounds"] for x in infos) or 1
+        launches = sum(x["rounds"] for x in infos) or 1     # tree rounds of ALL window groups (summed by the library)
         phase = {k: sum(x["phase_ms"][k] for x in infos) / max(len(infos), 1) for k in infos[0]["phase_ms"]} if infos else {}
         achieved = pairs * PAIR_ALGO_BYTES / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
+        # ---- checker leg (outside the timed region): the last timed result against the known discrete logs -------
+        verified = None
+        if verify:
+            _, s_host = ctx.generate_scalars(n, seed=1000 + last_set, to_host=True, raw=True)   # the same stream, read back
+            exp = expected_from_logs(args.curve, a_host, s_host, n)
+            verified = bool(last is not None and last.as_tuple() == exp)
+            del s_host
         # Big inputs run as two window groups on two streams, so the event-timed launch durations above are those of
         # kernels SHARING the GPU.  One extra, untimed step with the groups serialised gives the exclusive figures.
         excl = None
+        pcie = None
         if world == 1:
             _, xi = ctx.run_device(scal[0].data_ptr(), n, c=c, serial=True)
             x_ms = xi["phase_ms"]["accumulate"]
@@ -220,6 +276,7 @@ def main():
                 "achieved": xi["n_pairs"] * PAIR_ALGO_BYTES / (x_ms * 1e-3) / 1e9,
                 "frac": xi["n_pairs"] * PAIR_ALGO_BYTES / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "int_mad_frac": xi["n_pairs"] * PAIR_MADS / (x_ms * 1e-3) / INT_MAD_PEAK,
+                "int_mad_frac_at_2_waves_per_simd": xi["n_pairs"] * PAIR_MADS / (x_ms * 1e-3) / INT_MAD_AT_2_WAVES,
                 "phase_ms": xi["phase_ms"],
                 # the counting sort (histogram + scans + scatter): 2 N K entries, each read twice as a 4-byte digit and
                 # written once as a 4-byte payload to a random slot of its bucket
@@ -232,10 +289,15 @@ def main():
                     "peak": HBM_PEAK_GBS,
                     "unit": "GB/s",
                     "frac": 2 * n * K * SORT_ALGO_BYTES / (xi["phase_ms"]["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "note": "random 4-byte stores: every payload write dirties its own 64-byte sector, so the algorithmic "
-                            "rate understates the sectors moved; hidden under the accumulation of the other window group",
                 },
             }
+            # the same MSM with the scalars handed over as a HOST buffer (2^n x 32 bytes cross PCIe first): never `value`
+            _, s_host = ctx.generate_scalars(n, seed=1000, to_host=True, raw=True)
+            tp = time.perf_counter()
+            ctx.run(s_host, c=c)
+            pms = (time.perf_counter() - tp) * 1e3
+            del s_host
+            pcie = {"ms": pms, "points_per_s": n / (pms * 1e-3), "note": "one MSM with host-resident (pageable) scalars"}
         out = {
             "metric": f"{'BLS12-381' if is381 else 'BLS12-377'} G1 MSM throughput",
             "value": n * args.steps / dt,
@@ -256,8 +318,12 @@ def main():
                 "windows": K,
                 "parallelism": "single-gpu" if world == 1 else f"window-shard x{world}, one RCCL all-gather of {K}x144 B",
                 "points": "P_i = a_i*G generated on GPU (resident)",
-                "scalars": "uniform < q, fresh per step, resident in HBM before the timed region",
+                "scalars": f"uniform < q, fresh per step ({n_sets} distinct sets cycled), resident in HBM before the timed region",
             },
+            "verified": verified,
+            "verified_how": "last timed result == (sum s_i a_i mod q) G from the known discrete logs of the generated points "
+                            "(dot product: oracle/msm_oracle.c, scalar multiplication: oracle/msm_oracle.py), outside the timed region",
+            **step_stats(step_ms),
             "roofline": {
                 "kernel": "k_batch_add (bucket accumulation tree, all rounds)",
                 "bound": "hbm",
@@ -266,8 +332,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pairs / launches * PAIR_TRAFFIC_BYTES_PMC,
-                "traffic_note": "bytes per launch = pair additions per launch x 485 B/pair from the committed PMC passes "
-                                "(profiles/r01_pmc_2p24.json, regular rounds); not collected inside this run",
+                "traffic_note": "bytes per launch = pair additions per launch x the bytes per pair of the committed PMC passes "
+                                "(profiles/, regular rounds); not collected inside this run",
                 "algorithmic_bytes_per_launch": pairs / launches * PAIR_ALGO_BYTES,
                 "algorithmic_bytes_per_pair_add": PAIR_ALGO_BYTES,
                 "pair_adds_per_step": pairs / max(len(infos), 1),
@@ -280,16 +346,20 @@ def main():
                     "frac": (pairs * PAIR_MADS / (acc_ms * 1e-3) / INT_MAD_PEAK) if acc_ms else 0.0,
                 },
                 "exclusive": excl,
-                "note": "the kernel is integer-ALU bound (no MFMA path exists for carry-propagated big integers); 'hbm' is the "
-                        "nearer of the two allowed labels, int_mad carries the ALU roofline; 'exclusive' = same kernels with the "
-                        "two window-group streams serialised (one untimed step)",
+                "note": "achieved = pair additions x 288 algorithmic bytes / event-timed accumulation time; the launches of the two "
+                        "window-group streams overlap, 'exclusive' = the same kernels with the streams serialised (one untimed step). "
+                        "The kernel moves ~490 B per pair addition (prefix-product scratch, second read of x) and is bound by that "
+                        "traffic: with the multiplications compiled out it runs in 83 % of its time (DESIGN.md section 5)",
             },
             "phase_ms": phase,
+            "pcie_inclusive": pcie,
             "result_is_infinity": bool(last.isZero) if last is not None else None,
         }
         if world == 1 and not args.no_cpu_baseline and not is381:
             out["cpu_baseline"] = cpu_baseline(ctx, min(args.cpu_log2n, args.log2n), seed=777)
         print(json.dumps(out), flush=True)
+        if verified is False:
+            sys.exit("bench: the MSM result failed the known-discrete-log check")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

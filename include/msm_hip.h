@@ -32,7 +32,9 @@ enum {
   MSM_ERR_HIP = 2,         /* HIP runtime failure (message has the HIP error string) */
   MSM_ERR_POINT = 3,       /* coordinate >= p, or point not on the curve (when validation is requested) */
   MSM_ERR_NO_POINTS = 4,   /* msm called before msm_set_points, or with n > resident points */
-  MSM_ERR_NO_DEVICE = 5    /* no usable GPU: there is no CPU fallback */
+  MSM_ERR_NO_DEVICE = 5,   /* no usable GPU: there is no CPU fallback */
+  MSM_ERR_SCALAR = 6,      /* a scalar >= the group order q and msm_opts.strict was set (default: reduced mod q) */
+  MSM_ERR_INTERNAL = 7     /* host allocation failure or another unexpected condition; no C++ exception crosses this ABI */
 };
 
 enum {
@@ -57,7 +59,9 @@ typedef struct msm_opts {
   int32_t no_glv;       /* != 0 (Weierstrass curves): no endomorphism split -- digits of the full scalar, K = ceil((b + 1) / c)
                            with b = bit length of q: the window structure of msmProjective / msmBasic
                            (src/parallel.ts:69-87, src/msm-basic.ts:56-91).  Same group element, 2x the additions */
-  int32_t reserved[2];
+  int32_t strict;       /* != 0: a scalar >= q fails the call with MSM_ERR_SCALAR.  Default: such scalars are reduced mod q
+                           (the reference specifies inputs < q, src/curve-random.ts:151-194, and does not check) */
+  int32_t reserved[1];
 } msm_opts;
 
 #define MSM_N_PHASES 8
@@ -74,7 +78,7 @@ typedef struct msm_result {
   int32_t is_infinity;  /* Weierstrass only; twisted Edwards returns (0, 1) for the identity */
   int32_t c;            /* window size used */
   int32_t K;            /* number of windows */
-  int32_t rounds;       /* accumulation tree rounds of the last window group */
+  int32_t rounds;       /* accumulation tree rounds (k_batch_add launches) summed over all window groups */
   float phase_ms[MSM_N_PHASES];
   uint64_t n_pairs;     /* affine pair additions issued (all rounds, all windows) */
   uint64_t max_bucket;  /* largest bucket population seen */
@@ -83,6 +87,14 @@ typedef struct msm_result {
 /* Context: binds one curve to one GPU (device index as seen by HIP). Replaces
  * `Weierstraß.create(params)` / `TwistedEdwards.create(params)` (src/parallel.ts:40-66, 179-200). */
 int msm_ctx_create(msm_ctx** out, int curve, int device);
+/* The same over a device list ("create(curve id, device list)").  Every device holds the whole
+ * point set; msm_run / msm_window_sums cut the window range into one contiguous shard per device (windows are
+ * independent until the final sum, src/msm-batched-affine.ts:312-333), run the shards from one host thread per device
+ * and combine the K x 144 bytes of partition sums on the host -- so a C or JS host can use a whole node without
+ * torch.distributed.  Device scalars must live on devices[0]; they are copied peer-to-peer to the others.
+ * (bench.py --gpus N keeps the one-process-per-GPU RCCL form of the north star.) */
+int msm_ctx_create_multi(msm_ctx** out, int curve, const int32_t* devices, int32_t n_devices);
+int msm_ctx_device_count(const msm_ctx* ctx);
 void msm_ctx_destroy(msm_ctx* ctx);
 const char* msm_last_error(const msm_ctx* ctx);
 
@@ -91,6 +103,19 @@ const char* msm_last_error(const msm_ctx* ctx);
  * per call as in preparePointsAndScalars, src/msm-batched-affine.ts:350-421).
  * on_device != 0: `points` is a device pointer.  check_curve != 0: verify the curve equation. */
 int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, int check_curve);
+
+/* Point-set handles (the reference's `pointPtr`s are independent allocations, src/parallel.ts:97-116): a context starts
+ * with point set 0; msm_pointset_create adds an empty one and makes it current, msm_pointset_select switches.
+ * msm_set_points / msm_generate_points / msm_run / msm_get_points always act on the current set. */
+int msm_pointset_create(msm_ctx* ctx, int32_t* id_out);
+int msm_pointset_select(msm_ctx* ctx, int32_t id);
+int msm_pointset_destroy(msm_ctx* ctx, int32_t id);
+
+/* Device buffers for scalar handles (`scalarPtr`s are independent allocations too): owned by the context, freed by
+ * msm_device_free or with the context.  On a multi-device context they live on devices[0]. */
+int msm_device_alloc(msm_ctx* ctx, uint64_t bytes, void** dev_ptr_out);
+int msm_device_free(msm_ctx* ctx, void* dev_ptr);
+int msm_device_upload(msm_ctx* ctx, void* dev_ptr, const void* host, uint64_t bytes);
 
 /* sum_i scalars[i] * points[i] over the first n resident points
  * (msm / msmUnsafe, src/msm-batched-affine.ts:69-340, 587-598; for the Edwards curve msmBasic,

@@ -2,7 +2,8 @@
 // (src/parallel.ts:135-160, 251-289; scripts/zprize23/submission-bls377.ts:20-23).
 export type CurveParams = { label: string; modulus: bigint; order: bigint };
 
-export type PointPtr = { size: number; n: number };
+/** one resident point set of the context (its own allocation, like every pointer of the reference) */
+export type PointPtr = { size: number; n: number; set: number; free(): void };
 export type ScalarPtr = { size: number; bytes: Buffer | null; n: number };
 
 /** canonical affine result: what `Affine.toBigint(Projective.toAffine(result))` yields in the reference */
@@ -35,14 +36,22 @@ export interface Curve {
   close(): void;
 }
 
-export const Weierstrass: { create(params: CurveParams, device?: number): Curve };
-export const TwistedEdwards: { create(params: CurveParams, device?: number): Curve };
+/** device: a GPU index, or a list of indices: one curve object over several GPUs of the node (windows sharded inside the library) */
+export const Weierstrass: { create(params: CurveParams, device?: number | number[]): Curve };
+export const TwistedEdwards: { create(params: CurveParams, device?: number | number[]): Curve };
 export const bls12377Params: CurveParams;
 export const bls12381Params: CurveParams;
 export const pallasParams: CurveParams;
 export const edOnBls12377Params: CurveParams;
 
-/** scripts/zprize23/submission-bls377.ts:20-65, submission.ts:19-60 */
+/** shared body of the per-curve entries js/submission-bls377.js and js/submission.js, which export the reference's exact
+ * `compute_msm(inputPoints, inputScalars)` (scripts/zprize23/submission-bls377.ts:20-65, submission.ts:19-60) */
+export function compute_msm_on(
+  curve: Curve,
+  coordBytes: number,
+  inputPoints: { x: bigint; y: bigint; isZero?: boolean }[] | Uint8Array,
+  inputScalars: bigint[] | Uint8Array
+): Promise<{ x: bigint; y: bigint }>;
 export function compute_msm(
   curve: Curve,
   coordBytes: number,

@@ -4,6 +4,8 @@
 const fs = require("fs");
 const path = require("path");
 const M = require("./montgomery-hip.js");
+const subBls = require("./submission-bls377.js");   // compute_msm(points, scalars): the reference's signature
+const subEd = require("./submission.js");
 
 function assert(c, msg) { if (!c) { console.error("FAILED: " + msg); process.exit(1); } }
 
@@ -16,8 +18,10 @@ async function main() {
     isZero: false,
   };
   const q = M.bls12377Params.order;
-  let r = await M.compute_msm(bls, 48, [point, point], [BigInt(2), q - BigInt(1)]);
+  let r = await subBls.compute_msm([point, point], [BigInt(2), q - BigInt(1)]);
   assert(r.x === point.x && r.y === point.y, "2P + (q-1)P = P");
+  r = await M.compute_msm(bls, 48, [point, point], [BigInt(2), q - BigInt(1)]);
+  assert(r.x === point.x && r.y === point.y, "2P + (q-1)P = P (explicit curve object)");
   console.log("2 points ok");
   const n = 1000;
   let scalars = [], sum = BigInt(0);
@@ -27,8 +31,8 @@ async function main() {
     scalars.push(seed % q);
     sum = (sum + scalars[i]) % q;
   }
-  const r2 = await M.compute_msm(bls, 48, Array(n).fill(point), scalars);
-  const r3 = await M.compute_msm(bls, 48, [point], [sum]);
+  const r2 = await subBls.compute_msm(Array(n).fill(point), scalars);
+  const r3 = await subBls.compute_msm([point], [sum]);
   assert(r2.x === r3.x && r2.y === r3.y, "same points: msm = (sum s) P");
   console.log("same points ok");
   const gold = JSON.parse(fs.readFileSync(path.join(__dirname, "..", "tests", "golden", "msm377.json"), "utf8"));
@@ -43,7 +47,29 @@ async function main() {
     assert(log.length > 0, "log");
   }
   console.log("golden bls12-377 ok:", gold.cases.length, "cases");
+  {
+    // two point pointers side by side: the second pointsFromBytes must not replace the points behind the first
+    const a = gold.cases[0], b = gold.cases[1];
+    const pa = bls.Parallel.getPointer(a.points.length / 2), pb = bls.Parallel.getPointer(b.points.length / 2);
+    const sa = bls.Parallel.getScalarPointer(a.scalars.length / 2), sb = bls.Parallel.getScalarPointer(b.scalars.length / 2);
+    await bls.Parallel.pointsFromBytes(pa, Buffer.from(a.points, "hex"), a.n);
+    await bls.Parallel.pointsFromBytes(pb, Buffer.from(b.points, "hex"), b.n);
+    await bls.Parallel.scalarsFromBytes(sa, Buffer.from(a.scalars, "hex"), a.n);
+    await bls.Parallel.scalarsFromBytes(sb, Buffer.from(b.scalars, "hex"), b.n);
+    for (const [c, sp, pp] of [[a, sa, pa], [b, sb, pb], [a, sa, pa]]) {
+      const { result } = await bls.Parallel.msm(sp, pp, c.n, false, { c: c.c || 0 });
+      if (c.result === null) assert(result.isZero, "pointer " + c.name);
+      else assert(result.x === BigInt(c.result[0]) && result.y === BigInt(c.result[1]), "pointer " + c.name);
+    }
+    console.log("two point pointers ok");
+  }
   bls.close();
+  let threw = false;
+  try { bls.close(); } catch (e) { threw = true; }
+  assert(threw, "a second close() of the same context must throw, not double-free");
+  threw = false;
+  try { M.hip.setPoints(M.hip.createContext(M.hip.CURVE_BLS12_377_G1, 0), Buffer.alloc(96), 64, 0); } catch (e) { threw = true; }
+  assert(threw, "setPoints with a point size that is not the curve's must throw");
 
   // --- Ed-on-BLS12-377 (submission-test.ts:5-21)
   const ed = M.TwistedEdwards.create(M.edOnBls12377Params);
@@ -51,7 +77,7 @@ async function main() {
     x: BigInt("2796670805570508460920584878396618987767121022598342527208237783066948667246"),
     y: BigInt("8134280397689638111748378379571739274369602049665521098046934931245960532166"),
   };
-  r = await M.compute_msm(ed, 32, [ep, ep], [BigInt(2), M.edOnBls12377Params.order - BigInt(1)]);
+  r = await subEd.compute_msm([ep, ep], [BigInt(2), M.edOnBls12377Params.order - BigInt(1)]);
   assert(r.x === ep.x && r.y === ep.y, "ed: 2P + (q-1)P = P");
   const goldEd = JSON.parse(fs.readFileSync(path.join(__dirname, "..", "tests", "golden", "msm_ed377.json"), "utf8"));
   for (const c of goldEd.cases) {

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MSM_HIP_LIB: A/B experiments with alternative builds of the same extension (tools/ab_time.py)
 LIB_PATH = os.environ.get("MSM_HIP_LIB") or os.path.join(_HERE, "libmsm_hip.so")
 
-MSM_OK, MSM_ERR_ARG, MSM_ERR_HIP, MSM_ERR_POINT, MSM_ERR_NO_POINTS, MSM_ERR_NO_DEVICE = range(6)
+MSM_OK, MSM_ERR_ARG, MSM_ERR_HIP, MSM_ERR_POINT, MSM_ERR_NO_POINTS, MSM_ERR_NO_DEVICE, MSM_ERR_SCALAR, MSM_ERR_INTERNAL = range(8)
 CURVE_BLS12_377_G1 = 0
 CURVE_ED_ON_BLS12_377 = 1
 CURVE_BLS12_381_G1 = 2
@@ -27,12 +27,14 @@ EXPORTS = (
     "msm_ctx_create", "msm_ctx_destroy", "msm_last_error", "msm_set_points", "msm_run", "msm_window_sums",
     "msm_combine", "msm_combine_curve", "msm_plan", "msm_generate_points", "msm_generate_scalars", "msm_get_points", "msm_test_fp",
     "msm_test_glv", "msm_test_batch_add", "msm_test_batch_inverse",
+    "msm_ctx_create_multi", "msm_ctx_device_count", "msm_pointset_create", "msm_pointset_select", "msm_pointset_destroy",
+    "msm_device_alloc", "msm_device_free", "msm_device_upload",
 )
 
 
 class MsmOpts(C.Structure):
     _fields_ = [("c", C.c_int32), ("unsafe", C.c_int32), ("k_lo", C.c_int32), ("k_hi", C.c_int32), ("serial", C.c_int32),
-                ("no_glv", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("no_glv", C.c_int32), ("strict", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class MsmResult(C.Structure):
@@ -87,6 +89,14 @@ def load() -> C.CDLL:
     lib.msm_test_glv.argtypes = [vp, vp, vp, u64]
     lib.msm_test_batch_add.argtypes = [vp, vp, vp, vp, u64]
     lib.msm_test_batch_inverse.argtypes = [vp, vp, vp, u64, C.c_uint32]
+    lib.msm_ctx_create_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(i32), i32]
+    lib.msm_ctx_device_count.argtypes = [vp]
+    lib.msm_pointset_create.argtypes = [vp, C.POINTER(i32)]
+    lib.msm_pointset_select.argtypes = [vp, i32]
+    lib.msm_pointset_destroy.argtypes = [vp, i32]
+    lib.msm_device_alloc.argtypes = [vp, u64, C.POINTER(vp)]
+    lib.msm_device_free.argtypes = [vp, vp]
+    lib.msm_device_upload.argtypes = [vp, vp, vp, u64]
     for name in EXPORTS:
         if name not in ("msm_ctx_destroy", "msm_last_error"):
             getattr(lib, name).restype = C.c_int

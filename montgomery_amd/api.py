@@ -15,7 +15,7 @@ either on the host or in HBM).  All arithmetic happens in libmsm_hip.so; there i
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 from . import _lib
@@ -150,16 +150,25 @@ def _result_to_dict(res: MsmResult) -> Dict:
 class MsmContext:
     """One curve bound to one GPU: thin object wrapper over the msm_* C functions."""
 
-    def __init__(self, curve: int = _lib.CURVE_BLS12_377_G1, device: int = 0):
+    def __init__(self, curve: int = _lib.CURVE_BLS12_377_G1, device: int = 0, devices: Optional[Sequence[int]] = None):
+        """device: one GPU.  devices: a list of GPUs of this node -- the context then shards every MSM by scalar window
+        across them from host threads inside the library (msm_ctx_create_multi)."""
         self._lib = _lib.load()
         h = C.c_void_p()
-        rc = self._lib.msm_ctx_create(C.byref(h), curve, device)
+        if devices is not None and len(devices) > 0:
+            arr = (C.c_int32 * len(devices))(*devices)
+            rc = self._lib.msm_ctx_create_multi(C.byref(h), curve, arr, len(devices))
+            device = devices[0]
+        else:
+            rc = self._lib.msm_ctx_create(C.byref(h), curve, device)
         if rc != _lib.MSM_OK:
             raise MsmError(rc, "msm_ctx_create failed (no usable GPU?) -- there is no CPU fallback")
         self._h = h
         self.curve = curve
         self.device = device
         self.n_points = 0
+        self._cur_set = 0
+        self._set_sizes: Dict[int, int] = {0: 0}
         self.coord_bytes = 32 if curve == _lib.CURVE_ED_ON_BLS12_377 else 48
 
     def close(self) -> None:
@@ -177,6 +186,43 @@ class MsmContext:
         if rc != _lib.MSM_OK:
             raise MsmError(rc, self._lib.msm_last_error(self._h).decode())
 
+    # -- handles: point sets and device buffers ----------------------------------------------
+    def pointset_create(self) -> int:
+        """A new, empty resident point set; it becomes the current one (msm_pointset_create)."""
+        i = C.c_int32()
+        self._check(self._lib.msm_pointset_create(self._h, C.byref(i)))
+        self.n_points = 0
+        self._set_sizes[i.value] = 0
+        return i.value
+
+    def pointset_select(self, set_id: int) -> None:
+        self._check(self._lib.msm_pointset_select(self._h, set_id))
+        self._cur_set = set_id
+        self.n_points = self._set_sizes.get(set_id, 0)
+
+    def pointset_destroy(self, set_id: int) -> None:
+        self._check(self._lib.msm_pointset_destroy(self._h, set_id))
+        self._set_sizes.pop(set_id, None)
+        if self._cur_set == set_id:
+            self._cur_set = 0
+            self.n_points = self._set_sizes.get(0, 0)
+
+    def device_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self._lib.msm_device_alloc(self._h, nbytes, C.byref(p)))
+        return int(p.value)
+
+    def device_free(self, dev_ptr: int) -> None:
+        self._check(self._lib.msm_device_free(self._h, C.c_void_p(dev_ptr)))
+
+    def device_upload(self, dev_ptr: int, data: BytesLike) -> None:
+        buf = data if isinstance(data, C.Array) else (C.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")
+        self._check(self._lib.msm_device_upload(self._h, C.c_void_p(dev_ptr), buf, len(data)))
+
+    @property
+    def n_devices(self) -> int:
+        return int(self._lib.msm_ctx_device_count(self._h))
+
     # -- points ---------------------------------------------------------------------------
     def set_points(self, points: BytesLike, check_curve: bool = False) -> int:
         step = 2 * self.coord_bytes
@@ -186,24 +232,34 @@ class MsmContext:
         buf = (C.c_uint8 * max(len(points), 1)).from_buffer_copy(bytes(points) or b"\0")
         self._check(self._lib.msm_set_points(self._h, buf, n, 0, int(check_curve)))
         self.n_points = n
+        self._set_sizes[self._cur_set] = n
         return n
 
     def set_points_device(self, dev_ptr: int, n: int, check_curve: bool = False) -> int:
         self._check(self._lib.msm_set_points(self._h, C.c_void_p(dev_ptr), n, 1, int(check_curve)))
         self.n_points = n
+        self._set_sizes[self._cur_set] = n
         return n
 
-    def generate_points(self, n: int, seed: int = 1, want_scalars: bool = False) -> Optional[bytes]:
+    def generate_points(self, n: int, seed: int = 1, want_scalars: bool = False, raw: bool = False):
+        """n resident points P_i = a_i G generated on the GPU.  want_scalars: also return the a_i (n x 32 bytes LE) --
+        as `bytes`, or with raw=True as the ctypes array itself (no second 2 GB copy at 2^26)."""
         out = (C.c_uint8 * (32 * n))() if want_scalars and n else None
         self._check(self._lib.msm_generate_points(self._h, n, seed, out))
         self.n_points = n
+        self._set_sizes[self._cur_set] = n
+        if out is not None and raw:
+            return out
         return bytes(out) if out is not None else (b"" if want_scalars else None)
 
-    def generate_scalars(self, n: int, seed: int = 1, to_host: bool = False, into: int = 0) -> Tuple[int, Optional[bytes]]:
-        """n random scalars < q on the device.  `into`: caller-owned device pointer (n * 32 bytes), 0 = library buffer."""
+    def generate_scalars(self, n: int, seed: int = 1, to_host: bool = False, into: int = 0, raw: bool = False):
+        """n random scalars < q on the device.  `into`: caller-owned device pointer (n * 32 bytes), 0 = library buffer.
+        to_host: also return a host copy (bytes; the ctypes array itself with raw=True)."""
         dev = C.c_void_p(into or None)
         out = (C.c_uint8 * (32 * n))() if to_host and n else None
         self._check(self._lib.msm_generate_scalars(self._h, n, seed, C.byref(dev), out))
+        if out is not None and raw:
+            return int(dev.value or 0), out
         return int(dev.value or 0), (bytes(out) if out is not None else None)
 
     def get_points(self, first: int, count: int) -> bytes:
@@ -229,7 +285,8 @@ class MsmContext:
         if len(scalars) % 32:
             raise MsmError(_lib.MSM_ERR_ARG, f"scalar buffer length {len(scalars)} is not a multiple of 32")
         n = len(scalars) // 32
-        buf = (C.c_uint8 * max(len(scalars), 1)).from_buffer_copy(bytes(scalars) or b"\0")
+        # a ctypes array is handed over as it is (no 2 GB copies at 2^26), anything else is copied once
+        buf = scalars if isinstance(scalars, C.Array) else (C.c_uint8 * max(len(scalars), 1)).from_buffer_copy(bytes(scalars) or b"\0")
         return self._run(buf, n, 0, c, unsafe, no_glv=no_glv)
 
     def run_device(self, dev_ptr: int, n: int, c: Optional[int] = None, unsafe: bool = False, serial: bool = False,
@@ -252,6 +309,8 @@ class MsmContext:
     def window_sums(self, scalars: Union[BytesLike, int], n: int, k_lo: int, k_hi: int, c: Optional[int] = None,
                     on_device: bool = False) -> Tuple[bytes, Dict]:
         """Partition sums P_k, k in [k_lo, k_hi): (k_hi - k_lo) x 144 bytes (X, Y, Z)."""
+        if k_hi <= k_lo or k_lo < 0:   # (0, 0) would mean "all windows" to the C side and overrun the 144-byte buffer below
+            raise MsmError(_lib.MSM_ERR_ARG, f"empty or negative window range [{k_lo}, {k_hi})")
         opts = MsmOpts(c=c or 0, k_lo=k_lo, k_hi=k_hi)
         res = MsmResult()
         out = (C.c_uint8 * (144 * max(k_hi - k_lo, 1)))()
@@ -314,22 +373,43 @@ class MsmContext:
 # ---------------------------------------------------------------------------------------------
 
 
-@dataclass
 class PointPtr:
-    """Handle standing in for the reference's `pointPtr` (byte offset of an affine point array)."""
+    """Handle standing in for the reference's `pointPtr` (byte offset of an affine point array): one resident point set
+    of the context, its own allocation like every pointer of the reference; freed when the handle goes away."""
 
-    size: int = 0
-    n: int = 0
+    def __init__(self, ctx: Optional["MsmContext"] = None, size: int = 0, n: int = 0, set_id: int = 0):
+        self._ctx, self.size, self.n, self.set_id = ctx, size, n, set_id
+
+    def close(self) -> None:
+        ctx, self._ctx = self._ctx, None
+        if ctx is not None and self.set_id > 0 and getattr(ctx, "_h", None):
+            ctx.pointset_destroy(self.set_id)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
-@dataclass
 class ScalarPtr:
-    """Handle standing in for `scalarPtr`: host bytes or a device pointer with a count."""
+    """Handle standing in for `scalarPtr`: host bytes (`scalarsFromBytes`) or a device buffer of its own
+    (`randomScalars`); the device buffer is freed when the handle goes away."""
 
-    size: int = 0
-    data: bytes = b""
-    dev_ptr: int = 0
-    n: int = 0
+    def __init__(self, ctx: Optional["MsmContext"] = None, size: int = 0, data: bytes = b"", dev_ptr: int = 0, n: int = 0):
+        self._ctx, self.size, self.data, self.dev_ptr, self.n = ctx, size, data, dev_ptr, n
+
+    def close(self) -> None:
+        ctx, self._ctx = self._ctx, None
+        if ctx is not None and self.dev_ptr and getattr(ctx, "_h", None):
+            ctx.device_free(self.dev_ptr)
+        self.dev_ptr = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _Parallel:
@@ -343,10 +423,10 @@ class _Parallel:
         self._wire_bytes = (params.modulus.bit_length() + 7) // 8 if hasattr(params, "modulus") else ctx.coord_bytes
 
     def getPointer(self, size: int) -> PointPtr:
-        return PointPtr(size=size)
+        return PointPtr(self._ctx, size=size, set_id=self._ctx.pointset_create())
 
     def getScalarPointer(self, size: int) -> ScalarPtr:
-        return ScalarPtr(size=size)
+        return ScalarPtr(self._ctx, size=size)
 
     def pointsFromBytes(self, pointPtr: PointPtr, pointInput: BytesLike, n: int) -> None:
         """src/parallel.ts:97-116 (96 B/point) / :215-229 (64 B/point): x || y little-endian -> resident device points."""
@@ -358,6 +438,7 @@ class _Parallel:
             padded = np.zeros((2 * n, cb), dtype=np.uint8)
             padded[:, :wb] = np.frombuffer(buf, dtype=np.uint8).reshape(2 * n, wb)
             buf = padded.tobytes()
+        self._ctx.pointset_select(pointPtr.set_id)
         self._ctx.set_points(buf)
         pointPtr.n = n
 
@@ -369,21 +450,27 @@ class _Parallel:
 
     def randomPointsFast(self, n: int, seed: int = 1) -> PointPtr:
         """src/curve-random.ts:14-92 (generated on the GPU; the seed is explicit, the reference is unseeded)."""
+        ptr = self.getPointer(2 * self._wire_bytes * n)
         self._ctx.generate_points(n, seed)
-        return PointPtr(size=96 * n, n=n)
+        ptr.n = n
+        return ptr
 
     def randomScalars(self, n: int, seed: int = 1) -> ScalarPtr:
         """src/curve-random.ts:151-194."""
-        dev, _ = self._ctx.generate_scalars(n, seed)
-        return ScalarPtr(size=32 * n, dev_ptr=dev, n=n)
+        dev = self._ctx.device_alloc(32 * max(n, 1))   # the handle's own buffer: two handles never alias
+        self._ctx.generate_scalars(n, seed, into=dev)
+        return ScalarPtr(self._ctx, size=32 * n, dev_ptr=dev, n=n)
 
     def msm(self, scalarPtr: ScalarPtr, pointPtr: PointPtr, N: int, verboseTiming: bool = False,
             options: Optional[Dict] = None) -> Dict:
         """`msm` (src/msm-batched-affine.ts:69-340): returns {"result": AffineResult, "log": [...]}.
         options: {"c": window bits, "useSafeAdditions": bool}."""
         options = options or {}
-        if N > self._ctx.n_points:
-            raise MsmError(_lib.MSM_ERR_NO_POINTS, f"{N} scalars but {self._ctx.n_points} resident points")
+        self._ctx.pointset_select(pointPtr.set_id)
+        if N > pointPtr.n or N > self._ctx.n_points:
+            raise MsmError(_lib.MSM_ERR_NO_POINTS, f"{N} scalars but {min(pointPtr.n, self._ctx.n_points)} points behind this pointer")
+        if N > scalarPtr.n:
+            raise MsmError(_lib.MSM_ERR_ARG, f"{N} scalars requested but the scalar pointer holds {scalarPtr.n}")
         unsafe = not options.get("useSafeAdditions", True)
         no_glv = bool(options.get("noGlv", False))
         if scalarPtr.dev_ptr:

@@ -13,12 +13,26 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <exception>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 using namespace msm;
+
+// Experiment knobs (window-group count, round geometry, ...) are environment variables ONLY in builds made with
+// -DMSM_TUNING (tools/policy_sweep.sh, make ab EXTRA=-DMSM_TUNING); the product never reads the environment.
+#ifdef MSM_TUNING
+#define MSM_KNOB(var, name, lo) do { if (const char* _e = getenv(name)) var = std::max<long long>((lo), atoll(_e)); } while (0)
+#define MSM_KNOB_SET(name) (getenv(name) != nullptr)
+#else
+#define MSM_KNOB(var, name, lo) do { } while (0)
+#define MSM_KNOB_SET(name) false
+#endif
 
 namespace {
 
@@ -31,6 +45,12 @@ struct HipFail {
   hipError_t e;
   const char* what;
   int line;
+};
+
+// non-HIP failure raised inside the pipeline (mapped to its error code at the ABI boundary)
+struct MsmFail {
+  int code;
+  std::string msg;
 };
 
 #define HIPCHK(x)                                   \
@@ -65,17 +85,85 @@ inline const CurveInfo& curve_info(int curve) {
   return curve == MSM_CURVE_BLS12_381_G1 ? bls381 : curve == MSM_CURVE_PALLAS ? pallas : curve == MSM_CURVE_ED_ON_BLS12_377 ? ed377 : bls377;
 }
 
+// One helper thread per context, started with it: the second window group of a big MSM runs here (the calling thread
+// takes the first), so no thread is created per call.  run() hands over a job, wait() returns when it is done and
+// re-raises whatever the job threw.
+class HelperThread {
+ public:
+  HelperThread() : th_([this] { loop(); }) {}
+  ~HelperThread() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    th_.join();
+  }
+  void run(std::function<void()> job) {
+    std::lock_guard<std::mutex> l(mu_);
+    job_ = std::move(job);
+    busy_ = true;
+    err_ = nullptr;
+    cv_.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> l(mu_);
+    cv_.wait(l, [this] { return !busy_; });
+    if (err_) {
+      std::exception_ptr e = err_;
+      err_ = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+
+ private:
+  void loop() {
+    std::unique_lock<std::mutex> l(mu_);
+    for (;;) {
+      cv_.wait(l, [this] { return quit_ || (busy_ && job_); });
+      if (quit_) return;
+      std::function<void()> job = std::move(job_);
+      job_ = nullptr;
+      l.unlock();
+      std::exception_ptr e;
+      try { job(); } catch (...) { e = std::current_exception(); }
+      l.lock();
+      err_ = e;
+      busy_ = false;
+      cv_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::function<void()> job_;
+  std::exception_ptr err_;
+  bool busy_ = false, quit_ = false;
+  std::thread th_;   // last member: the thread starts after everything it touches exists
+};
+
 struct msm_ctx {
+  std::unique_ptr<HelperThread> helper;
   int curve = 0;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[12];
+  hipEvent_t ev[12] = {};
   std::string err;
   int n_cu = 256;
 
-  // resident points
+  // resident points: `rows` / `n_points` are the CURRENT point set; the others wait in `sets` (msm_pointset_*)
   DevBuf rows;
   uint64_t n_points = 0;
+  struct PointSet {
+    DevBuf rows;
+    uint64_t n = 0;
+    bool live = false;
+  };
+  std::vector<PointSet> sets = std::vector<PointSet>(1);   // slot 0 = the default set
+  int cur_set = 0;
+  std::vector<void*> allocs;        // device buffers handed out by msm_device_alloc
+  // multi-device context (msm_ctx_create_multi): this context drives devices[0], one child context per further device
+  std::vector<msm_ctx*> children;
+  std::vector<std::unique_ptr<HelperThread>> fan;   // one host thread per child for the window-shard fan-out
 
   // staging / misc buffers shared by all window groups
   DevBuf scal, errflag, misc;
@@ -88,7 +176,7 @@ struct msm_ctx {
     DevBuf dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, columns2, rows_sum, bucket_proj, bufA, bufB,
         scratch, columns, partials, part, dig2, idx2, block_hist2, blk_tab, blk_tab2;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8];
+    hipEvent_t ev[8] = {};
     uint32_t* h_info = nullptr;   // pinned, 64 words
     uint32_t* h_part = nullptr;   // pinned, window sums read-back
     DevBuf* all[23] = {&dig, &counts, &cursor, &tail_off, &info, &slots, &block_hist, &scan_partial, &desc, &columns2, &rows_sum,
@@ -151,6 +239,14 @@ int fail_hip(msm_ctx* ctx, const HipFail& f) {
   return fail(ctx, MSM_ERR_HIP, "HIP error %d (%s) at msm_api.hip:%d: %s", (int)f.e, hipGetErrorString(f.e), f.line, f.what);
 }
 
+// every extern "C" entry point ends its try block with this: no C++ exception crosses the C ABI
+#define MSM_CATCH_ALL(ctx)                                                                                  \
+  catch (const HipFail& f) { return fail_hip(ctx, f); }                                                     \
+  catch (const MsmFail& f) { return fail(ctx, f.code, "%s", f.msg.c_str()); }                               \
+  catch (const std::bad_alloc&) { return fail(ctx, MSM_ERR_INTERNAL, "host memory allocation failed"); }    \
+  catch (const std::exception& e) { return fail(ctx, MSM_ERR_INTERNAL, "unexpected exception: %s", e.what()); } \
+  catch (...) { return fail(ctx, MSM_ERR_INTERNAL, "unexpected exception"); }
+
 // GPU-tuned window size (the reference's table, src/msm-common.ts:25-41, was tuned for 16 CPU threads and copies
 // points).  Weierstrass + GLV (b + 1 = 127 or 128 bits): measured over N = 2^4 .. 2^26 (tools/small_sizes.py), c = 16
 // (K = 8, no degenerate top window, one window's counters fit the LDS) wins from N = 2^12 up -- by 20 % over c = 13
@@ -178,6 +274,7 @@ struct Plan {
   int c, K, L_log;
   uint32_t L;
   bool no_glv;
+  bool strict = false;   // msm_opts.strict: scalars >= q fail the call instead of being reduced
   bool lone = false;   // one window, one group: nothing else shares the GPU (see round_geom)
 };
 
@@ -189,6 +286,7 @@ int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
   // b = Scalar.maxBits (126 after GLV, src/wasm/glv.ts:216-226) or Scalar.sizeInBits (251, src/msm-basic.ts:56)
   // b = Scalar.maxBits after GLV (src/wasm/glv.ts:216-226), or the bit length of q without it (src/msm-basic.ts:56)
   pl.no_glv = !te && opts && opts->no_glv;
+  pl.strict = opts && opts->strict;
   const int b = te ? 251 : pl.no_glv ? curve_info(ctx ? ctx->curve : MSM_CURVE_BLS12_377_G1).q_bits : glv_bits;
   if (pl.no_glv && c < 4) return MSM_ERR_ARG;   // keeps K <= 64
   pl.c = c;
@@ -222,11 +320,15 @@ struct RoundGeom {
 RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather = false, bool lone = false) {
   uint64_t target = (uint64_t)ctx->n_cu * 4 * MSM_BA_WAVES * 64;  // as many lanes as the kernel's launch bounds keep resident
   uint64_t half_below = 0;  // steps at full width below which a non-gather round runs on half as many lanes (to be retuned)
-  if (const char* e = getenv("MSM_HALF_BELOW")) half_below = (uint64_t)std::max(0, atoi(e));
+  MSM_KNOB(half_below, "MSM_HALF_BELOW", 0);
   if (!gather && n_out < target * half_below) target /= 2;
   uint32_t max_steps = (lone && n_out >= target * 512) ? 128 : 512;
-  if (const char* e = getenv("MSM_MAX_STEPS")) max_steps = (uint32_t)std::max(1, atoi(e));       // tuning knobs
-  if (const char* e = getenv("MSM_TARGET_WAVES")) target = (uint64_t)ctx->n_cu * 4 * 64 * std::max(1, atoi(e));
+  MSM_KNOB(max_steps, "MSM_MAX_STEPS", 1);
+  {
+    long long tw = 0;
+    MSM_KNOB(tw, "MSM_TARGET_WAVES", 1);
+    if (tw) target = (uint64_t)ctx->n_cu * 4 * 64 * (uint64_t)tw;
+  }
   uint64_t steps = (n_out + target - 1) / target;
   steps = std::max<uint64_t>(1, std::min<uint64_t>(steps, max_steps));
   uint64_t threads = (n_out + steps - 1) / steps;
@@ -291,7 +393,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   // pairs that occupy a lane for nothing) for twice the k_bucket_finish work, which is negligible there.
   uint64_t mean = std::max<uint64_t>(1, two_n / L);
   uint64_t per_bucket_left = mean >= 1024 ? 16 : 8;
-  if (const char* e = getenv("MSM_PBL")) per_bucket_left = std::max(1, atoi(e));
+  MSM_KNOB(per_bucket_left, "MSM_PBL", 1);
   uint32_t logG = 1;
   while (logG < 10 && (1ull << (logG + 1)) * per_bucket_left <= mean) logG++;
 
@@ -302,21 +404,20 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   ctx->ensure(w.info, 64 * 4);
 
   // sort path: LDS-privatised histogram/ranking.  One level when a window's counters fit the LDS (c <= 16), two
-  // levels (coarse bins of 2^15 buckets, then the same LDS sort per bin) up to c = 24; global atomics otherwise.
+  // levels (coarse bins of 2^15 buckets, then the same LDS sort per bin) up to c = 24, the largest window make_plan accepts.
   const bool one_level = (size_t)L * 4 <= 128 * 1024;
-  const bool two_level = !one_level && pl.c <= 24;
-  const bool lds_sort = one_level || two_level;
+  const bool two_level = !one_level;
   const uint32_t shift = two_level ? (uint32_t)(pl.c - 1 - 15) : 0;   // low bits kept for the second level
   const uint32_t Hn = 1u << shift;                                    // coarse bins per window
   const uint32_t L2 = two_level ? 32768u : L;                         // buckets per (virtual) window
   const uint32_t V = (uint32_t)kc * Hn;                               // virtual windows
   uint32_t sortB = 1;
   uint64_t chunk = two_n;
-  if (lds_sort) {
+  {
     // big inputs: finer slices also keep the round-1 gathers of neighbouring lanes inside one Infinity-Cache-sized
     // range of point rows (measured: 193 -> 183 ms at 2^26); small inputs: fewer, larger blocks (less fixed cost)
     uint64_t mult = two_n >= (1ull << 27) ? 8 : two_n >= (1ull << 24) ? 4 : 2;   // measured 2^21 .. 2^26
-    if (const char* e = getenv("MSM_SORTB_MULT")) mult = std::max(1, atoi(e));
+    MSM_KNOB(mult, "MSM_SORTB_MULT", 1);
     uint64_t want = std::max<uint64_t>(1, (mult * ctx->n_cu + kc - 1) / kc);
     uint64_t maxb = std::max<uint64_t>(1, two_n / 8192);
     sortB = (uint32_t)std::min<uint64_t>(want, maxb);
@@ -327,16 +428,14 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   uint32_t n_active2 = 0;
 
   HIPCHK(hipEventRecord(w.ev[0], s));
-  if (!lds_sort) HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));
   {
     uint32_t grid = (uint32_t)((n + 255) / 256);
-    uint32_t* cnt = lds_sort ? (uint32_t*)nullptr : (uint32_t*)w.counts.p;
     if (te)
-      hipLaunchKernelGGL(te::k_te_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, cnt, d_scalars, (uint32_t)n, pl.c,
-                         pl.K, k_lo, kc);
+      hipLaunchKernelGGL(te::k_te_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K,
+                         k_lo, kc, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p);
     else
-      W_LAUNCH(ctx, k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, cnt, d_scalars, (uint32_t)n, pl.c, pl.K,
-                         k_lo, kc, pl.no_glv ? 0 : 1);
+      W_LAUNCH(ctx, k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K, k_lo, kc,
+                         pl.no_glv ? 0 : 1, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p);
   }
   HIPCHK(hipEventRecord(w.ev[1], s));
   if (one_level) {
@@ -344,7 +443,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
                        (const uint32_t*)w.dig.p, two_n, chunk, L, 0u, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.block_hist.p,
                        (uint32_t*)w.counts.p, sortB, L, (uint32_t)kc, (const uint32_t*)nullptr);
-  } else if (two_level) {
+  } else {
     // level 1: coarse histogram -> partition offsets (host scan of V counters) -> partitioned (digit, entry) arrays
     ctx->ensure(w.part, (size_t)(2 * V + 2) * 4);
     uint32_t* d_cnt = (uint32_t*)w.part.p;            // V coarse counts
@@ -397,7 +496,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   int RT = 0;
   uint64_t total_slots = 0;
   uint32_t max_bucket = 0;
-  if (lds_sort) {
+  {
     // largest bucket -> number of tail rounds (first of two small read-backs), then the multi-block scan
     HIPCHK(hipMemsetAsync(w.info.p, 0, 64 * 4, s));
     hipLaunchKernelGGL(k_bucket_max, dim3((uint32_t)std::min<uint64_t>(1024, (nb + 255) / 256)), dim3(256), 0, s,
@@ -420,14 +519,6 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     HIPCHK(hipMemcpyAsync(w.h_info, w.info.p, 64 * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     total_slots = w.h_info[0];
-  } else {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, (const uint32_t*)w.counts.p, (uint32_t)nb, logG,
-                       (uint32_t*)w.cursor.p, (uint32_t*)w.tail_off.p, (uint32_t*)w.info.p);
-    HIPCHK(hipMemcpyAsync(w.h_info, w.info.p, 64 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    total_slots = w.h_info[0];
-    max_bucket = w.h_info[1];
-    RT = (int)w.h_info[2];
   }
   st.max_bucket = std::max<uint64_t>(st.max_bucket, max_bucket);
 
@@ -438,24 +529,19 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.slots.p,
                        (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n,
                        chunk, L, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-  } else if (two_level) {
-    if (n_active2)
-      hipLaunchKernelGGL(k_scatter_lds, dim3(n_active2), dim3(SORT_THREADS), (size_t)L2 * 4, s, (uint32_t*)w.slots.p,
-                         (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist2.p, (const uint32_t*)w.dig2.p, (uint64_t)0,
-                         chunk2, L2, (const uint32_t*)w.part.p + V, (const uint32_t*)w.idx2.p, (const uint32_t*)w.blk_tab.p);
-  } else {
-    uint64_t grid = (n_entries + 255) / 256;
-    hipLaunchKernelGGL(k_scatter, dim3((uint32_t)grid), dim3(256), 0, s, (uint32_t*)w.slots.p, (uint32_t*)w.cursor.p,
-                       (const uint32_t*)w.dig.p, two_n, n_entries, L);
+  } else if (n_active2) {
+    hipLaunchKernelGGL(k_scatter_lds, dim3(n_active2), dim3(SORT_THREADS), (size_t)L2 * 4, s, (uint32_t*)w.slots.p,
+                       (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist2.p, (const uint32_t*)w.dig2.p, (uint64_t)0,
+                       chunk2, L2, (const uint32_t*)w.part.p + V, (const uint32_t*)w.idx2.p, (const uint32_t*)w.blk_tab.p);
   }
   HIPCHK(hipEventRecord(w.ev[2], s));
 
   // accumulation tree
   // Weierstrass: tail rounds run only until no bucket holds more than FINISH_MAX elements; k_bucket_finish ends it
   uint32_t FINISH_MAX = 32;
-  if (const char* e = getenv("MSM_FINISH_MAX")) FINISH_MAX = (uint32_t)std::max(1, atoi(e));
+  MSM_KNOB(FINISH_MAX, "MSM_FINISH_MAX", 1);
   uint32_t tail_min_pairs = 1u << 21;
-  if (const char* e = getenv("MSM_TAIL_MIN")) tail_min_pairs = (uint32_t)std::max(1, atoi(e));
+  MSM_KNOB(tail_min_pairs, "MSM_TAIL_MIN", 1);
   const bool use_finish = true;
   int r_stop = RT;
   if (use_finish) {
@@ -555,7 +641,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     }
     off_fin = (const uint32_t*)w.tail_off.p + (uint64_t)r_stop * (nb + 1);
   }
-  st.rounds = round;
+  st.rounds += round;
   const uint32_t* bucket_proj = nullptr;
   if (use_finish && total_slots > 0) {
     ctx->ensure(w.bucket_proj, nb * (te ? 4 * te::TL : 3 * NL) * 4);
@@ -586,7 +672,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   // buckets per lane: enough lanes to fill the chip, but never more than 16 buckets deep (2 additions each)
   uint32_t TC = 2;
   while (TC < 16 && nb / TC > 65536) TC *= 2;
-  if (const char* e = getenv("MSM_TC")) TC = (uint32_t)std::max(1, atoi(e));
+  MSM_KNOB(TC, "MSM_TC", 1);
   TC = std::min<uint32_t>(TC, L);
   uint32_t nchunks = (L + TC - 1) / TC;
   // bit-sliced weighting (Weierstrass path, enough chunks to matter, TC a power of two)
@@ -777,7 +863,7 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   // measured on MI355X: two groups win 14 % at 2^23 / 2^24, 3 % at 2^22, nothing at 2^21 -- below that the fixed
   // per-group latencies (read-backs, bucket reduction depth) cost more than the overlap returns
   int want_groups = (nwin >= 2 && n >= (1ull << 22)) ? 2 : 1;
-  if (const char* e = getenv("MSM_GROUPS")) want_groups = std::max(1, atoi(e));
+  MSM_KNOB(want_groups, "MSM_GROUPS", 1);
   wpg = std::max(1, std::min(wpg, (nwin + want_groups - 1) / want_groups));
   struct Group {
     int ka, kb;
@@ -786,7 +872,7 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   std::vector<Group> groups;
   // A single window (the 8-GPU shard) has no second window group to hide its sort and tails under: split it by
   // points instead -- two half-size sub-MSMs of the same window on the two streams, their sums added on the host.
-  const bool split_points = nwin == 1 && want_groups == 1 && !ctx->is_te() && n >= (1ull << 24) && !getenv("MSM_GROUPS");
+  const bool split_points = nwin == 1 && want_groups == 1 && !ctx->is_te() && n >= (1ull << 24) && !MSM_KNOB_SET("MSM_GROUPS");
   if (split_points) {
     const uint64_t h = n / 2;
     groups.push_back({k_lo, k_hi, 0, h});
@@ -795,40 +881,46 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg), 0, n});
   }
   std::vector<uint32_t> split_part[2];
+  HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));   // staged scalars are in place before the group streams start
   std::atomic<int> next{0};
   GroupStats sts[msm_ctx::N_WS];
-  HipFail fails[msm_ctx::N_WS];
-  bool failed[msm_ctx::N_WS] = {false, false};
   auto worker = [&](int slot) {
-    try {
-      HIPCHK(hipSetDevice(ctx->device));
-      for (;;) {
-        int gi = next.fetch_add(1);
-        if (gi >= (int)groups.size()) break;
-        const int ka = groups[gi].ka, kb = groups[gi].kb;
-        std::vector<uint32_t> part((size_t)(kb - ka) * pw);
-        Plan pg = pl;
-        pg.lone = groups.size() == 1 && kb - ka == 1;
-        run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, part.data(), sts[slot]);
-        if (split_points) split_part[gi] = part;
-        else memcpy(&words[(size_t)(ka - k_lo) * pw], part.data(), part.size() * 4);
-      }
-    } catch (const HipFail& f) {
-      fails[slot] = f;
-      failed[slot] = true;
+    HIPCHK(hipSetDevice(ctx->device));
+    for (;;) {
+      int gi = next.fetch_add(1);
+      if (gi >= (int)groups.size()) break;
+      const int ka = groups[gi].ka, kb = groups[gi].kb;
+      std::vector<uint32_t> part((size_t)(kb - ka) * pw);
+      Plan pg = pl;
+      pg.lone = groups.size() == 1 && kb - ka == 1;
+      run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, part.data(), sts[slot]);
+      if (split_points) split_part[gi] = part;
+      else memcpy(&words[(size_t)(ka - k_lo) * pw], part.data(), part.size() * 4);
     }
   };
   const int nthreads = (opts && opts->serial) ? 1 : std::min<int>(msm_ctx::N_WS, (int)groups.size());
-  if (nthreads <= 1) {
-    worker(0);
-  } else {
-    std::thread t1(worker, 1);
-    worker(0);
-    t1.join();
+  {
+    // Whatever either worker throws (HIP failure, bad_alloc, ...) is re-raised here only after BOTH have stopped and both
+    // group streams are idle: no queued kernel of a failed call may still run when the context is used again.
+    std::exception_ptr err;
+    if (nthreads > 1) ctx->helper->run([&] { worker(1); });
+    try { worker(0); } catch (...) { err = std::current_exception(); }
+    if (nthreads > 1) {
+      try { ctx->helper->wait(); } catch (...) { if (!err) err = std::current_exception(); }
+    }
+    if (err) {
+      next.store((int)groups.size());
+      for (auto& w : ctx->ws) (void)hipStreamSynchronize(w.stream);
+      std::rethrow_exception(err);
+    }
   }
-  for (int i = 0; i < msm_ctx::N_WS; i++)
-    if (failed[i]) throw fails[i];
+  {
+    // scalars >= q seen by k_digits: refused under msm_opts.strict (otherwise they were reduced mod q)
+    HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->errflag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (pl.strict && (ctx->h_info[0] & 4u)) throw MsmFail{MSM_ERR_SCALAR, "a scalar is >= the group order q (msm_opts.strict)"};
+  }
   if (split_points) {
     const msm_host::Proj6 sum = ctx->hc.add(partial_to_host(ctx, split_part[0].data()), partial_to_host(ctx, split_part[1].data()));
     host_to_partial(ctx, sum, words.data());
@@ -836,7 +928,7 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   for (int i = 0; i < msm_ctx::N_WS; i++) {
     st.n_pairs += sts[i].n_pairs;
     st.max_bucket = std::max(st.max_bucket, sts[i].max_bucket);
-    st.rounds = std::max(st.rounds, sts[i].rounds);
+    st.rounds += sts[i].rounds;   // tree rounds (k_batch_add launches) of ALL window groups, like n_pairs and ms_acc
     st.ms_digits += sts[i].ms_digits; st.ms_sort += sts[i].ms_sort; st.ms_acc += sts[i].ms_acc;
     st.ms_red += sts[i].ms_red; st.ms_r1 += sts[i].ms_r1;
   }
@@ -862,6 +954,87 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   return MSM_OK;
 }
 
+
+// Multi-device context: the window range [k_lo, k_hi) is cut into contiguous shards, one per device (windows are
+// independent until the Horner step, src/msm-batched-affine.ts:312-333); device d runs window_sums_impl on its own
+// context from its own host thread, the partition sums (36 words per window) come back to the caller's thread.
+// Scalars: a host buffer is uploaded by every device itself; a device buffer (it lives on devices[0]) is copied
+// peer-to-peer into the other devices' staging buffers first.
+int multi_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, int k_lo, int k_hi,
+                      const Plan& pl, std::vector<uint32_t>& words, msm_result* stats) {
+  const int ndev = 1 + (int)ctx->children.size();
+  const int nwin = k_hi - k_lo, pw = ctx->is_te() ? 32 : 36;
+  words.assign((size_t)nwin * pw, 0);
+  std::vector<int> lo(ndev), hi(ndev);
+  for (int d = 0, k = k_lo; d < ndev; d++) {
+    const int cnt = nwin / ndev + (d < nwin % ndev ? 1 : 0);
+    lo[d] = k;
+    hi[d] = k + cnt;
+    k += cnt;
+  }
+  std::vector<std::vector<uint32_t>> part(ndev);
+  std::vector<msm_result> st(ndev);
+  for (auto& r : st) memset(&r, 0, sizeof r);
+  auto shard = [&](int d) {
+    if (hi[d] <= lo[d]) return;
+    msm_ctx* c = d == 0 ? ctx : ctx->children[d - 1];
+    HIPCHK(hipSetDevice(c->device));
+    const void* sc = scalars;
+    if (on_device && d > 0) {
+      c->ensure(c->scal, n * 32);
+      HIPCHK(hipMemcpyPeerAsync(c->scal.p, c->device, scalars, ctx->device, n * 32, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      sc = c->scal.p;
+    }
+    window_sums_impl(c, sc, n, on_device, opts, lo[d], hi[d], pl, part[d], &st[d]);
+  };
+  std::exception_ptr err;
+  for (int d = 1; d < ndev; d++) ctx->fan[d - 1]->run([&, d] { shard(d); });
+  try { shard(0); } catch (...) { err = std::current_exception(); }
+  for (int d = 1; d < ndev; d++) {
+    try { ctx->fan[d - 1]->wait(); } catch (...) { if (!err) err = std::current_exception(); }
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (err) std::rethrow_exception(err);
+  for (int d = 0; d < ndev; d++)
+    if (hi[d] > lo[d]) memcpy(&words[(size_t)(lo[d] - k_lo) * pw], part[d].data(), part[d].size() * 4);
+  if (stats) {
+    for (int d = 0; d < ndev; d++) {
+      stats->n_pairs += st[d].n_pairs;
+      stats->rounds += st[d].rounds;
+      stats->max_bucket = std::max(stats->max_bucket, st[d].max_bucket);
+      for (int j = 0; j < MSM_N_PHASES; j++) stats->phase_ms[j] = std::max(stats->phase_ms[j], st[d].phase_ms[j]);
+    }
+    stats->c = pl.c;
+    stats->K = pl.K;
+  }
+  return MSM_OK;
+}
+
+// the one entry the ABI functions use: single- or multi-device
+int any_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, int k_lo, int k_hi,
+                    const Plan& pl, std::vector<uint32_t>& words, msm_result* stats) {
+  if (ctx->children.empty()) return window_sums_impl(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
+  return multi_window_sums(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
+}
+
+// runs f(child) for every child of a multi-device context on the fan-out threads, and f(ctx) on the calling thread;
+// returns the first error code
+template <class F>
+int on_all_devices(msm_ctx* ctx, F f) {
+  const int nch = (int)ctx->children.size();
+  std::vector<int> rc(nch + 1, MSM_OK);
+  for (int i = 0; i < nch; i++) ctx->fan[i]->run([&, i] { rc[i + 1] = f(ctx->children[i]); });
+  rc[0] = f(ctx);
+  for (int i = 0; i < nch; i++) ctx->fan[i]->wait();
+  for (int i = 0; i <= nch; i++)
+    if (rc[i] != MSM_OK) {
+      if (i > 0) ctx->err = ctx->children[i - 1]->err;
+      return rc[i];
+    }
+  return MSM_OK;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -878,10 +1051,12 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     return MSM_ERR_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MSM_ERR_NO_DEVICE;
-  msm_ctx* ctx = new msm_ctx();
+  msm_ctx* ctx = new (std::nothrow) msm_ctx();
+  if (!ctx) return MSM_ERR_INTERNAL;
   ctx->curve = curve;
   ctx->device = device;
   try {
+    ctx->helper.reset(new HelperThread());
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -904,8 +1079,11 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     HIPCHK(hipFuncSetAttribute((const void*)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   } catch (const HipFail& f) {
     fprintf(stderr, "msm_ctx_create: HIP error %s at line %d\n", hipGetErrorString(f.e), f.line);
-    delete ctx;
+    msm_ctx_destroy(ctx);
     return MSM_ERR_HIP;
+  } catch (...) {
+    msm_ctx_destroy(ctx);
+    return MSM_ERR_INTERNAL;
   }
   ctx->hc.F.init(curve == MSM_CURVE_ED_ON_BLS12_377 ? Fp377::PW : curve_info(curve).pw);   // (the Edwards context uses hte)
   ctx->k_dev_to_host = ctx->hc.F.pow2(378);
@@ -921,7 +1099,14 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
 
 void msm_ctx_destroy(msm_ctx* ctx) {
   if (!ctx) return;
+  ctx->fan.clear();
+  for (msm_ctx* c : ctx->children) msm_ctx_destroy(c);
+  ctx->children.clear();
   (void)hipSetDevice(ctx->device);
+  for (size_t i = 0; i < ctx->sets.size(); i++)
+    if ((int)i != ctx->cur_set) ctx->release(ctx->sets[i].rows);
+  for (void* p : ctx->allocs) (void)hipFree(p);
+  ctx->allocs.clear();
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->errflag, &ctx->misc}) ctx->release(*b);
   for (auto& w : ctx->ws) {
@@ -929,18 +1114,18 @@ void msm_ctx_destroy(msm_ctx* ctx) {
     for (DevBuf* b : w.all) ctx->release(*b);
     if (w.h_info) (void)hipHostFree(w.h_info);
     if (w.h_part) (void)hipHostFree(w.h_part);
-    for (auto& e : w.ev) (void)hipEventDestroy(e);
+    for (auto& e : w.ev) if (e) (void)hipEventDestroy(e);
     if (w.stream) (void)hipStreamDestroy(w.stream);
   }
   if (ctx->h_info) (void)hipHostFree(ctx->h_info);
-  for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+  for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
 const char* msm_last_error(const msm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, int check_curve) {
+static int set_points_one(msm_ctx* ctx, const void* points, uint64_t n, int on_device, int check_curve) {
   if (!ctx || (!points && n)) return fail(ctx, MSM_ERR_ARG, "msm_set_points: null argument");
   if (n >= (1ull << 30)) return fail(ctx, MSM_ERR_ARG, "msm_set_points: n must be < 2^30");
   const bool te = ctx->is_te();
@@ -973,14 +1158,30 @@ int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, 
     if (ctx->h_info[0] & 1) return fail(ctx, MSM_ERR_POINT, "msm_set_points: coordinate >= p");
     if (ctx->h_info[0] & 2) return fail(ctx, MSM_ERR_POINT, "msm_set_points: point not on curve");
     ctx->n_points = n;
-  } catch (const HipFail& f) {
-    return fail_hip(ctx, f);
-  }
+  } MSM_CATCH_ALL(ctx)
   return MSM_OK;
 }
 
+int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, int check_curve) {
+  if (!ctx || ctx->children.empty()) return set_points_one(ctx, points, n, on_device, check_curve);
+  // multi-device context: every device keeps the whole point set (the windows are sharded, not the points)
+  try {
+    std::vector<uint8_t> host;
+    const void* src = points;
+    if (on_device && n) {   // the buffer lives on devices[0]: the other devices take it through the host
+      host.resize((size_t)n * (ctx->is_te() ? 64 : 96));
+      HIPCHK(hipSetDevice(ctx->device));
+      HIPCHK(hipMemcpy(host.data(), points, host.size(), hipMemcpyDeviceToHost));
+      src = host.data();
+    }
+    return on_all_devices(ctx, [&](msm_ctx* c) {
+      return (c == ctx) ? set_points_one(c, points, n, on_device, check_curve) : set_points_one(c, src, n, 0, check_curve);
+    });
+  } MSM_CATCH_ALL(ctx)
+}
+
 int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_out, int32_t* K_out) {
-  Plan pl;
+  Plan pl;   // plain arithmetic: nothing here can throw
   int rc = make_plan(ctx, n, opts, pl);
   if (rc) return rc;
   if (c_out) *c_out = pl.c;
@@ -1004,7 +1205,7 @@ int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device
     std::vector<uint32_t> words;
     if (ctx->is_te()) {
       // extended point (X : Y : Z : T) sent as X || Y || Z; the receiver rebuilds T (msm_combine: T Z = X Y)
-      if (n) window_sums_impl(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
+      if (n) any_window_sums(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
       const auto& C = ctx->hte;
       msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}}, t;
       for (int k = 0; k < k_hi - k_lo; k++) {
@@ -1019,7 +1220,7 @@ int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device
     if (n == 0) {
       words.assign((size_t)(k_hi - k_lo) * 36, 0);
     } else {
-      window_sums_impl(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
+      any_window_sums(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
     }
     // to 48-byte canonical integers (leave device Montgomery form on the host)
     for (int k = 0; k < k_hi - k_lo; k++) {
@@ -1035,9 +1236,7 @@ int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device
       ctx->hc.F.mul(t, P.Z, one); fe6_to_bytes(partials_out + (size_t)k * 144 + 96, t);
     }
     if (stats) { stats->c = pl.c; stats->K = pl.K; }
-  } catch (const HipFail& f) {
-    return fail_hip(ctx, f);
-  }
+  } MSM_CATCH_ALL(ctx)
   return MSM_OK;
 }
 
@@ -1097,19 +1296,24 @@ int te_combine_impl(const uint8_t* partials, int32_t K, int32_t c, msm_result* o
 int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
   // pure host arithmetic: ctx may be NULL (then BLS12-377 G1; msm_combine_curve names the curve without a context)
   if (!partials || !out || K <= 0 || c <= 0) return fail(ctx, MSM_ERR_ARG, "msm_combine: bad argument");
-  if (ctx && ctx->is_te()) {
-    int rc = te_combine_impl(partials, K, c, out);
-    return rc ? fail(ctx, rc, "msm_combine: coordinate >= p") : MSM_OK;
-  }
-  return combine_impl(ctx, ctx ? ctx->hc : *static_host_curve(MSM_CURVE_BLS12_377_G1), partials, K, c, out);
+  try {
+    if (ctx && ctx->is_te()) {
+      int rc = te_combine_impl(partials, K, c, out);
+      return rc ? fail(ctx, rc, "msm_combine: coordinate >= p") : MSM_OK;
+    }
+    return combine_impl(ctx, ctx ? ctx->hc : *static_host_curve(MSM_CURVE_BLS12_377_G1), partials, K, c, out);
+  } MSM_CATCH_ALL(ctx)
 }
 
 int msm_combine_curve(int curve, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
   if (!partials || !out || K <= 0 || c <= 0) return MSM_ERR_ARG;
-  if (curve == MSM_CURVE_ED_ON_BLS12_377) return te_combine_impl(partials, K, c, out);
-  const msm_host::Curve6* C = static_host_curve(curve);
-  if (!C) return MSM_ERR_ARG;
-  return combine_impl(nullptr, *C, partials, K, c, out);
+  msm_ctx* const no_ctx = nullptr;
+  try {
+    if (curve == MSM_CURVE_ED_ON_BLS12_377) return te_combine_impl(partials, K, c, out);
+    const msm_host::Curve6* C = static_host_curve(curve);
+    if (!C) return MSM_ERR_ARG;
+    return combine_impl(nullptr, *C, partials, K, c, out);
+  } MSM_CATCH_ALL(no_ctx)
 }
 
 namespace {
@@ -1154,7 +1358,7 @@ int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const 
   try {
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<uint32_t> words;
-    window_sums_impl(ctx, scalars, n, on_device, opts, 0, pl.K, pl, words, out);
+    any_window_sums(ctx, scalars, n, on_device, opts, 0, pl.K, pl, words, out);
     HIPCHK(hipEventRecord(ctx->ev[10], ctx->stream));
     if (ctx->is_te()) {
       te_horner_to_affine(ctx, words, pl.K, pl.c, out);
@@ -1169,9 +1373,7 @@ int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const 
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[10], ctx->ev[11]));
     out->phase_ms[MSM_T_FINAL] = ms;
     out->phase_ms[MSM_T_TOTAL] += ms;
-  } catch (const HipFail& f) {
-    return fail_hip(ctx, f);
-  }
+  } MSM_CATCH_ALL(ctx)
   return MSM_OK;
 }
 
@@ -1194,9 +1396,7 @@ int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy
           for (int q = 0; q < 4; q++)
             for (int b = 0; b < 8; b++) out_xy[i * 64 + 32 * j + 8 * q + b] = (uint8_t)(t.v[q] >> (8 * b));
         }
-    } catch (const HipFail& f) {
-      return fail_hip(ctx, f);
-    }
+    } MSM_CATCH_ALL(ctx)
     return MSM_OK;
   }
   try {
@@ -1217,9 +1417,7 @@ int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy
         fe6_to_bytes(out_xy + i * 96 + 48 * j, t);
       }
     }
-  } catch (const HipFail& f) {
-    return fail_hip(ctx, f);
-  }
+  } MSM_CATCH_ALL(ctx)
   return MSM_OK;
 }
 
@@ -1241,9 +1439,7 @@ int msm_test_fp(msm_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_
     HIPCHK(hipMemcpyAsync(out, d + 2 * n * nb, n * nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
-  } catch (const HipFail& f) {
-    return fail_hip(ctx, f);
-  }
+  } MSM_CATCH_ALL(ctx)
   return MSM_OK;
 }
 
@@ -1265,9 +1461,7 @@ int msm_test_batch_inverse(msm_ctx* ctx, const uint8_t* xs, uint8_t* out, uint64
     HIPCHK(hipMemcpyAsync(out, d + n * nb, n * nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
-  } catch (const HipFail& f) {
-    return fail_hip(ctx, f);
-  }
+  } MSM_CATCH_ALL(ctx)
   return MSM_OK;
 }
 
@@ -1284,9 +1478,7 @@ int msm_test_glv(msm_ctx* ctx, const uint8_t* scalars, uint8_t* out, uint64_t n)
     HIPCHK(hipMemcpyAsync(out, d + n * 32, n * 40, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
-  } catch (const HipFail& f) {
-    return fail_hip(ctx, f);
-  }
+  } MSM_CATCH_ALL(ctx)
   return MSM_OK;
 }
 
@@ -1354,9 +1546,7 @@ int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t
         memcpy(out + e * 64 + 32, yb, 32);
       }
       for (DevBuf* b : {&rows, &wire, &slots, &outb}) ctx->release(*b);
-    } catch (const HipFail& f) {
-      return fail_hip(ctx, f);
-    }
+    } MSM_CATCH_ALL(ctx)
     return MSM_OK;
   }
   try {
@@ -1415,21 +1605,24 @@ int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t
       }
     }
     for (DevBuf* b : {&rows, &wire, &slots, &outb, &scr}) ctx->release(*b);
-  } catch (const HipFail& f) {
-    return fail_hip(ctx, f);
-  }
+  } MSM_CATCH_ALL(ctx)
   return MSM_OK;
 }
 
-int msm_generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
-  if (!ctx) return MSM_ERR_ARG;
+static int generate_points_one(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
   try {
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->is_te()) return msm_gen::generate_points_te(ctx, n, seed, a_out);
     return msm_gen::generate_points(ctx, n, seed, a_out);
-  } catch (const HipFail& f) {
-    return fail_hip(ctx, f);
-  }
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
+  if (!ctx) return MSM_ERR_ARG;
+  if (ctx->children.empty()) return generate_points_one(ctx, n, seed, a_out);
+  try {   // the generator is deterministic in (seed, index): every device builds the identical set
+    return on_all_devices(ctx, [&](msm_ctx* c) { return generate_points_one(c, n, seed, c == ctx ? a_out : nullptr); });
+  } MSM_CATCH_ALL(ctx)
 }
 
 int msm_generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void** dev_ptr_out, uint8_t* host_out) {
@@ -1437,9 +1630,123 @@ int msm_generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void** dev_ptr
   try {
     HIPCHK(hipSetDevice(ctx->device));
     return msm_gen::generate_scalars(ctx, n, seed, dev_ptr_out, host_out);
-  } catch (const HipFail& f) {
-    return fail_hip(ctx, f);
-  }
+  } MSM_CATCH_ALL(ctx)
 }
+
+// ---- point-set handles: several resident point sets per context, one of them current ------------------------
+
+static int pointset_select_one(msm_ctx* ctx, int32_t id) {
+  if (id < 0 || id >= (int)ctx->sets.size() || (id != 0 && !ctx->sets[id].live))
+    return fail(ctx, MSM_ERR_ARG, "msm_pointset_select: no point set %d", (int)id);
+  if (id == ctx->cur_set) return MSM_OK;
+  ctx->sets[ctx->cur_set].rows = ctx->rows;
+  ctx->sets[ctx->cur_set].n = ctx->n_points;
+  ctx->rows = ctx->sets[id].rows;
+  ctx->n_points = ctx->sets[id].n;
+  ctx->cur_set = id;
+  return MSM_OK;
+}
+
+int msm_pointset_create(msm_ctx* ctx, int32_t* id_out) {
+  if (!ctx || !id_out) return fail(ctx, MSM_ERR_ARG, "msm_pointset_create: null argument");
+  try {
+    return on_all_devices(ctx, [&](msm_ctx* c) {
+      int id = -1;
+      for (size_t i = 1; i < c->sets.size(); i++)
+        if (!c->sets[i].live) { id = (int)i; break; }
+      if (id < 0) { c->sets.emplace_back(); id = (int)c->sets.size() - 1; }   // children stay in lockstep: same ids
+      c->sets[id] = msm_ctx::PointSet();
+      c->sets[id].live = true;
+      if (c == ctx) *id_out = id;
+      return pointset_select_one(c, id);
+    });
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_pointset_select(msm_ctx* ctx, int32_t id) {
+  if (!ctx) return MSM_ERR_ARG;
+  try {
+    return on_all_devices(ctx, [&](msm_ctx* c) { return pointset_select_one(c, id); });
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_pointset_destroy(msm_ctx* ctx, int32_t id) {
+  if (!ctx) return MSM_ERR_ARG;
+  if (id <= 0 || id >= (int)ctx->sets.size() || !ctx->sets[id].live)
+    return fail(ctx, MSM_ERR_ARG, "msm_pointset_destroy: no such point set %d (the default set 0 stays)", (int)id);
+  try {
+    return on_all_devices(ctx, [&](msm_ctx* c) {
+      if (c->cur_set == id) pointset_select_one(c, 0);
+      (void)hipSetDevice(c->device);
+      c->release(c->sets[id].rows);
+      c->sets[id] = msm_ctx::PointSet();
+      return (int)MSM_OK;
+    });
+  } MSM_CATCH_ALL(ctx)
+}
+
+// ---- device buffers for scalar handles ------------------------------------------------------------------------
+
+int msm_device_alloc(msm_ctx* ctx, uint64_t bytes, void** dev_ptr_out) {
+  if (!ctx || !dev_ptr_out) return fail(ctx, MSM_ERR_ARG, "msm_device_alloc: null argument");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, std::max<uint64_t>(bytes, 32)));
+    ctx->allocs.push_back(p);
+    *dev_ptr_out = p;
+    return MSM_OK;
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_device_free(msm_ctx* ctx, void* dev_ptr) {
+  if (!ctx) return MSM_ERR_ARG;
+  auto it = std::find(ctx->allocs.begin(), ctx->allocs.end(), dev_ptr);
+  if (it == ctx->allocs.end()) return fail(ctx, MSM_ERR_ARG, "msm_device_free: not a buffer of this context");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->allocs.erase(it);
+    HIPCHK(hipFree(dev_ptr));
+    return MSM_OK;
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_device_upload(msm_ctx* ctx, void* dev_ptr, const void* host, uint64_t bytes) {
+  if (!ctx || !dev_ptr || (!host && bytes)) return fail(ctx, MSM_ERR_ARG, "msm_device_upload: null argument");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (bytes) HIPCHK(hipMemcpy(dev_ptr, host, bytes, hipMemcpyHostToDevice));
+    return MSM_OK;
+  } MSM_CATCH_ALL(ctx)
+}
+
+// ---- multi-device context ---------------------------------------------------------------------------------------
+
+int msm_ctx_create_multi(msm_ctx** out, int curve, const int32_t* devices, int32_t n_devices) {
+  if (!out || !devices || n_devices < 1) return MSM_ERR_ARG;
+  *out = nullptr;
+  msm_ctx* ctx = nullptr;
+  int rc = msm_ctx_create(&ctx, curve, devices[0]);
+  if (rc != MSM_OK) return rc;
+  try {
+    for (int i = 1; i < n_devices; i++) {
+      msm_ctx* c = nullptr;
+      rc = msm_ctx_create(&c, curve, devices[i]);
+      if (rc != MSM_OK) {
+        msm_ctx_destroy(ctx);
+        return rc;
+      }
+      ctx->children.push_back(c);
+      ctx->fan.emplace_back(new HelperThread());
+    }
+  } catch (...) {
+    msm_ctx_destroy(ctx);
+    return MSM_ERR_INTERNAL;
+  }
+  *out = ctx;
+  return MSM_OK;
+}
+
+int msm_ctx_device_count(const msm_ctx* ctx) { return ctx ? 1 + (int)ctx->children.size() : 0; }
 
 }  // extern "C"

@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) k_points_from_wire(uint32_t* rows, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_digits: scalars (N x 32 B LE) -> signed window digits of both GLV halves + bucket histogram
+// k_digits: scalars (N x 32 B LE) -> signed window digits of both GLV halves
 // ---------------------------------------------------------------------------------------------
 
 MSM_DEV bool words8_ge(const uint32_t (&a)[8], const uint32_t* q) {
@@ -183,8 +183,8 @@ MSM_DEV bool words8_ge(const uint32_t (&a)[8], const uint32_t* q) {
 
 // windows [k_lo, k_lo + k_cnt) of K_total are emitted (window groups / multi-GPU window shards)
 template <class CV>
-__global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts, const uint32_t* scalars, uint32_t n,
-                                                int c, int k_total, int k_lo, int k_cnt, int glv) {
+__global__ void __launch_bounds__(256) k_digits(uint32_t* dig, const uint32_t* scalars, uint32_t n, int c, int k_total,
+                                                int k_lo, int k_cnt, int glv, int strict, uint32_t* err) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -196,8 +196,12 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts,
   uint32_t q[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) q[j] = CV::G::Q[j];
-  // inputs are specified < q (src/curve-random.ts:151-194); larger values are reduced, not rejected
-  for (int it = 0; it < 16 && words8_ge(s, q); it++) bn_addsub<8, 8>(s, q, true);
+  // inputs are specified < q (src/curve-random.ts:151-194).  Larger values are reduced mod q -- the group element is the
+  // same -- unless the caller asked for strict checking (msm_opts.strict), in which case the call fails with MSM_ERR_SCALAR
+  if (words8_ge(s, q)) {
+    if (strict) atomicOr(err, 4u);
+    for (int it = 0; it < 16 && words8_ge(s, q); it++) bn_addsub<8, 8>(s, q, true);
+  }
 
   const uint32_t L = 1u << (c - 1);
   const uint64_t two_n = 2ull * n;
@@ -212,7 +216,6 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts,
       if (kk >= 0 && kk < k_cnt) {
         dig[(uint64_t)kk * two_n + 2ull * i] = l | (carry << 31);
         dig[(uint64_t)kk * two_n + 2ull * i + 1] = 0u;
-        if (counts && l) atomicAdd(&counts[(uint64_t)kk * L + (l - 1)], 1u);
       }
     }
     return;
@@ -229,7 +232,6 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, uint32_t* counts,
       if (kk >= 0 && kk < k_cnt) {
         uint32_t neg = carry ^ (h[hh].neg ? 1u : 0u);
         dig[(uint64_t)kk * two_n + 2ull * i + hh] = l | (neg << 31);
-        if (counts && l) atomicAdd(&counts[(uint64_t)kk * L + (l - 1)], 1u);  // only on the global-atomic sort path
       }
     }
   }

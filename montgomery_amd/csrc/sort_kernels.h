@@ -1,5 +1,5 @@
-// Curve-independent kernels of the MSM pipeline: bucket-size scans, the LDS-privatised counting sort (one- and
-// two-level) with its global-atomic fallback, and the operand descriptors of the tail rounds.
+// Curve-independent kernels of the MSM pipeline: bucket-size scans, the LDS-privatised counting sort (one level for
+// c <= 16, two levels up to the largest accepted window c = 24) and the operand descriptors of the tail rounds.
 // (reference phases: integrateBucketCounts src/msm-batched-affine.ts:423-447, sortPoints :456-502)
 // Included by msm_api.hip only; the curve-templated kernels live in msm_kernels.h.
 #pragma once
@@ -8,9 +8,9 @@
 namespace msm {
 
 // ---------------------------------------------------------------------------------------------
-// k_scan (single workgroup): bucket sizes -> padded slot offsets, cursor, tail-round offsets
-//   info[0] = total slots, info[1] = max bucket size, info[2] = RT (tail rounds),
-//   info[3 + r] = number of elements entering tail round r (r = 0..RT)
+// scans: bucket sizes -> padded slot offsets, cursor, tail-round offsets (k_pscan_* below)
+//   info[0] = total slots, info[1] = max bucket size,
+//   info[3 + r] = number of elements entering tail round r
 //   tail_off[r] has nb + 1 entries: offsets of ceil(ceil(n/G) / 2^r)
 // ---------------------------------------------------------------------------------------------
 
@@ -38,73 +38,6 @@ MSM_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wave, uint32_t& total
   }
   total = tot;
   return wave_base + x - v;
-}
-
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan(const uint32_t* counts, uint32_t nb, uint32_t logG,
-                                                       uint32_t* cursor, uint32_t* tail_off, uint32_t* info) {
-  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
-  __shared__ uint32_t lds_max;
-  const uint32_t G1 = (1u << logG) - 1;
-  if (threadIdx.x == 0) lds_max = 0;
-  __syncthreads();
-  // pass A: max bucket size
-  uint32_t mx = 0;
-  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) mx = max(mx, counts[b]);
-  atomicMax(&lds_max, mx);
-  __syncthreads();
-  mx = lds_max;
-  uint32_t capmax = (mx + G1) >> logG;
-  int RT = 0;
-  while ((1u << RT) < capmax) RT++;
-  // pass B: slot offsets (cursor) with padding to multiples of G
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < nb; base += SCAN_THREADS * SCAN_ITEMS) {
-    uint32_t v[SCAN_ITEMS], sum = 0;
-    uint32_t b0 = base + threadIdx.x * SCAN_ITEMS;
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) {
-      uint32_t b = b0 + j;
-      v[j] = b < nb ? ((counts[b] + G1) >> logG) << logG : 0u;
-      sum += v[j];
-    }
-    uint32_t tot;
-    uint32_t ex = block_excl_scan(sum, lds_wave, tot) + carry;
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) {
-      uint32_t b = b0 + j;
-      if (b < nb) cursor[b] = ex;
-      ex += v[j];
-    }
-    carry += tot;
-  }
-  if (threadIdx.x == 0) { info[0] = carry; info[1] = mx; info[2] = (uint32_t)RT; }
-  // pass C: tail-round offsets
-  for (int r = 0; r <= RT; r++) {
-    uint32_t* off = tail_off + (uint64_t)r * (nb + 1);
-    const uint32_t rnd = (1u << r) - 1;
-    carry = 0;
-    for (uint32_t base = 0; base < nb; base += SCAN_THREADS * SCAN_ITEMS) {
-      uint32_t v[SCAN_ITEMS], sum = 0;
-      uint32_t b0 = base + threadIdx.x * SCAN_ITEMS;
-#pragma unroll
-      for (int j = 0; j < SCAN_ITEMS; j++) {
-        uint32_t b = b0 + j;
-        uint32_t cg = b < nb ? (counts[b] + G1) >> logG : 0u;
-        v[j] = (cg + rnd) >> r;
-        sum += v[j];
-      }
-      uint32_t tot;
-      uint32_t ex = block_excl_scan(sum, lds_wave, tot) + carry;
-#pragma unroll
-      for (int j = 0; j < SCAN_ITEMS; j++) {
-        uint32_t b = b0 + j;
-        if (b < nb) off[b] = ex;
-        ex += v[j];
-      }
-      carry += tot;
-    }
-    if (threadIdx.x == 0) { off[nb] = carry; info[3 + r] = carry; }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -216,24 +149,6 @@ __global__ void __launch_bounds__(256) k_tail_desc(uint32_t* desc, const uint32_
   uint32_t j = e - off_out[lo];
   uint32_t ia = off_in[lo] + 2 * j;
   desc[e] = (ia << 1) | ((ia + 1) < off_in[lo + 1] ? 1u : 0u);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_scatter: digits -> bucket-ordered payload slots (order inside a bucket is arbitrary; the
-// bucket sum does not depend on it)
-// ---------------------------------------------------------------------------------------------
-
-__global__ void __launch_bounds__(256) k_scatter(uint32_t* slots, uint32_t* cursor, const uint32_t* dig, uint64_t two_n,
-                                                 uint64_t total, uint32_t L) {
-  uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= total) return;
-  uint32_t d = dig[id];
-  uint32_t l = d & 0x7FFFFFFFu;
-  if (l == 0) return;
-  uint64_t kk = id / two_n;
-  uint32_t j = (uint32_t)(id - kk * two_n);
-  uint32_t pos = atomicAdd(&cursor[kk * L + (l - 1)], 1u);
-  slots[pos] = (j << 1) | (d >> 31);
 }
 
 // ---------------------------------------------------------------------------------------------

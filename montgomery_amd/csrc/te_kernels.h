@@ -216,8 +216,8 @@ __global__ void __launch_bounds__(256) k_te_points_from_wire(uint32_t* rows, con
 // k_te_digits: signed window digits of full-width scalars (no GLV), src/msm-basic.ts:72-91
 // ---------------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) k_te_digits(uint32_t* dig, uint32_t* counts, const uint32_t* scalars, uint32_t n, int c,
-                                                   int k_total, int k_lo, int k_cnt) {
+__global__ void __launch_bounds__(256) k_te_digits(uint32_t* dig, const uint32_t* scalars, uint32_t n, int c, int k_total, int k_lo,
+                                                   int k_cnt, int strict, uint32_t* err) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -229,7 +229,10 @@ __global__ void __launch_bounds__(256) k_te_digits(uint32_t* dig, uint32_t* coun
   uint32_t q[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) q[j] = FRED_Q[j];
-  for (int it = 0; it < 64 && words8_ge(s, q); it++) bn_addsub<8, 8>(s, q, true);   // scalars >= q are reduced (2^256 < 56 q)
+  if (words8_ge(s, q)) {   // scalars >= q are reduced (2^256 < 56 q), or refused under msm_opts.strict
+    if (strict) atomicOr(err, 4u);
+    for (int it = 0; it < 64 && words8_ge(s, q); it++) bn_addsub<8, 8>(s, q, true);
+  }
   const uint32_t L = 1u << (c - 1);
   uint32_t carry = 0;
   for (int k = 0; k < k_total; k++) {
@@ -238,7 +241,6 @@ __global__ void __launch_bounds__(256) k_te_digits(uint32_t* dig, uint32_t* coun
     int kk = k - k_lo;
     if (kk >= 0 && kk < k_cnt) {
       dig[(uint64_t)kk * n + i] = l | (carry << 31);
-      if (counts && l) atomicAdd(&counts[(uint64_t)kk * L + (l - 1)], 1u);
     }
   }
 }

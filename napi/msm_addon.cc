@@ -6,11 +6,13 @@
 // `compute_msm` (scripts/zprize23/submission-bls377.ts:20-65) on top of the functions exported here.
 // Plain N-API (C), version 8 as shipped with the image's node 12; no node-addon-api / node-gyp.
 //
-// Exports: createContext(curve, device) -> external handle, destroyContext(h), setPoints(h, Buffer, check),
+// Exports: createContext(curve, device | [devices]) -> external handle, destroyContext(h), setPoints(h, Buffer, pointBytes, check),
+//          pointsetCreate(h) -> id, pointsetSelect(h, id), pointsetDestroy(h, id),
 //          msm(h, Buffer scalars, c) -> {x: Buffer, y: Buffer, isZero, c, K, phaseMs: Float64Array(8)},
 //          plan(h, n, c) -> {c, K}, generatePoints(h, n, seed) -> n, generateScalars(h, n, seed) -> Buffer
 #include <node_api.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "msm_hip.h"
 
@@ -29,13 +31,36 @@ static napi_value throw_msm(napi_env env, msm_ctx* ctx, int rc, const char* what
   return NULL;
 }
 
-static msm_ctx* get_ctx(napi_env env, napi_value v) {
+// What a JS context handle points at: the sizes of the curve's wire format are derived here, never taken from JS
+// (a wrong size from the caller would make the library read past the Buffer or this shim read past res.x).
+typedef struct {
+  msm_ctx* ctx;      /* NULL after destroyContext: a second destroy or any later call throws instead of double-freeing */
+  int32_t curve;
+  size_t coord_bytes, point_bytes;
+} js_ctx;
+
+static js_ctx* get_handle(napi_env env, napi_value v) {
   void* p = NULL;
   if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
     napi_throw_type_error(env, NULL, "expected a context handle from createContext()");
     return NULL;
   }
-  return (msm_ctx*)p;
+  js_ctx* h = (js_ctx*)p;
+  if (!h->ctx) {
+    napi_throw_error(env, NULL, "this context has been destroyed");
+    return NULL;
+  }
+  return h;
+}
+static msm_ctx* get_ctx(napi_env env, napi_value v) {
+  js_ctx* h = get_handle(env, v);
+  return h ? h->ctx : NULL;
+}
+static void finalize_handle(napi_env env, void* data, void* hint) {
+  (void)env; (void)hint;
+  js_ctx* h = (js_ctx*)data;
+  if (h->ctx) msm_ctx_destroy(h->ctx);
+  free(h);
 }
 
 static napi_value CreateContext(napi_env env, napi_callback_info info) {
@@ -44,12 +69,41 @@ static napi_value CreateContext(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   int32_t curve = 0, device = 0;
   if (argc > 0) napi_get_value_int32(env, argv[0], &curve);
-  if (argc > 1) napi_get_value_int32(env, argv[1], &device);
   msm_ctx* ctx = NULL;
-  int rc = msm_ctx_create(&ctx, curve, device);
+  int rc;
+  bool is_array = false;
+  if (argc > 1) napi_is_array(env, argv[1], &is_array);
+  if (is_array) {   // a device list: one context over several GPUs of the node (msm_ctx_create_multi)
+    uint32_t nd = 0;
+    NAPI_OK(napi_get_array_length(env, argv[1], &nd));
+    if (nd == 0 || nd > 64) {
+      napi_throw_range_error(env, NULL, "device list must hold 1..64 device indices");
+      return NULL;
+    }
+    int32_t devs[64];
+    for (uint32_t i = 0; i < nd; i++) {
+      napi_value e;
+      NAPI_OK(napi_get_element(env, argv[1], i, &e));
+      NAPI_OK(napi_get_value_int32(env, e, &devs[i]));
+    }
+    rc = msm_ctx_create_multi(&ctx, curve, devs, (int32_t)nd);
+  } else {
+    if (argc > 1) napi_get_value_int32(env, argv[1], &device);
+    rc = msm_ctx_create(&ctx, curve, device);
+  }
   if (rc != MSM_OK) return throw_msm(env, NULL, rc, "createContext");
+  js_ctx* h = (js_ctx*)calloc(1, sizeof(js_ctx));
+  if (!h) {
+    msm_ctx_destroy(ctx);
+    napi_throw_error(env, NULL, "out of memory");
+    return NULL;
+  }
+  h->ctx = ctx;
+  h->curve = curve;
+  h->coord_bytes = curve == MSM_CURVE_ED_ON_BLS12_377 ? 32 : 48;
+  h->point_bytes = 2 * h->coord_bytes;
   napi_value out;
-  NAPI_OK(napi_create_external(env, ctx, NULL, NULL, &out));
+  NAPI_OK(napi_create_external(env, h, finalize_handle, NULL, &out));
   return out;
 }
 
@@ -57,8 +111,11 @@ static napi_value DestroyContext(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  msm_ctx* ctx = get_ctx(env, argv[0]);
-  if (ctx) msm_ctx_destroy(ctx);
+  js_ctx* h = get_handle(env, argv[0]);   // throws on a handle that was destroyed before
+  if (h) {
+    msm_ctx_destroy(h->ctx);
+    h->ctx = NULL;
+  }
   return NULL;
 }
 
@@ -66,16 +123,17 @@ static napi_value SetPoints(napi_env env, napi_callback_info info) {  // pointsF
   size_t argc = 4;
   napi_value argv[4];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  msm_ctx* ctx = get_ctx(env, argv[0]);
-  if (!ctx) return NULL;
+  js_ctx* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  msm_ctx* ctx = h->ctx;
   void* data;
   size_t len;
   NAPI_OK(napi_get_buffer_info(env, argv[1], &data, &len));
-  int32_t point_bytes = 96, check = 0;
+  int32_t point_bytes = (int32_t)h->point_bytes, check = 0;
   if (argc > 2) napi_get_value_int32(env, argv[2], &point_bytes);
   if (argc > 3) napi_get_value_int32(env, argv[3], &check);
-  if (point_bytes <= 0 || len % (size_t)point_bytes) {
-    napi_throw_range_error(env, NULL, "point buffer length is not a multiple of the point size");
+  if ((size_t)point_bytes != h->point_bytes || len % h->point_bytes) {   // the C ABI reads n x point_bytes of this curve
+    napi_throw_range_error(env, NULL, "point buffer: expected a multiple of the curve's point size (96 bytes, Ed-on-BLS12-377: 64)");
     return NULL;
   }
   int rc = msm_set_points(ctx, data, len / point_bytes, 0, check);
@@ -89,8 +147,9 @@ static napi_value Msm(napi_env env, napi_callback_info info) {  // msm / msmUnsa
   size_t argc = 5;   // (ctx, scalars, c, coordBytes, noGlv)
   napi_value argv[5];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  msm_ctx* ctx = get_ctx(env, argv[0]);
-  if (!ctx) return NULL;
+  js_ctx* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  msm_ctx* ctx = h->ctx;
   void* data;
   size_t len;
   NAPI_OK(napi_get_buffer_info(env, argv[1], &data, &len));
@@ -100,9 +159,8 @@ static napi_value Msm(napi_env env, napi_callback_info info) {  // msm / msmUnsa
   }
   msm_opts opts;
   memset(&opts, 0, sizeof opts);
-  int32_t coord = 48;
+  int32_t coord = (int32_t)h->coord_bytes;   // of the context's curve; the fourth argument is accepted and ignored
   if (argc > 2) napi_get_value_int32(env, argv[2], &opts.c);
-  if (argc > 3) napi_get_value_int32(env, argv[3], &coord);
   if (argc > 4) napi_get_value_int32(env, argv[4], &opts.no_glv);   // msmProjective, src/parallel.ts:69-87
   msm_result res;
   int rc = msm_run(ctx, data, len / 32, 0, &opts, &res);
@@ -187,10 +245,40 @@ static napi_value GenerateScalars(napi_env env, napi_callback_info info) {
   return buf;
 }
 
+// point-set handles: pointsetCreate(h) -> id (becomes current), pointsetSelect(h, id), pointsetDestroy(h, id)
+static napi_value PointsetCreate(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  msm_ctx* ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  int32_t id = 0;
+  int rc = msm_pointset_create(ctx, &id);
+  if (rc != MSM_OK) return throw_msm(env, ctx, rc, "pointsetCreate");
+  napi_value out;
+  NAPI_OK(napi_create_int32(env, id, &out));
+  return out;
+}
+static napi_value PointsetOp(napi_env env, napi_callback_info info, int destroy) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  msm_ctx* ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  int32_t id = 0;
+  NAPI_OK(napi_get_value_int32(env, argv[1], &id));
+  int rc = destroy ? msm_pointset_destroy(ctx, id) : msm_pointset_select(ctx, id);
+  if (rc != MSM_OK) return throw_msm(env, ctx, rc, destroy ? "pointsetDestroy" : "pointsetSelect");
+  return NULL;
+}
+static napi_value PointsetSelect(napi_env env, napi_callback_info info) { return PointsetOp(env, info, 0); }
+static napi_value PointsetDestroy(napi_env env, napi_callback_info info) { return PointsetOp(env, info, 1); }
+
 NAPI_MODULE_INIT() {
   struct { const char* name; napi_callback fn; } fns[] = {
       {"createContext", CreateContext}, {"destroyContext", DestroyContext}, {"setPoints", SetPoints}, {"msm", Msm}, {"plan", Plan},
-      {"generatePoints", GeneratePoints}, {"generateScalars", GenerateScalars}};
+      {"generatePoints", GeneratePoints}, {"generateScalars", GenerateScalars},
+      {"pointsetCreate", PointsetCreate}, {"pointsetSelect", PointsetSelect}, {"pointsetDestroy", PointsetDestroy}};
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;
     if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;

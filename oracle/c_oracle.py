@@ -29,6 +29,8 @@ def load() -> C.CDLL:
         lib.oracle_fp_op.restype = None
         lib.oracle_window_size.argtypes = [C.c_int]
         lib.oracle_window_size.restype = C.c_int
+        lib.oracle_dot_u256.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        lib.oracle_dot_u256.restype = None
         _lib = lib
     return _lib
 
@@ -67,3 +69,15 @@ def fp_op(op: int, a: int, b: int = 0) -> int:
     bb = (C.c_uint8 * 48).from_buffer_copy(b.to_bytes(48, "little"))
     lib.oracle_fp_op(op, ab, bb, out)
     return int.from_bytes(bytes(out), "little")
+
+
+def dot_mod(a, s, n: int, q: int) -> int:
+    """sum_i a_i * s_i mod q over n pairs of 32-byte little-endian integers; `a`, `s`: bytes or ctypes arrays (not copied)."""
+    lib = load()
+
+    def ptr(x):
+        return x if isinstance(x, C.Array) else (C.c_uint8 * max(len(x), 1)).from_buffer_copy(x or b"\0")
+
+    out = (C.c_uint64 * 10)()
+    lib.oracle_dot_u256(ptr(a), ptr(s), n, out)
+    return sum(int(w) << (64 * i) for i, w in enumerate(out)) % q

@@ -16,8 +16,8 @@
  *   reduceBucketsColumnProjective           src/msm-batched-affine.ts:556-583
  *   final sum                               src/msm-batched-affine.ts:312-333
  *   projective add / double                 src/curve-projective.ts:51-160, :202-253
- * Windows are independent until the final sum, so the `omp parallel for` over k below is the analogue
- * of the reference's thread split by window in sortPoints (`range(K)`, :474).
+ * Threads: every phase of a window runs on all host cores, entries split across threads for slicing and sorting,
+ * buckets split across threads for the accumulation rounds and the reduction (the reference's SPMD layout).
  *
  * Build: see oracle/Makefile (gcc -O2 -fopenmp -shared).
  */
@@ -333,8 +333,15 @@ int oracle_msm_bls377(const uint8_t* points, const uint8_t* scalars, uint64_t n,
   aff* pts = (aff*)malloc(sizeof(aff) * n2);
   uint64_t* mags = (uint64_t*)malloc(16 * n2);
   if (!pts || !mags) return -1;
+  int nthreads = 1;
+#ifdef _OPENMP
+  nthreads = omp_get_max_threads();
+  /* small inputs: a parallel region over 128 threads costs more than the work it splits (K windows x 4 regions each) */
+  { uint64_t useful = n2 / 2048 + 1; if ((uint64_t)nthreads > useful) nthreads = (int)useful; }
+#endif
+  if (threads_used) *threads_used = nthreads;
   int bad = 0;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nthreads)
   for (int64_t i = 0; i < (int64_t)n; i++) {
     fe x, y;
     fe_from_bytes(&x, points + 96 * i);
@@ -365,74 +372,116 @@ int oracle_msm_bls377(const uint8_t* points, const uint8_t* scalars, uint64_t n,
   if (bad) { free(pts); free(mags); return -1; }
 
   proj* part = (proj*)malloc(sizeof(proj) * K);
-  int nthreads = 1;
-#ifdef _OPENMP
-  nthreads = omp_get_max_threads();
-  if (nthreads > K) nthreads = K;
-#endif
-  if (threads_used) *threads_used = nthreads;
   int oom = 0;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
-  for (int k = 0; k < K; k++) {
+  /* Windows one after the other, every phase of a window on ALL threads -- the reference's SPMD layout: entries split
+   * across threads for slicing / counting / sorting (:175-203, :456-502), buckets split across threads for the
+   * accumulation rounds and the reduction (`computeBucketsSplit`, :626-667, src/msm-common.ts:72-172). */
+  uint32_t* dig = (uint32_t*)malloc(4 * n2);
+  uint64_t* start = (uint64_t*)malloc((L + 2) * 8);
+  uint64_t* cursor = (uint64_t*)malloc((L + 2) * 8);
+  aff* sorted = (aff*)malloc(sizeof(aff) * (n2 ? n2 : 1));
+  if (!dig || !start || !cursor || !sorted) oom = 1;
+  for (int k = 0; k < K && !oom; k++) {
     /* slice + count (:175-203).  NOTE: digits need the carry of all lower windows. */
-    uint32_t* dig = (uint32_t*)malloc(4 * n2);
-    uint64_t* start = (uint64_t*)calloc(L + 2, 8);
-    if (!dig || !start) { oom = 1; free(dig); free(start); continue; }
-    for (uint64_t j = 0; j < n2; j++) {
+    memset(start, 0, (L + 2) * 8);
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t j = 0; j < (int64_t)n2; j++) {
       uint32_t carry = 0, l = 0;
       for (int kk = 0; kk <= k; kk++) {
         l = bits128(&mags[2 * j], kk * c, c) + carry;
         if (l > L) { l = (uint32_t)(2 * L - l); carry = 1; } else carry = 0;
       }
       dig[j] = l | (carry << 31);
-      if (l) start[l + 1]++;
+      if (l) __atomic_fetch_add(&start[l + 1], 1, __ATOMIC_RELAXED);
     }
     /* integrate (:423-447): start[l] = first slot of bucket l, start[L+1] = total */
     for (uint64_t l = 1; l <= L + 1; l++) start[l] += start[l - 1];
-    uint64_t total = start[L + 1];
-    /* scatter (:456-502): copy points (or their negation) into bucket order */
-    aff* sorted = (aff*)malloc(sizeof(aff) * (total ? total : 1));
-    uint64_t* cursor = (uint64_t*)malloc(8 * (L + 2));
-    if (!sorted || !cursor) { oom = 1; free(dig); free(start); free(sorted); free(cursor); continue; }
+    const uint64_t total = start[L + 1];
+    /* scatter (:456-502): copy points (or their negation) into bucket order; the order inside a bucket is whatever the
+     * threads' cursor increments make it -- the bucket sum does not depend on it */
     memcpy(cursor, start, 8 * (L + 2));
-    uint64_t maxb = 0;
-    for (uint64_t j = 0; j < n2; j++) {
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t j = 0; j < (int64_t)n2; j++) {
       uint32_t l = dig[j] & 0x7fffffffu;
       if (!l) continue;
       aff a = pts[j];
       if (dig[j] >> 31) fe_neg(&a.y, &a.y);
-      sorted[cursor[l]++] = a;
+      sorted[__atomic_fetch_add(&cursor[l], 1, __ATOMIC_RELAXED)] = a;
     }
-    for (uint64_t l = 1; l <= L; l++) { uint64_t sz = start[l + 1] - start[l]; if (sz > maxb) maxb = sz; }
-    /* accumulation rounds (:243-282) */
-    size_t maxpairs = total / 2 + 1;
-    aff** Gp = (aff**)malloc(sizeof(aff*) * maxpairs);
-    aff** Hp = (aff**)malloc(sizeof(aff*) * maxpairs);
-    fe* pre = (fe*)malloc(sizeof(fe) * maxpairs);
-    uint8_t* kind = (uint8_t*)malloc(maxpairs);
-    if (!Gp || !Hp || !pre || !kind) oom = 1;
-    else
-      for (uint64_t m = 1; m < maxb; m *= 2) {
-        size_t np = 0;
-        for (uint64_t l = 1; l <= L; l++) {
-          uint64_t bs = start[l], be = start[l + 1];
-          for (uint64_t q = bs; q + m < be; q += 2 * m) { Gp[np] = &sorted[q]; Hp[np] = &sorted[q + m]; np++; }
+    /* accumulation rounds (:243-282) and bucket reduction (:556-583): buckets [lo, hi] per thread, equal shares of the
+     * sorted entries; every thread builds its own pair lists and shares one inversion per round among them */
+    proj* tsum = (proj*)malloc(sizeof(proj) * nthreads);
+    if (!tsum) { oom = 1; break; }
+#pragma omp parallel num_threads(nthreads)
+    {
+      int tid = 0, nt = 1;
+#ifdef _OPENMP
+      tid = omp_get_thread_num(); nt = omp_get_num_threads();
+#endif
+      /* bucket range of this thread: boundaries where the cumulative entry count crosses tid / nt of the total */
+      uint64_t lo = 1, hi = 0;
+      {
+        const uint64_t want_lo = total / nt * tid, want_hi = (tid == nt - 1) ? total : total / nt * (tid + 1);
+        uint64_t a = 1, b = L + 1;   /* first bucket l with start[l] >= want_lo */
+        while (a < b) { uint64_t m = (a + b) / 2; if (start[m] >= want_lo) b = m; else a = m + 1; }
+        lo = a;
+        a = 1; b = L + 1;
+        while (a < b) { uint64_t m = (a + b) / 2; if (start[m] >= want_hi) b = m; else a = m + 1; }
+        hi = a - 1;                 /* buckets lo .. hi */
+        if (tid == nt - 1) hi = L;
+      }
+      proj contrib;
+      proj_zero(&contrib);
+      if (lo <= hi) {
+        const uint64_t ebeg = start[lo], eend = start[hi + 1];
+        uint64_t maxb = 0;
+        for (uint64_t l = lo; l <= hi; l++) { uint64_t sz = start[l + 1] - start[l]; if (sz > maxb) maxb = sz; }
+        size_t maxpairs = (eend - ebeg) / 2 + 1;
+        aff** Gp = (aff**)malloc(sizeof(aff*) * maxpairs);
+        aff** Hp = (aff**)malloc(sizeof(aff*) * maxpairs);
+        fe* pre = (fe*)malloc(sizeof(fe) * maxpairs);
+        uint8_t* kind = (uint8_t*)malloc(maxpairs);
+        if (!Gp || !Hp || !pre || !kind) {
+#pragma omp atomic write
+          oom = 1;
+        } else {
+          for (uint64_t m = 1; m < maxb; m *= 2) {
+            size_t np = 0;
+            for (uint64_t l = lo; l <= hi; l++) {
+              uint64_t bs = start[l], be = start[l + 1];
+              for (uint64_t q = bs; q + m < be; q += 2 * m) { Gp[np] = &sorted[q]; Hp[np] = &sorted[q + m]; np++; }
+            }
+            if (np) batch_add(Gp, Hp, np, pre, kind);
+          }
+          /* reduction of this thread's bucket range: sum_l l * B_l = tri + (lo - 1) * row (:574-580) */
+          proj row, tri;
+          proj_zero(&row); proj_zero(&tri);
+          for (uint64_t l = hi; l >= lo; l--) {
+            if (start[l + 1] > start[l] && !sorted[start[l]].inf) {
+              proj Bk; Bk.X = sorted[start[l]].x; Bk.Y = sorted[start[l]].y; Bk.Z = ONE;
+              proj_add(&row, &row, &Bk);
+            }
+            proj_add(&tri, &tri, &row);
+          }
+          uint64_t w = lo - 1;
+          contrib = tri;
+          while (w) {              /* double-and-add of the row sum */
+            if (w & 1) proj_add(&contrib, &contrib, &row);
+            w >>= 1;
+            if (w) proj_dbl(&row, &row);
+          }
         }
-        if (np) batch_add(Gp, Hp, np, pre, kind);
+        free(Gp); free(Hp); free(pre); free(kind);
       }
-    /* bucket reduction (:556-583), lstart = 1 */
-    proj row, tri;
-    proj_zero(&row); proj_zero(&tri);
-    for (uint64_t l = L; l >= 1; l--) {
-      if (start[l + 1] > start[l] && !sorted[start[l]].inf) {
-        proj Bk; Bk.X = sorted[start[l]].x; Bk.Y = sorted[start[l]].y; Bk.Z = ONE;
-        proj_add(&row, &row, &Bk);
-      }
-      proj_add(&tri, &tri, &row);
+      tsum[tid] = contrib;
     }
-    part[k] = tri;
-    free(dig); free(start); free(sorted); free(cursor); free(Gp); free(Hp); free(pre); free(kind);
+    proj acc;
+    proj_zero(&acc);
+    for (int i = 0; i < nthreads; i++) proj_add(&acc, &acc, &tsum[i]);
+    part[k] = acc;
+    free(tsum);
   }
+  free(dig); free(start); free(cursor); free(sorted);
   free(pts); free(mags);
   if (oom) { free(part); return -2; }
   /* final sum (:322-333) */
@@ -450,6 +499,37 @@ int oracle_msm_bls377(const uint8_t* points, const uint8_t* scalars, uint64_t n,
   fe_mul(&x, &x, &one); fe_mul(&y, &y, &one);
   fe_to_bytes(out, &x); fe_to_bytes(out + 48, &y);
   return 0;
+}
+
+/* sum_i a_i * s_i over n pairs of 32-byte little-endian integers, as ONE 640-bit integer (10 x 64-bit words, no modular
+ * reduction: the caller reduces mod q).  Checker of the known-discrete-log identity sum s_i P_i = (sum s_i a_i) G at sizes
+ * Python integers are too slow for (2^26: 6.7e7 products). */
+void oracle_dot_u256(const uint8_t* a, const uint8_t* s, uint64_t n, uint64_t* out10) {
+  uint64_t total[10] = {0};
+#pragma omp parallel
+  {
+    uint64_t acc[10] = {0};
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+      uint64_t x[4], y[4];
+      memcpy(x, a + 32 * i, 32);
+      memcpy(y, s + 32 * i, 32);
+      uint64_t prod[8] = {0};
+      for (int u = 0; u < 4; u++) {
+        u128 c = 0;
+        for (int v = 0; v < 4; v++) { c += (u128)x[u] * y[v] + prod[u + v]; prod[u + v] = (uint64_t)c; c >>= 64; }
+        prod[u + 4] = (uint64_t)c;
+      }
+      u128 c = 0;
+      for (int j = 0; j < 10; j++) { c += (u128)acc[j] + (j < 8 ? prod[j] : 0); acc[j] = (uint64_t)c; c >>= 64; }
+    }
+#pragma omp critical
+    {
+      u128 c = 0;
+      for (int j = 0; j < 10; j++) { c += (u128)total[j] + acc[j]; total[j] = (uint64_t)c; c >>= 64; }
+    }
+  }
+  memcpy(out10, total, sizeof total);
 }
 
 /* field operator for KATs: op 0 = a*b mod p, 1 = a^-1 mod p, 2 = a+b, 3 = a-b (plain canonical integers) */

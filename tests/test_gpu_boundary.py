@@ -1,0 +1,126 @@
+"""Boundary behaviour of the C ABI / facade that the reference has by construction and round 1 lacked:
+independent pointer handles (every `getPointer` / `randomScalars` of the reference is its own allocation,
+src/parallel.ts:97-133, src/curve-random.ts:151-194), a distinct status for out-of-range scalars, and the
+device-list context of SURVEY.md section 8(b).  Needs an MI355X: `-m gpu`."""
+import pytest
+
+from oracle import msm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+C = O.BLS12_377
+G = (C.gx, C.gy)
+
+
+def test_scalar_handles_are_independent_allocations():
+    """a = randomScalars(n); b = randomScalars(n); msm(a) must use a's data (round 1 computed with b's), also after
+    a bigger handle was made and dropped in between."""
+    from montgomery_amd.api import BLS12_377_PARAMS, Weierstrass
+
+    cv = Weierstrass.create(BLS12_377_PARAMS)
+    par, ctx = cv.Parallel, cv.context
+    n = 3000
+    pp = par.randomPointsFast(n, seed=5)
+    a_logs = O.scalars_from_bytes(ctx.generate_points(n, seed=5, want_scalars=True))   # same seed: the same points
+    a = par.randomScalars(n, seed=101)
+    b = par.randomScalars(n, seed=202)
+    assert a.dev_ptr != b.dev_ptr
+    big = par.randomScalars(50 * n, seed=303)     # grows nothing that a or b point into
+    big.close()
+    _, sa = ctx.generate_scalars(n, seed=101, to_host=True)
+    _, sb = ctx.generate_scalars(n, seed=202, to_host=True)
+    ea = O.aff_scale(sum(x * y for x, y in zip(a_logs, O.scalars_from_bytes(sa))) % C.q, G, C.p)
+    eb = O.aff_scale(sum(x * y for x, y in zip(a_logs, O.scalars_from_bytes(sb))) % C.q, G, C.p)
+    assert ea != eb
+    assert par.msm(a, pp, n)["result"].as_tuple() == ea
+    assert par.msm(b, pp, n)["result"].as_tuple() == eb
+    assert par.msm(a, pp, n)["result"].as_tuple() == ea
+    a.close(); b.close(); pp.close()
+    cv.context.close()
+
+
+def test_point_handles_coexist():
+    """Two `pointPtr`s of one curve object stay valid side by side; msm() uses the one it is given."""
+    from montgomery_amd import MsmError
+    from montgomery_amd.api import BLS12_377_PARAMS, Weierstrass
+
+    cv = Weierstrass.create(BLS12_377_PARAMS)
+    par = cv.Parallel
+    p1, _ = O.random_points_bls377("bnd/p1", 40)
+    p2, _ = O.random_points_bls377("bnd/p2", 25)
+    sc = O.prng_ints("bnd/s", 40, C.q)
+    pp1, pp2 = par.getPointer(40 * 96), par.getPointer(25 * 96)
+    assert pp1.set_id != pp2.set_id
+    par.pointsFromBytes(pp1, O.points_to_bytes(p1, 48), 40)
+    par.pointsFromBytes(pp2, O.points_to_bytes(p2, 48), 25)     # must not replace the points behind pp1
+    sp = par.getScalarPointer(40 * 32)
+    par.scalarsFromBytes(sp, O.scalars_to_bytes(sc), 40)
+    assert par.msm(sp, pp1, 40)["result"].as_tuple() == O.msm_naive_affine(sc, p1, C)
+    assert par.msm(sp, pp2, 25)["result"].as_tuple() == O.msm_naive_affine(sc[:25], p2, C)
+    assert par.msm(sp, pp1, 40)["result"].as_tuple() == O.msm_naive_affine(sc, p1, C)
+    with pytest.raises(MsmError):
+        par.msm(sp, pp2, 40)           # only 25 points behind this pointer
+    pp2.close()
+    assert par.msm(sp, pp1, 40)["result"].as_tuple() == O.msm_naive_affine(sc, p1, C)
+    cv.context.close()
+
+
+def test_strict_scalars_status(gpu_ctx):
+    """Scalars >= q: reduced mod q by default (same group element), MSM_ERR_SCALAR under msm_opts.strict."""
+    import ctypes as CT
+
+    from montgomery_amd import MsmError, _lib
+    from montgomery_amd._lib import MsmOpts, MsmResult
+
+    pts, _ = O.random_points_bls377("bnd/strict", 20)
+    sc = O.prng_ints("bnd/strict/s", 20, C.q)
+    sc[7] += C.q                                    # still < 2^256
+    gpu_ctx.set_points(O.points_to_bytes(pts, 48))
+    res, _ = gpu_ctx.run(O.scalars_to_bytes(sc))
+    assert res.as_tuple() == O.msm_naive_affine([s % C.q for s in sc], pts, C)
+    buf = (CT.c_uint8 * (32 * 20)).from_buffer_copy(O.scalars_to_bytes(sc))
+    out = MsmResult()
+    rc = gpu_ctx._lib.msm_run(gpu_ctx._h, buf, 20, 0, CT.byref(MsmOpts(strict=1)), CT.byref(out))
+    assert rc == _lib.MSM_ERR_SCALAR
+    assert b"group order" in gpu_ctx._lib.msm_last_error(gpu_ctx._h)
+    sc[7] -= C.q
+    buf = (CT.c_uint8 * (32 * 20)).from_buffer_copy(O.scalars_to_bytes(sc))
+    assert gpu_ctx._lib.msm_run(gpu_ctx._h, buf, 20, 0, CT.byref(MsmOpts(strict=1)), CT.byref(out)) == _lib.MSM_OK
+    with pytest.raises(MsmError):
+        gpu_ctx.window_sums(O.scalars_to_bytes(sc), 20, 0, 0)      # (0, 0) is no longer "all windows" on the Python side
+
+
+@pytest.mark.parametrize("lg", [8, 16])
+def test_device_list_context_on_one_gpu(gpu_ctx, lg):
+    """msm_ctx_create_multi with the device list [0, 0, 0]: three device contexts (here on the same GPU), the windows
+    sharded 3 / 3 / 2 across them by host threads inside the library, partition sums combined on the host.  Host and
+    device scalars, MSM and window sums, against the single-device context on the same inputs."""
+    from montgomery_amd.api import MsmContext
+
+    n = 1 << lg
+    multi = MsmContext(devices=[0, 0, 0])
+    assert multi.n_devices == 3
+    a = O.scalars_from_bytes(multi.generate_points(n, seed=77, want_scalars=True))
+    gpu_ctx.generate_points(n, seed=77)
+    dev, sb = multi.generate_scalars(n, seed=78, to_host=True)
+    single, info1 = gpu_ctx.run(sb)
+    exp = O.aff_scale(sum(x * y for x, y in zip(a, O.scalars_from_bytes(sb))) % C.q, G, C.p)
+    assert single.as_tuple() == exp
+    r_host, info = multi.run(sb)
+    assert r_host.as_tuple() == exp
+    assert info["n_pairs"] == info1["n_pairs"] and info["K"] == info1["K"]
+    r_dev, _ = multi.run_device(dev, n)
+    assert r_dev.as_tuple() == exp
+    K, c = info["K"], info["c"]
+    parts, _ = multi.window_sums(sb, n, 0, K)
+    assert multi.combine(parts, K, c).as_tuple() == exp
+    # a second point set on the multi context, then back
+    sid = multi.pointset_create()
+    pts, _ = O.random_points_bls377("bnd/multi", 9)
+    multi.set_points(O.points_to_bytes(pts, 48))
+    sc = O.prng_ints("bnd/multi/s", 9, C.q)
+    assert multi.run(O.scalars_to_bytes(sc))[0].as_tuple() == O.msm_naive_affine(sc, pts, C)
+    multi.pointset_select(0)
+    assert multi.run(sb)[0].as_tuple() == exp
+    multi.pointset_destroy(sid)
+    multi.close()

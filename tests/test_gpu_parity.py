@@ -318,6 +318,20 @@ def test_msm_large_known_discrete_logs(gpu_ctx, lg):
     assert res2.as_tuple() == res.as_tuple()
 
 
+def test_msm_2p26_known_discrete_logs(gpu_ctx, c_oracle):
+    """BASELINE configs[2], the size the headline number is quoted on: 2^26 distinct points P_i = a_i G, 2^26 uniform
+    scalars, sum s_i P_i == (sum s_i a_i mod q) G.  The dot product runs in the C oracle (OpenMP); the reference checks
+    every size it benchmarks the same way against its slow path (src/msm.test.ts:64-70, scripts/msm-weierstrass.ts:97-107)."""
+    n = 1 << 26
+    a = gpu_ctx.generate_points(n, seed=2626, want_scalars=True, raw=True)
+    dev, s = gpu_ctx.generate_scalars(n, seed=6262, to_host=True, raw=True)
+    res, info = gpu_ctx.run_device(dev, n)
+    k = c_oracle.dot_mod(a, s, n, C.q)
+    del a, s
+    assert info["c"] == 16 and info["K"] == 8
+    assert res.as_tuple() == O.aff_scale(k, (C.gx, C.gy), P_MOD), info
+
+
 def test_msm_large_linearity(gpu_ctx):
     """MSM(s) + MSM(t) = MSM(s + t) and MSM(q - s) = -MSM(s) at 2^18, host scalars (PCIe path)."""
     n = 1 << 18
