@@ -192,6 +192,7 @@ class MsmContext:
         i = C.c_int32()
         self._check(self._lib.msm_pointset_create(self._h, C.byref(i)))
         self.n_points = 0
+        self._cur_set = i.value
         self._set_sizes[i.value] = 0
         return i.value
 
