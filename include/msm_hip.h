@@ -172,6 +172,23 @@ int msm_test_glv(msm_ctx* ctx, const uint8_t* scalars, uint8_t* out, uint64_t n)
  * unified extended addition of the gather round (src/curve-twisted-edwards.ts:84-165), n x 64 bytes each way. */
 int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t* out, uint64_t n);
 
+/* ---- worst-case / operator-level surface (round 2) ---- */
+/* fe_mul / fe_sqr on RAW register-form operands: n x NL 30-bit limbs as uint32 (NL = 13; Ed-on-BLS12-377: 9), exactly as
+ * given -- unreduced values up to the documented 2^6 p, all-ones limbs -- and the result limbs as they leave the
+ * multiplier (not reduced).  op = MSM_OP_MUL or MSM_OP_SQR.  Mirrors src/field.test.ts:27-155 on [0, 2p) and beyond. */
+int msm_test_fp_raw(msm_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, uint64_t n);
+/* curve operators, one per element: Weierstrass curves take and return homogeneous projective points n x (X || Y || Z),
+ * 48-byte little-endian integers < p (any representative; Z = 0 is the identity); Ed-on-BLS12-377 extended points
+ * n x (X || Y || Z || T) of 32 bytes.  op 0: general addition with every edge case (proj_add / te_add, 9M form),
+ * 1: doubling of P, 2 (Weierstrass): mixed addition, Q affine with (0, 0) the identity.
+ * src/curve-projective.test.ts:77-208, src/curve-twisted-edwards.test.ts:55-158. */
+enum { MSM_CURVE_OP_ADD = 0, MSM_CURVE_OP_DOUBLE = 1, MSM_CURVE_OP_ADD_MIXED = 2 };
+int msm_test_curve_op(msm_ctx* ctx, int op, const uint8_t* p, const uint8_t* q, uint8_t* out, uint64_t n);
+/* msm_test_batch_add through the plane-reading modes of the tree kernel with a chosen number of pairs per lane (= per
+ * shared inversion): mode 1 = regular rounds, 2 = tail rounds (operand descriptors; an all-zero H_e is passed as
+ * "no second operand").  steps >= 1. */
+int msm_test_batch_add_mode(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t* out, uint64_t n, int mode, uint32_t steps);
+
 #ifdef __cplusplus
 }
 #endif

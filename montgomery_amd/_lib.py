@@ -29,6 +29,7 @@ EXPORTS = (
     "msm_test_glv", "msm_test_batch_add", "msm_test_batch_inverse",
     "msm_ctx_create_multi", "msm_ctx_device_count", "msm_pointset_create", "msm_pointset_select", "msm_pointset_destroy",
     "msm_device_alloc", "msm_device_free", "msm_device_upload",
+    "msm_test_fp_raw", "msm_test_curve_op", "msm_test_batch_add_mode",
 )
 
 
@@ -97,6 +98,9 @@ def load() -> C.CDLL:
     lib.msm_device_alloc.argtypes = [vp, u64, C.POINTER(vp)]
     lib.msm_device_free.argtypes = [vp, vp]
     lib.msm_device_upload.argtypes = [vp, vp, vp, u64]
+    lib.msm_test_fp_raw.argtypes = [vp, C.c_int, vp, vp, vp, u64]
+    lib.msm_test_curve_op.argtypes = [vp, C.c_int, vp, vp, vp, u64]
+    lib.msm_test_batch_add_mode.argtypes = [vp, vp, vp, vp, u64, C.c_int, C.c_uint32]
     for name in EXPORTS:
         if name not in ("msm_ctx_destroy", "msm_last_error"):
             getattr(lib, name).restype = C.c_int

@@ -360,6 +360,33 @@ class MsmContext:
         self._check(self._lib.msm_test_batch_inverse(self._h, bx, out, n, per_lane))
         return bytes(out)
 
+    def test_fp_raw(self, op: int, a_limbs: Sequence[Sequence[int]], b_limbs: Sequence[Sequence[int]]) -> List[List[int]]:
+        """fe_mul / fe_sqr on raw 30-bit-limb operands (lists of NL ints per element); returns the raw result limbs."""
+        nl = 9 if self.curve == _lib.CURVE_ED_ON_BLS12_377 else 13
+        n = len(a_limbs)
+        A = (C.c_uint32 * (nl * n))(*[w for e in a_limbs for w in e])
+        B = (C.c_uint32 * (nl * n))(*[w for e in b_limbs for w in e])
+        out = (C.c_uint32 * (nl * n))()
+        self._check(self._lib.msm_test_fp_raw(self._h, op, A, B, out, n))
+        return [[int(out[i * nl + j]) for j in range(nl)] for i in range(n)]
+
+    def test_curve_op(self, op: int, p: BytesLike, q: BytesLike) -> bytes:
+        """Projective (X || Y || Z, 48 B each) or extended Edwards (X || Y || Z || T, 32 B each) operator; see msm_hip.h."""
+        bp = (C.c_uint8 * len(p)).from_buffer_copy(bytes(p))
+        bq = (C.c_uint8 * len(q)).from_buffer_copy(bytes(q))
+        out = (C.c_uint8 * len(p))()
+        nb = 128 if self.curve == _lib.CURVE_ED_ON_BLS12_377 else 144
+        self._check(self._lib.msm_test_curve_op(self._h, op, bp, bq, out, len(p) // nb))
+        return bytes(out)
+
+    def test_batch_add_mode(self, g: BytesLike, h: BytesLike, mode: int, steps: int) -> bytes:
+        n = len(g) // 96
+        bg = (C.c_uint8 * len(g)).from_buffer_copy(bytes(g))
+        bh = (C.c_uint8 * len(h)).from_buffer_copy(bytes(h))
+        out = (C.c_uint8 * len(g))()
+        self._check(self._lib.msm_test_batch_add_mode(self._h, bg, bh, out, n, mode, steps))
+        return bytes(out)
+
     def test_batch_add(self, g: BytesLike, h: BytesLike) -> bytes:
         n = len(g) // (2 * self.coord_bytes)
         bg = (C.c_uint8 * len(g)).from_buffer_copy(bytes(g))

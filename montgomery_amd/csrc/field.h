@@ -14,9 +14,11 @@
 // Memory form: NW packed 32-bit little-endian words, Montgomery representation, CANONICAL
 // (value in [0, p)) so equality is a plain word compare.
 //
-// Value-range discipline (the reference keeps values < 2p with R = 2^406; we have R >= 2^13 p):
-//   fe_mul/fe_sqr accept any operands with a*b < 2^12 * p * p and return a value < p + p/2,
-//   so sums/differences of a few elements may be multiplied without reduction.
+// Value-range discipline (the reference keeps values < 2p with R = 2^406): fe_mul / fe_sqr accept any operands with
+// normalised limbs and return a value < p + a b / R, i.e. < 1.5 p whenever a b < R p / 2 -- that is a b < 2^12 p^2 for
+// the 377-bit prime (R = 2^13 p), 2^14 p^2 for the 253-bit prime, and 2^8 p^2 for BLS12-381 (R = 2^9 p), which still
+// covers every product the kernels form (operands below 4.5 p and 2 p).  So sums / differences of a few elements may be
+// multiplied without reduction.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

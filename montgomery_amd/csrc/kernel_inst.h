@@ -20,6 +20,8 @@
   X(msm::k_test_fp<CV>, (uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int))                                    \
   X(msm::k_test_batch_inverse<CV>, (uint32_t*, const uint32_t*, uint32_t, uint32_t))                                     \
   X(msm::k_test_glv<CV>, (uint32_t*, const uint32_t*, uint32_t))                                                         \
+  X(msm::k_test_fp_raw<CV>, (uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int))                                \
+  X(msm::k_test_curve_op<CV>, (uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int))                              \
   X(msm_gen::k_gen_points<CV>, (uint32_t*, const uint32_t*, uint64_t, uint64_t))
 
 #define MSM_EXTERN_KERNEL(name, args) extern template __global__ void name args;

@@ -1617,6 +1617,125 @@ static int generate_points_one(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t*
   } MSM_CATCH_ALL(ctx)
 }
 
+int msm_test_fp_raw(msm_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, uint64_t n) {
+  if (!ctx || !a || !b || !out) return fail(ctx, MSM_ERR_ARG, "msm_test_fp_raw: null argument");
+  if (op != MSM_OP_MUL && op != MSM_OP_SQR) return fail(ctx, MSM_ERR_ARG, "msm_test_fp_raw: op must be MSM_OP_MUL or MSM_OP_SQR");
+  const size_t nb = (ctx->is_te() ? te::TL : NL) * 4;
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->ensure(ctx->misc, n * nb * 3 + 64);
+    uint8_t* d = (uint8_t*)ctx->misc.p;
+    HIPCHK(hipMemcpyAsync(d, a, n * nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d + n * nb, b, n * nb, hipMemcpyHostToDevice, ctx->stream));
+    const dim3 grid((uint32_t)((n + 255) / 256));
+    if (ctx->is_te())
+      hipLaunchKernelGGL(te::k_te_test_fp_raw, grid, dim3(256), 0, ctx->stream, (uint32_t*)(d + 2 * n * nb), (const uint32_t*)d,
+                         (const uint32_t*)(d + n * nb), (uint32_t)n, op);
+    else
+      W_LAUNCH(ctx, k_test_fp_raw, grid, dim3(256), 0, ctx->stream, (uint32_t*)(d + 2 * n * nb), (const uint32_t*)d,
+                         (const uint32_t*)(d + n * nb), (uint32_t)n, op);
+    HIPCHK(hipMemcpyAsync(out, d + 2 * n * nb, n * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    return MSM_OK;
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_test_curve_op(msm_ctx* ctx, int op, const uint8_t* p, const uint8_t* q, uint8_t* out, uint64_t n) {
+  if (!ctx || !p || !q || !out) return fail(ctx, MSM_ERR_ARG, "msm_test_curve_op: null argument");
+  if (op < 0 || op > 2) return fail(ctx, MSM_ERR_ARG, "msm_test_curve_op: unknown operator");
+  const size_t nb = ctx->is_te() ? 128 : 144;
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->ensure(ctx->misc, n * nb * 3 + 64);
+    uint8_t* d = (uint8_t*)ctx->misc.p;
+    HIPCHK(hipMemcpyAsync(d, p, n * nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d + n * nb, q, n * nb, hipMemcpyHostToDevice, ctx->stream));
+    const dim3 grid((uint32_t)((n + 63) / 64));
+    if (ctx->is_te())
+      hipLaunchKernelGGL(te::k_te_test_curve_op, grid, dim3(64), 0, ctx->stream, (uint32_t*)(d + 2 * n * nb), (const uint32_t*)d,
+                         (const uint32_t*)(d + n * nb), (uint32_t)n, op);
+    else
+      W_LAUNCH(ctx, k_test_curve_op, grid, dim3(64), 0, ctx->stream, (uint32_t*)(d + 2 * n * nb), (const uint32_t*)d,
+                         (const uint32_t*)(d + n * nb), (uint32_t)n, op);
+    HIPCHK(hipMemcpyAsync(out, d + 2 * n * nb, n * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    return MSM_OK;
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_test_batch_add_mode(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t* out, uint64_t n, int mode, uint32_t steps) {
+  if (!ctx || !g || !h || !out || n == 0 || steps == 0) return fail(ctx, MSM_ERR_ARG, "msm_test_batch_add_mode: bad argument");
+  if (ctx->is_te() || (mode != MODE_REGULAR && mode != MODE_SEARCH))
+    return fail(ctx, MSM_ERR_ARG, "msm_test_batch_add_mode: Weierstrass curves, mode 1 (regular) or 2 (search)");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    // element 2e = G_e, 2e + 1 = H_e in plane layout; search mode: an all-zero H_e is passed as "no second operand"
+    const uint64_t T = ((n + steps - 1) / steps + 255) / 256 * 256;
+    const uint64_t in_cap = 2 * (uint64_t)steps * T;     // idle lanes of the last step read (and ignore) up to here
+    DevBuf rows, wire, planes, outb, scr, desc;
+    ctx->ensure(wire, 2 * n * 96);
+    ctx->ensure(rows, 2 * n * ROW_WORDS * 4);
+    ctx->ensure(planes, in_cap * 96);
+    ctx->ensure(outb, (uint64_t)steps * T * 96);
+    ctx->ensure(scr, (size_t)steps * NL * T * 4);
+    std::vector<uint8_t> inter(2 * n * 96);
+    std::vector<uint32_t> hd(n);
+    for (uint64_t i = 0; i < n; i++) {
+      memcpy(&inter[(2 * i) * 96], g + i * 96, 96);
+      memcpy(&inter[(2 * i + 1) * 96], h + i * 96, 96);
+      bool hz = true;
+      for (int j = 0; j < 96; j++) hz = hz && h[i * 96 + j] == 0;
+      hd[i] = (uint32_t)((2 * i) << 1) | (hz ? 0u : 1u);
+    }
+    HIPCHK(hipMemcpyAsync(wire.p, inter.data(), inter.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(planes.p, 0, in_cap * 96, ctx->stream));
+    W_LAUNCH(ctx, k_points_from_wire, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)rows.p,
+                       (const uint32_t*)wire.p, 2 * n, 0, (uint32_t*)ctx->errflag.p);
+    hipLaunchKernelGGL(k_test_rows_to_planes, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, (uint4*)planes.p,
+                       in_cap, (const uint32_t*)rows.p, (uint32_t)(2 * n));
+    BatchArgs a{};
+    a.in = (const uint4*)planes.p;
+    a.in_cap = in_cap;
+    a.out = (uint4*)outb.p;
+    a.out_cap = (uint64_t)steps * T;
+    a.scratch = (uint32_t*)scr.p;
+    a.n_out = n;
+    a.steps = steps;
+    if (mode == MODE_SEARCH) {
+      ctx->ensure(desc, n * 4);
+      HIPCHK(hipMemcpyAsync(desc.p, hd.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+      a.desc = (const uint32_t*)desc.p;
+      W_LAUNCH_MODE(ctx, k_batch_add, MODE_SEARCH, dim3((uint32_t)(T / 256)), dim3(256), 0, ctx->stream, a);
+    } else {
+      W_LAUNCH_MODE(ctx, k_batch_add, MODE_REGULAR, dim3((uint32_t)(T / 256)), dim3(256), 0, ctx->stream, a);
+    }
+    std::vector<uint32_t> pl(a.out_cap * 24);
+    HIPCHK(hipMemcpyAsync(pl.data(), outb.p, pl.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
+    for (uint64_t e = 0; e < n; e++) {
+      uint32_t w[24];
+      for (int cpl = 0; cpl < 6; cpl++)
+        for (int q = 0; q < 4; q++) w[4 * cpl + q] = pl[((uint64_t)cpl * a.out_cap + e) * 4 + q];
+      memset(out + e * 96, 0, 96);
+      if (w[11] == INF_WORD) continue;
+      for (int j = 0; j < 2; j++) {
+        msm_host::Fe6 t;
+        words_to_fe6(t, w + 12 * j);
+        ctx->hc.F.mul(t, t, ctx->k_dev_to_host);
+        ctx->hc.F.mul(t, t, one);
+        fe6_to_bytes(out + e * 96 + 48 * j, t);
+      }
+    }
+    for (DevBuf* b : {&rows, &wire, &planes, &outb, &scr, &desc}) ctx->release(*b);
+    return MSM_OK;
+  } MSM_CATCH_ALL(ctx)
+}
+
 int msm_generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
   if (!ctx) return MSM_ERR_ARG;
   if (ctx->children.empty()) return generate_points_one(ctx, n, seed, a_out);

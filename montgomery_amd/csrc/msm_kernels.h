@@ -650,6 +650,56 @@ __global__ void __launch_bounds__(256) k_test_batch_inverse(uint32_t* out, const
   }
 }
 
+// Raw-limb multiplier test: operands are NL 30-bit limbs exactly as given -- unreduced sums, all-ones limbs -- and the
+// result limbs are stored as they leave fe_mul / fe_sqr (no reduction): the worst-case side of src/field.test.ts:27-155.
+template <class CV>
+__global__ void __launch_bounds__(256) k_test_fp_raw(uint32_t* out, const uint32_t* a, const uint32_t* b, uint32_t n, int op) {
+  using F = typename CV::F;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe<F> x, y, r;
+#pragma unroll
+  for (int l = 0; l < F::NL; l++) { x.l[l] = a[(uint64_t)i * F::NL + l]; y.l[l] = b[(uint64_t)i * F::NL + l]; }
+  if (op == OP_SQR) fe_sqr<F>(r, x);
+  else fe_mul<F>(r, x, y);
+#pragma unroll
+  for (int l = 0; l < F::NL; l++) out[(uint64_t)i * F::NL + l] = r.l[l];
+}
+
+// Curve operators on projective points (X, Y, Z: 3 x 12 canonical plain-integer words each, any representative):
+// op 0 = proj_add (general, every edge case), 1 = proj_double, 2 = proj_add_mixed (Q affine: Q.Z ignored, Q == (0, 0) is
+// the identity).  Operator-level counterpart of src/curve-projective.test.ts:77-208.
+enum : int { CURVE_OP_ADD = 0, CURVE_OP_DOUBLE = 1, CURVE_OP_ADD_MIXED = 2 };
+template <class CV>
+__global__ void __launch_bounds__(64) k_test_curve_op(uint32_t* out, const uint32_t* pp, const uint32_t* qq, uint32_t n, int op) {
+  using F = typename CV::F;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe<F> r2, one;
+#pragma unroll
+  for (int l = 0; l < NL; l++) r2.l[l] = F::R2[l];
+  fe_set_zero<F>(one);
+  one.l[0] = 1;
+  Proj<F> P, Q, R;
+  Fe<F>* co[6] = {&P.X, &P.Y, &P.Z, &Q.X, &Q.Y, &Q.Z};
+  bool q_zero_xy = true;
+  for (int j = 0; j < 6; j++) {
+    const uint32_t* src = (j < 3 ? pp : qq) + (uint64_t)i * 36 + (j % 3) * 12;
+    fe_load<F>(*co[j], src);
+    if (j == 3 || j == 4) q_zero_xy = q_zero_xy && fe_is_zero_canonical<F>(*co[j]);
+    fe_mul<F>(*co[j], *co[j], r2);      // to Montgomery form, < 1.5 p
+  }
+  if (op == CURVE_OP_DOUBLE) proj_double<F>(R, P);
+  else if (op == CURVE_OP_ADD_MIXED) proj_add_mixed<F>(R, P, Q, q_zero_xy);
+  else proj_add<F>(R, P, Q);
+  Fe<F>* ro[3] = {&R.X, &R.Y, &R.Z};
+  for (int j = 0; j < 3; j++) {
+    fe_mul<F>(*ro[j], *ro[j], one);     // leave Montgomery form
+    fe_reduce_4p<F>(*ro[j]);
+    fe_store<F>(out + (uint64_t)i * 36 + j * 12, *ro[j]);
+  }
+}
+
 // out: n x 10 words: |s0| (4), |s1| (4), neg0, neg1
 template <class CV>
 __global__ void __launch_bounds__(256) k_test_glv(uint32_t* out, const uint32_t* scalars, uint32_t n) {

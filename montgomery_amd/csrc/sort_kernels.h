@@ -289,6 +289,17 @@ __global__ void __launch_bounds__(SORT_THREADS) k_scatter_coarse(uint32_t* dig2,
 }
 
 
+// point rows (k_points_from_wire) -> tree planes, element e of the planes = row e: test input of the plane-reading modes
+__global__ void __launch_bounds__(256) k_test_rows_to_planes(uint4* planes, uint64_t cap, const uint32_t* rows, uint32_t n) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  uint32_t w[NW];
+  load_words12(w, rows + (uint64_t)e * ROW_WORDS);
+  store_planes3(planes, cap, 0, e, w);
+  load_words12(w, rows + (uint64_t)e * ROW_WORDS + ROW_Y);
+  store_planes3(planes, cap, 3, e, w);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_finish_hist / k_finish_perm: order the buckets by the number of elements they still hold when the tree stops,
 // largest first, so that the 64 lanes of a k_bucket_finish wave run the same number of additions (a wave costs its

@@ -480,5 +480,43 @@ __global__ void __launch_bounds__(256) k_te_test_fp(uint32_t* out, const uint32_
   fe_store<FT>(out + (uint64_t)i * TW, r);
 }
 
+// raw-limb multiplier test on the 253-bit field (see k_test_fp_raw)
+__global__ void __launch_bounds__(256) k_te_test_fp_raw(uint32_t* out, const uint32_t* a, const uint32_t* b, uint32_t n, int op) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe<FT> x, y, r;
+#pragma unroll
+  for (int l = 0; l < TL; l++) { x.l[l] = a[(uint64_t)i * TL + l]; y.l[l] = b[(uint64_t)i * TL + l]; }
+  if (op == OP_SQR) fe_sqr<FT>(r, x);
+  else fe_mul<FT>(r, x, y);
+#pragma unroll
+  for (int l = 0; l < TL; l++) out[(uint64_t)i * TL + l] = r.l[l];
+}
+
+// general unified addition (te_add, 9M) on extended points (X, Y, Z, T: 4 x 8 canonical plain-integer words each):
+// the operator of src/curve-twisted-edwards.test.ts:55-158; op 1 = doubling through the same formula (P + P)
+__global__ void __launch_bounds__(64) k_te_test_curve_op(uint32_t* out, const uint32_t* pp, const uint32_t* qq, uint32_t n, int op) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe<FT> r2, one;
+  TE_CONST(r2, R2);
+  fe_set_zero<FT>(one);
+  one.l[0] = 1;
+  Ext P, Q, R;
+  Fe<FT>* co[8] = {&P.X, &P.Y, &P.Z, &P.T, &Q.X, &Q.Y, &Q.Z, &Q.T};
+  for (int j = 0; j < 8; j++) {
+    fe_load<FT>(*co[j], (j < 4 ? pp : qq) + (uint64_t)i * 32 + (j % 4) * 8);
+    fe_mul<FT>(*co[j], *co[j], r2);
+  }
+  if (op == 1) te_add(R, P, P);
+  else te_add(R, P, Q);
+  Fe<FT>* ro[4] = {&R.X, &R.Y, &R.Z, &R.T};
+  for (int j = 0; j < 4; j++) {
+    fe_mul<FT>(*ro[j], *ro[j], one);
+    fe_reduce_4p<FT>(*ro[j]);
+    fe_store<FT>(out + (uint64_t)i * 32 + j * 8, *ro[j]);
+  }
+}
+
 }  // namespace te
 }  // namespace msm

@@ -36,6 +36,14 @@ static void op(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
   store<C>(out, r);
 }
 
+// raw-limb multiplier / squaring: NL limbs in, NL limbs out, nothing reduced (worst-case operand tests)
+template <class C>
+static void op_raw(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  Fe<C> x, y, r;
+  for (int i = 0; i < C::NL; i++) { x.l[i] = a[i]; y.l[i] = b[i]; }
+  if (which == 1) fe_sqr<C>(r, x); else fe_mul<C>(r, x, y);
+  for (int i = 0; i < C::NL; i++) out[i] = r.l[i];
+}
 extern "C" {
 // field 0 = Fp377 (12 words), 1 = Fp253 (8 words), 2 = Fp381 (12 words), 3 = FpPallas (12 words, upper 4 zero); operands are canonical Montgomery-form words
 void host_fp_op(int field, int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
@@ -43,6 +51,12 @@ void host_fp_op(int field, int which, const uint32_t* a, const uint32_t* b, uint
   else if (field == 1) op<Fp253>(which, a, b, out);
   else if (field == 2) op<Fp381>(which, a, b, out);
   else op<FpPallas>(which, a, b, out);
+}
+void host_fp_raw(int field, int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  if (field == 0) op_raw<Fp377>(which, a, b, out);
+  else if (field == 1) op_raw<Fp253>(which, a, b, out);
+  else if (field == 2) op_raw<Fp381>(which, a, b, out);
+  else op_raw<FpPallas>(which, a, b, out);
 }
 // curve 0 = BLS12-377 lattice, 2 = BLS12-381 lattice, 3 = Pallas lattice
 void host_glv(int curve, const uint32_t* s8, uint32_t* out10) {

@@ -82,3 +82,43 @@ def test_glv_decompose_host_build(lib, curve):
         a0 = sum(int(out[i]) << (32 * i) for i in range(4))
         a1 = sum(int(out[4 + i]) << (32 * i) for i in range(4))
         assert (a0, a1, bool(out[8]), bool(out[9])) == O.glv_decompose(s, g)
+
+
+def _worst_case_limb_operands(p, nl, seed):
+    """Operands the kernels actually feed the multiplier (field.h: a * b < 2^12 p^2, limbs normalised): canonical values,
+    sums / differences of a few elements up to 2^6 p, values just below multiples of p, and limb patterns that maximise
+    the column sums (all limbs 2^30 - 1 up to the top limb of the bound)."""
+    vals = [0, 1, p - 1, p, p + 1, 2 * p - 1, 4 * p - 3, 63 * p, 64 * p - 1, (1 << (30 * (nl - 1))) - 1]
+    vals.append((1 << ((64 * p).bit_length() - 1)) - 1)   # every limb below the top one is all ones, still under the bound
+    vals += [v * k + d for v in O.prng_ints(f"host/raw{seed}", 60, p) for k, d in ((1, 0), (7, 3), (63, 0))]
+    return [v for v in vals if v < 64 * p]
+
+
+@pytest.mark.parametrize("field", [0, 1, 2, 3])
+def test_mul_sqr_on_unreduced_and_all_ones_operands(lib, field):
+    """fe_mul / fe_sqr on raw limbs: the result is congruent to a b / R, below p + a b / R (so below 1.5 p whenever
+    a b < 2^12 p^2 ... here up to 2^12 p^2 exactly at the corner), and its limbs are normalised.  Also the all-ones
+    limb pattern 2^(30 NL) - 1, beyond the contract: no accumulator may wrap, the value must still be congruent."""
+    p, _, nl = FIELDS[field]
+    R = 1 << (30 * nl)
+    rinv = pow(R, -1, p)
+    lib.host_fp_raw.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def raw(which, a, b):
+        A = (C.c_uint32 * nl)(*[(a >> (30 * i)) & 0x3FFFFFFF if i < nl - 1 else a >> (30 * i) for i in range(nl)])
+        B = (C.c_uint32 * nl)(*[(b >> (30 * i)) & 0x3FFFFFFF if i < nl - 1 else b >> (30 * i) for i in range(nl)])
+        out = (C.c_uint32 * nl)()
+        lib.host_fp_raw(field, which, A, B, out)
+        assert all(int(w) < (1 << 30) for w in out[: nl - 1]), "limbs not normalised"
+        return sum(int(w) << (30 * i) for i, w in enumerate(out))
+
+    vals = _worst_case_limb_operands(p, nl, field)
+    for i, a in enumerate(vals):
+        b = vals[-1 - i]
+        r = raw(0, a, b)
+        assert r % p == a * b * rinv % p and r < p + a * b // R + 1
+        r = raw(1, a, a)
+        assert r % p == a * a * rinv % p and r < p + a * a // R + 1
+    ones = R - 1
+    assert raw(0, ones, ones) % p == ones * ones * rinv % p
+    assert raw(1, ones, ones) % p == ones * ones * rinv % p
