@@ -155,7 +155,8 @@ int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy
 enum { MSM_OP_MUL = 0, MSM_OP_SQR = 1, MSM_OP_ADD = 2, MSM_OP_SUB = 3, MSM_OP_INV = 4,
        MSM_OP_TO_MONT = 5, MSM_OP_FROM_MONT = 6,
        MSM_OP_INV_FERMAT = 7,   /* a^(p-2): the cross-check of MSM_OP_INV (division steps) */
-       MSM_OP_INV_KALISKI = 8   /* the reference's almost-inverse, src/wasm/inverse.ts:136-218 */ };
+       MSM_OP_INV_KALISKI = 8,  /* the reference's almost-inverse, src/wasm/inverse.ts:136-218 */
+       MSM_OP_INV_WORDSLICED = 9 /* the reference's experimental word-sliced almost-inverse, src/inverse/faster-inverse-wasm.ts:133-343 */ };
 /* element-wise base-field op on n operands, each a 48-byte (32 for Ed) little-endian word string;
  * MUL/SQR/ADD/SUB/INV act on Montgomery-form operands (radix 2^390 / 2^270) and return canonical
  * Montgomery-form values, i.e. `multiply`, `square`, `add`, `subtract`, `inverse` of

@@ -20,7 +20,7 @@ CURVE_PALLAS = 3
 N_PHASES = 8
 PHASE_NAMES = ("total", "upload", "digits", "sort", "accumulate", "reduce", "final", "accumulate_round1")
 
-OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_INV, OP_TO_MONT, OP_FROM_MONT, OP_INV_FERMAT, OP_INV_KALISKI = range(9)
+OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_INV, OP_TO_MONT, OP_FROM_MONT, OP_INV_FERMAT, OP_INV_KALISKI, OP_INV_WORDSLICED = range(10)
 
 # every symbol include/msm_hip.h declares
 EXPORTS = (

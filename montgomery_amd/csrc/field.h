@@ -457,6 +457,185 @@ MSM_DEV void fe_inv_kaliski(Fe<C>& out, const Fe<C>& a_in) {
   for (int i = 0; i < N; i++) out.l[i] = r[i];
 }
 
+// Word-sliced almost-inverse: the reference's experimental `src/inverse/` (faster-inverse-wasm.ts:133-343, prototype
+// faster-inverse.ts:78-177).  Kaliski's binary gcd again, but w = 30 steps at a time are decided on the LOW words of u, v
+// (parity) and on 63-bit approximations of their HIGH ends (the comparison u >= v), recording the steps in a 2x2 matrix
+//   u' = (u f0 - v g0) / 2^w,  v' = (v g1 - u f1) / 2^w,   r' = r f0 + s g0,  s' = r f1 + s g1
+// that is then applied to the full-width values with 64-bit multiply-adds.  A comparison decided on the approximations
+// can be wrong; u or v then comes out negative and is negated together with its matrix row ("sign flip").
+// Ends with u = 0, v = 1 and a s = 2^k (mod p) after k = 30 x (outer iterations) steps; the input is a R (Montgomery
+// form), so doubling s up to the exponent 2 log2 R gives a^-1 R, as in fe_inv_kaliski.  Fourth inversion variant of
+// SURVEY section 8(f)-3, kept for cross-checks and timing (tools/ubench_inv.hip); the MSM uses fe_inv.
+template <int N>
+MSM_DEV void fe_signed_negate(int32_t (&v)[N], int32_t mask);   // below, with the division-step inverse
+
+template <int N>
+MSM_DEV int fe_ws_bitlen(const int32_t (&x)[N]) {
+  int len = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const uint32_t w = (uint32_t)x[i];
+    int hb = 0;
+    for (uint32_t t = w; t; t >>= 1) hb++;   // host-friendly; the device compiler turns it into a find-first-set
+    if (w) len = LB * i + hb;
+  }
+  return len;
+}
+// bits [shift, shift + 63) of a non-negative N-limb value
+template <int N>
+MSM_DEV int64_t fe_ws_hi63(const int32_t (&x)[N], int shift) {
+  uint64_t r = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const int pos = LB * i - shift;   // where limb i lands
+    const uint64_t w = (uint32_t)x[i];
+    if (pos >= 64 || pos <= -LB) continue;
+    r |= pos >= 0 ? (w << pos) : (w >> (-pos));
+  }
+  return (int64_t)(r & 0x7FFFFFFFFFFFFFFFull);
+}
+// x <- (x a - y b) / 2^30 (exact), y <- (y d - x c) / 2^30: limbs 0..N-2 normalised, top limb signed
+template <int N>
+MSM_DEV void fe_ws_update_uv(int32_t (&x)[N], int32_t (&y)[N], int32_t a, int32_t b, int32_t c, int32_t d) {
+  int64_t cx = 0, cy = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const int64_t tx = (int64_t)x[j] * a - (int64_t)y[j] * b + cx;
+    const int64_t ty = (int64_t)y[j] * d - (int64_t)x[j] * c + cy;
+    if (j > 0) { x[j - 1] = (int32_t)((uint32_t)tx & LMASK); y[j - 1] = (int32_t)((uint32_t)ty & LMASK); }
+    cx = tx >> LB;
+    cy = ty >> LB;
+  }
+  x[N - 1] = (int32_t)cx;
+  y[N - 1] = (int32_t)cy;
+}
+// x <- x a + y b, y <- x c + y d over M limbs (no shift), top limb signed
+template <int M>
+MSM_DEV void fe_ws_update_rs(int32_t (&x)[M], int32_t (&y)[M], int32_t a, int32_t b, int32_t c, int32_t d) {
+  int64_t cx = 0, cy = 0;
+#pragma unroll
+  for (int j = 0; j < M; j++) {
+    const int64_t tx = (int64_t)x[j] * a + (int64_t)y[j] * b + cx;
+    const int64_t ty = (int64_t)x[j] * c + (int64_t)y[j] * d + cy;
+    if (j + 1 < M) {
+      x[j] = (int32_t)((uint32_t)tx & LMASK); y[j] = (int32_t)((uint32_t)ty & LMASK);
+      cx = tx >> LB; cy = ty >> LB;
+    } else {
+      x[j] = (int32_t)tx; y[j] = (int32_t)ty;
+    }
+  }
+}
+
+template <class C>
+MSM_DEV void fe_inv_wordsliced(Fe<C>& out, const Fe<C>& a_in) {
+  constexpr int N = C::NL;
+  Fe<C> a = a_in;
+  fe_reduce_4p<C>(a);   // canonical [0, p)
+  int32_t u[N], v[N], r[N + 1], s[N + 1];
+#pragma unroll
+  for (int i = 0; i < N; i++) { u[i] = (int32_t)C::P[i]; v[i] = (int32_t)a.l[i]; r[i] = 0; s[i] = 0; }
+  r[N] = 0; s[N] = 0;
+  s[0] = 1;
+  int k = 0;
+#pragma unroll 1
+  for (int it = 0; it < 2 * N; it++) {   // the reference's bound: forLoop1(i, 0, 2 n)
+    uint32_t unz = 0, vnz = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { unz |= (uint32_t)u[i]; vnz |= (uint32_t)v[i]; }
+    const bool live = unz != 0 && vnz != 0;   // a == 0: v = 0 from the start, nothing to invert (result 0)
+    if (!fe_any_lane(live)) break;
+    if (!live) continue;
+    const int ulen = fe_ws_bitlen<N>(u), vlen = fe_ws_bitlen<N>(v);
+    int shift = (ulen > vlen ? ulen : vlen) - 63;
+    if (shift < 0) shift = 0;
+    int64_t uhi = fe_ws_hi63<N>(u, shift), vhi = fe_ws_hi63<N>(v, shift);
+    int32_t ulo = u[0], vlo = v[0];
+    int32_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+#pragma unroll 2
+    for (int j = 0; j < LB; j++) {
+      const bool ue = (ulo & 1) == 0, ve = (vlo & 1) == 0;
+      const bool sub_u = !ue && !ve && vhi <= uhi;       // u <- (u - v) / 2
+      const bool sub_v = !ue && !ve && !(vhi <= uhi);    // v <- (v - u) / 2
+      const bool side_u = ue || sub_u;                   // this step halves u (else v)
+      if (side_u) {
+        uhi = (uhi - (sub_u ? vhi : 0)) >> 1;
+        ulo = (ulo - (sub_u ? vlo : 0)) >> 1;
+        f0 += sub_u ? f1 : 0; g0 += sub_u ? g1 : 0;
+        f1 <<= 1; g1 <<= 1;
+      } else {
+        vhi = (vhi - (sub_v ? uhi : 0)) >> 1;
+        vlo = (vlo - (sub_v ? ulo : 0)) >> 1;
+        f1 += sub_v ? f0 : 0; g1 += sub_v ? g0 : 0;
+        f0 <<= 1; g0 <<= 1;
+      }
+    }
+    k += LB;
+    fe_ws_update_uv<N>(u, v, f0, g0, f1, g1);
+    // a comparison decided on the 63-bit approximations can be off: a negative result is negated with its matrix row
+    if (u[N - 1] < 0) { fe_signed_negate<N>(u, -1); f0 = -f0; g0 = -g0; }
+    if (v[N - 1] < 0) { fe_signed_negate<N>(v, -1); f1 = -f1; g1 = -g1; }
+    fe_ws_update_rs<N + 1>(r, s, f0, g0, f1, g1);
+  }
+  // v = 1 (or the input was 0 mod p) and a s = +-2^k.  The last batch kept halving u = 0, i.e. doubling s: `makeOdd`
+  // (faster-inverse-wasm.ts:47-104, faster-inverse.ts:168-176) strips those factors of two again (at most one limb's
+  // worth) and takes them off k; what remains is below p in magnitude.
+  const int32_t sneg = s[N] >> 31;            // a sign flip may leave s negative: work on |s|, negate at the end
+  fe_signed_negate<N + 1>(s, sneg);
+  {
+    const uint32_t lo = (uint32_t)s[0];
+    int tz = 0;
+    for (uint32_t t = lo; tz < LB && !(t & 1u); t >>= 1) tz++;   // lo == 0: a whole limb
+#pragma unroll
+    for (int i = 0; i <= N; i++) {
+      const uint32_t cur = (uint32_t)s[i], nxt = i < N ? (uint32_t)s[i + 1] : 0u;
+      s[i] = tz == LB ? (int32_t)nxt : (int32_t)(((cur >> tz) | (nxt << (LB - tz))) & (i < N ? LMASK : 0xFFFFFFFFu));
+    }
+    k -= tz;
+  }
+  int32_t pp[N + 1];
+#pragma unroll
+  for (int i = 0; i < N; i++) pp[i] = (int32_t)C::P[i];
+  pp[N] = 0;
+  auto sub_p_if_ge = [&]() {
+    int32_t t[N + 1], c = 0;
+#pragma unroll
+    for (int i = 0; i <= N; i++) {
+      int32_t d = s[i] - pp[i] + c;
+      if (i < N) { c = d >> LB; t[i] = d & (int32_t)LMASK; } else { t[i] = d; }
+    }
+    const bool ge = t[N] >= 0;
+#pragma unroll
+    for (int i = 0; i <= N; i++) s[i] = ge ? t[i] : s[i];
+  };
+  sub_p_if_ge();
+  if (sneg) {   // -|s| mod p = p - |s| (|s| != 0: it is invertible)
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i <= N; i++) {
+      int32_t d = pp[i] - s[i] + c;
+      if (i < N) { c = d >> LB; s[i] = d & (int32_t)LMASK; } else { s[i] = d; }
+    }
+  }
+  uint32_t snz = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) snz |= (uint32_t)u[i];
+  const bool zero_in = snz != 0;           // u never reached 0: the input was 0 mod p -> 0, like the other variants
+#pragma unroll 1
+  for (int e = 0; e < 2 * LB * N; e++) {
+    if (!fe_any_lane(k + e < 2 * LB * N)) break;
+    if (k + e >= 2 * LB * N) continue;
+    int32_t c = 0;   // s <- 2 s
+#pragma unroll
+    for (int i = 0; i <= N; i++) {
+      int32_t t = (s[i] << 1) + c;
+      if (i < N) { c = t >> LB; s[i] = t & (int32_t)LMASK; } else { s[i] = t; }
+    }
+    sub_p_if_ge();
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) out.l[i] = zero_in ? 0u : (uint32_t)s[i];
+}
+
 // Division-step inverse (Bernstein-Yang "safegcd", half-delta variant) on signed 30-bit limbs.
 // Plays the role of the reference's Kaliski almost-inverse (src/wasm/inverse.ts:136-218): a binary
 // gcd whose per-step decisions only look at the low bits -- but branch-free, so the 64 lanes of a

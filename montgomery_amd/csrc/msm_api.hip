@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <exception>
 #include <functional>
@@ -904,7 +905,12 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     // Whatever either worker throws (HIP failure, bad_alloc, ...) is re-raised here only after BOTH have stopped and both
     // group streams are idle: no queued kernel of a failed call may still run when the context is used again.
     std::exception_ptr err;
-    if (nthreads > 1) ctx->helper->run([&] { worker(1); });
+    long long stagger_us = 0;
+    MSM_KNOB(stagger_us, "MSM_STAGGER_US", 0);
+    if (nthreads > 1) ctx->helper->run([&, stagger_us] {
+      if (stagger_us) std::this_thread::sleep_for(std::chrono::microseconds(stagger_us));
+      worker(1);
+    });
     try { worker(0); } catch (...) { err = std::current_exception(); }
     if (nthreads > 1) {
       try { ctx->helper->wait(); } catch (...) { if (!err) err = std::current_exception(); }

@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu
 // ---------------------------------------------------------------------------------------------
 
 enum : int { OP_MUL = 0, OP_SQR = 1, OP_ADD = 2, OP_SUB = 3, OP_INV = 4, OP_TO_MONT = 5, OP_FROM_MONT = 6,
-             OP_INV_FERMAT = 7, OP_INV_KALISKI = 8 };
+             OP_INV_FERMAT = 7, OP_INV_KALISKI = 8, OP_INV_WORDSLICED = 9 };
 
 // a, b, out: n x 12 packed words; values are canonical Montgomery form unless the op says otherwise
 template <class CV>
@@ -600,8 +600,9 @@ __global__ void __launch_bounds__(256) k_test_fp(uint32_t* out, const uint32_t* 
     case OP_ADD: fe_add<F>(r, x, y); break;
     case OP_SUB: fe_sub_p<F>(r, x, y); break;
     case OP_INV: fe_inv<F>(r, x); break;
-    case OP_INV_FERMAT: fe_inv_fermat<F>(r, x); break;     // the three inverses of SURVEY section 8(f)-3
+    case OP_INV_FERMAT: fe_inv_fermat<F>(r, x); break;     // the inversion variants of SURVEY section 8(f)-3
     case OP_INV_KALISKI: fe_inv_kaliski<F>(r, x); break;
+    case OP_INV_WORDSLICED: fe_inv_wordsliced<F>(r, x); break;   // src/inverse/faster-inverse-wasm.ts:133-343
     case OP_TO_MONT: {
       Fe<F> r2;
 #pragma unroll

@@ -462,6 +462,7 @@ __global__ void __launch_bounds__(256) k_te_test_fp(uint32_t* out, const uint32_
     case OP_INV: fe_inv<FT>(r, x); break;
     case OP_INV_FERMAT: fe_inv_fermat<FT>(r, x); break;
     case OP_INV_KALISKI: fe_inv_kaliski<FT>(r, x); break;
+    case OP_INV_WORDSLICED: fe_inv_wordsliced<FT>(r, x); break;
     case OP_TO_MONT: {
       Fe<FT> r2;
       TE_CONST(r2, R2);

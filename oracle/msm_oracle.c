@@ -382,32 +382,66 @@ int oracle_msm_bls377(const uint8_t* points, const uint8_t* scalars, uint64_t n,
   aff* sorted = (aff*)malloc(sizeof(aff) * (n2 ? n2 : 1));
   if (!dig || !start || !cursor || !sorted) oom = 1;
   for (int k = 0; k < K && !oom; k++) {
-    /* slice + count (:175-203).  NOTE: digits need the carry of all lower windows. */
+    /* slice + count (:175-203) and scatter (:456-502).  NOTE: digits need the carry of all lower windows.
+     * Each thread counts its own contiguous share of the entries in a PRIVATE histogram and later scatters the same
+     * share from private cursors (a shared histogram bounces its cache lines between 256 threads on two sockets);
+     * windows whose private histograms would not fit fall back to atomic counters, which is fine there because with
+     * that many buckets two threads rarely meet on one. */
     memset(start, 0, (L + 2) * 8);
-#pragma omp parallel for schedule(static) num_threads(nthreads)
-    for (int64_t j = 0; j < (int64_t)n2; j++) {
-      uint32_t carry = 0, l = 0;
-      for (int kk = 0; kk <= k; kk++) {
-        l = bits128(&mags[2 * j], kk * c, c) + carry;
-        if (l > L) { l = (uint32_t)(2 * L - l); carry = 1; } else carry = 0;
+    const int use_local = (uint64_t)nthreads * (L + 2) * 4 <= (1ull << 30);
+    uint32_t* th = use_local ? (uint32_t*)calloc((size_t)nthreads * (L + 2), 4) : NULL;
+    const int local = th != NULL;
+#pragma omp parallel num_threads(nthreads)
+    {
+      int tid = 0, nt = 1;
+#ifdef _OPENMP
+      tid = omp_get_thread_num(); nt = omp_get_num_threads();
+#endif
+      const uint64_t jlo = n2 / nt * tid + (tid < (int)(n2 % nt) ? tid : n2 % nt);
+      const uint64_t jhi = jlo + n2 / nt + (tid < (int)(n2 % nt) ? 1 : 0);
+      uint32_t* mine = local ? th + (size_t)tid * (L + 2) : NULL;
+      for (uint64_t j = jlo; j < jhi; j++) {
+        uint32_t carry = 0, l = 0;
+        for (int kk = 0; kk <= k; kk++) {
+          l = bits128(&mags[2 * j], kk * c, c) + carry;
+          if (l > L) { l = (uint32_t)(2 * L - l); carry = 1; } else carry = 0;
+        }
+        dig[j] = l | (carry << 31);
+        if (l) { if (local) mine[l]++; else __atomic_fetch_add(&start[l + 1], 1, __ATOMIC_RELAXED); }
       }
-      dig[j] = l | (carry << 31);
-      if (l) __atomic_fetch_add(&start[l + 1], 1, __ATOMIC_RELAXED);
+#pragma omp barrier
+      if (local) {   /* bucket totals, bucket by bucket in parallel */
+#pragma omp for schedule(static)
+        for (int64_t l = 1; l <= (int64_t)L; l++) {
+          uint64_t tot = 0;
+          for (int t2 = 0; t2 < nt; t2++) tot += th[(size_t)t2 * (L + 2) + l];
+          start[l + 1] = tot;
+        }
+      }
+#pragma omp single
+      {
+        /* integrate (:423-447): start[l] = first slot of bucket l, start[L+1] = total */
+        for (uint64_t l = 1; l <= L + 1; l++) start[l] += start[l - 1];
+        memcpy(cursor, start, 8 * (L + 2));
+      }
+      if (local) {   /* private cursors: bucket start + what the threads before this one put there */
+#pragma omp for schedule(static)
+        for (int64_t l = 1; l <= (int64_t)L; l++) {
+          uint32_t run = 0;
+          for (int t2 = 0; t2 < nt; t2++) { uint32_t v = th[(size_t)t2 * (L + 2) + l]; th[(size_t)t2 * (L + 2) + l] = run; run += v; }
+        }
+      }
+      for (uint64_t j = jlo; j < jhi; j++) {
+        uint32_t l = dig[j] & 0x7fffffffu;
+        if (!l) continue;
+        aff a = pts[j];
+        if (dig[j] >> 31) fe_neg(&a.y, &a.y);
+        uint64_t pos = local ? start[l] + mine[l]++ : __atomic_fetch_add(&cursor[l], 1, __ATOMIC_RELAXED);
+        sorted[pos] = a;
+      }
     }
-    /* integrate (:423-447): start[l] = first slot of bucket l, start[L+1] = total */
-    for (uint64_t l = 1; l <= L + 1; l++) start[l] += start[l - 1];
+    free(th);
     const uint64_t total = start[L + 1];
-    /* scatter (:456-502): copy points (or their negation) into bucket order; the order inside a bucket is whatever the
-     * threads' cursor increments make it -- the bucket sum does not depend on it */
-    memcpy(cursor, start, 8 * (L + 2));
-#pragma omp parallel for schedule(static) num_threads(nthreads)
-    for (int64_t j = 0; j < (int64_t)n2; j++) {
-      uint32_t l = dig[j] & 0x7fffffffu;
-      if (!l) continue;
-      aff a = pts[j];
-      if (dig[j] >> 31) fe_neg(&a.y, &a.y);
-      sorted[__atomic_fetch_add(&cursor[l], 1, __ATOMIC_RELAXED)] = a;
-    }
     /* accumulation rounds (:243-282) and bucket reduction (:556-583): buckets [lo, hi] per thread, equal shares of the
      * sorted entries; every thread builds its own pair lists and shares one inversion per round among them */
     proj* tsum = (proj*)malloc(sizeof(proj) * nthreads);

@@ -478,6 +478,54 @@ _WINDOW_TABLE = {  # src/msm-common.ts:25-41
 }
 
 
+def almost_inverse_wordsliced(a: int, p: int, w: int, n: int, hi_bits: int = 63) -> Tuple[int, int, bool]:
+    """The reference's experimental word-sliced almost-inverse, src/inverse/faster-inverse.ts:78-177 (wasm twin:
+    src/inverse/faster-inverse-wasm.ts:133-343): Kaliski's binary gcd with w steps at a time decided on the low words
+    and on `hi_bits`-bit approximations of the high ends, applied to the full values as a 2x2 matrix.
+    Returns (s, k, sign_flip) with a * s = 2^k (mod p), 0 <= |s| < p after the final `makeOdd` step."""
+    u, v, r, s, k = p, a, 0, 1, 0
+    flip = False
+    for _ in range(2 * n):
+        f0, g0, f1, g1 = 1, 0, 0, 1
+        ulo, vlo = u & ((1 << w) - 1), v & ((1 << w) - 1)
+        shift = max(max(u.bit_length(), v.bit_length()) - hi_bits, 0)
+        uhi, vhi = u >> shift, v >> shift
+        for _ in range(w):
+            if ulo & 1 == 0:
+                uhi >>= 1; ulo >>= 1; f1 <<= 1; g1 <<= 1
+            elif vlo & 1 == 0:
+                vhi >>= 1; vlo >>= 1; f0 <<= 1; g0 <<= 1
+            else:
+                mhi = vhi - uhi
+                if mhi <= 0:
+                    uhi = -mhi >> 1; ulo = (ulo - vlo) >> 1
+                    f0 += f1; g0 += g1; f1 <<= 1; g1 <<= 1
+                else:
+                    vhi = mhi >> 1; vlo = (vlo - ulo) >> 1
+                    f1 += f0; g1 += g0; f0 <<= 1; g0 <<= 1
+            k += 1
+        unew, vnew = u * f0 - v * g0, v * g1 - u * f1
+        assert unew & ((1 << w) - 1) == 0 and vnew & ((1 << w) - 1) == 0
+        u, v = unew >> w, vnew >> w
+        if u < 0:
+            flip = True
+            u, f0, g0 = -u, -f0, -g0
+        if v < 0:
+            flip = True
+            v, f1, g1 = -v, -f1, -g1
+        r, s = r * f0 + s * g0, r * f1 + s * g1
+        if u == 0:
+            break
+        if v == 0:
+            raise ValueError("v = 0: the input is not invertible")
+    i = 0
+    while i < w and s & 1 == 0:   # makeOdd: the last batch kept doubling s after u had reached 0
+        s >>= 1
+        k -= 1
+        i += 1
+    return s, k, flip
+
+
 def window_size_reference(field_bits: int, n: int) -> int:
     """`windowSize`, src/msm-common.ts:8-13."""
     table = _WINDOW_TABLE["large" if field_bits > 260 else "small"]

@@ -31,6 +31,7 @@ static void op(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     case 4: fe_inv<C>(r, x); break;
     case 5: fe_inv_fermat<C>(r, x); break;
     case 6: fe_inv_kaliski<C>(r, x); break;
+    case 7: fe_inv_wordsliced<C>(r, x); break;
     default: r = x;
   }
   store<C>(out, r);

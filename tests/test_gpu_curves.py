@@ -91,6 +91,7 @@ def test_fp_operators_and_inverse(cv):
     inv = ctx.test_fp(_lib.OP_INV, mont)
     assert ctx.test_fp(_lib.OP_INV_FERMAT, mont[: 48 * 64]) == inv[: 48 * 64]
     assert ctx.test_fp(_lib.OP_INV_KALISKI, mont[: 48 * 64]) == inv[: 48 * 64]
+    assert ctx.test_fp(_lib.OP_INV_WORDSLICED, mont[: 48 * 64]) == inv[: 48 * 64]
     for per_lane in (1, 7, 100):
         out = ctx.test_fp(_lib.OP_FROM_MONT, ctx.test_batch_inverse(mont[: 48 * 203], per_lane))
         assert all(fb(out, i) == pow(v, -1, p) for i, v in enumerate(nz[:203])), per_lane

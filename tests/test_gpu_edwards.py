@@ -65,6 +65,7 @@ def test_fp253_operators(ed_ctx):
         assert ed_ctx.test_batch_inverse(mont, per_lane) == inv, per_lane
     assert ed_ctx.test_fp(_lib.OP_INV_FERMAT, mont[: 32 * 64]) == inv[: 32 * 64]
     assert ed_ctx.test_fp(_lib.OP_INV_KALISKI, mont[: 32 * 64]) == inv[: 32 * 64]
+    assert ed_ctx.test_fp(_lib.OP_INV_WORDSLICED, mont[: 32 * 64]) == inv[: 32 * 64]
 
 
 def test_unified_addition_operator(ed_ctx):

@@ -107,6 +107,8 @@ def test_fp_inverse_variants_agree(gpu_ctx):
     ref = gpu_ctx.test_fp(_lib.OP_INV, mont)
     assert gpu_ctx.test_fp(_lib.OP_INV_FERMAT, mont) == ref
     assert gpu_ctx.test_fp(_lib.OP_INV_KALISKI, mont) == ref
+    # fourth variant: the reference's experimental word-sliced almost-inverse, src/inverse/faster-inverse-wasm.ts:133-343
+    assert gpu_ctx.test_fp(_lib.OP_INV_WORDSLICED, mont) == ref
     back = gpu_ctx.test_fp(_lib.OP_FROM_MONT, ref)
     assert all(fb(back, i) == pow(v, -1, P_MOD) for i, v in enumerate(vals))
 

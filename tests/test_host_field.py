@@ -68,7 +68,10 @@ def test_inverse_divsteps_fermat_kaliski(lib, field):
     # the reference's own algorithm, Kaliski's almost-inverse (src/wasm/inverse.ts:136-218), as the third variant
     for a in vals[:120]:
         assert fp_op(lib, field, 6, a % p) == pow(a % p, -1, p) * R * R % p, hex(a)
-    assert fp_op(lib, field, 4, 0) == 0 and fp_op(lib, field, 6, 0) == 0
+    # the reference's experimental word-sliced almost-inverse (src/inverse/faster-inverse-wasm.ts:133-343), fourth variant
+    for a in vals[:200] + [p - 1, 1, 2, (1 << 117) - 1, (1 << (p.bit_length() - 1)) + 1]:
+        assert fp_op(lib, field, 7, a % p) == pow(a % p, -1, p) * R * R % p, hex(a)
+    assert fp_op(lib, field, 4, 0) == 0 and fp_op(lib, field, 6, 0) == 0 and fp_op(lib, field, 7, 0) == 0
 
 
 @pytest.mark.parametrize("curve", [0, 2, 3])

@@ -266,3 +266,18 @@ def test_golden_extra_curves(name, gold):
         pts = [None if P == (0, 0) else P for P in O.points_from_bytes(bytes.fromhex(c["points"]), 48)]
         exp = None if c["result"] is None else (H(c["result"][0]), H(c["result"][1]))
         assert O.msm_batched_affine(sc, pts, B, c=c["c"]) == exp, c["name"]
+
+
+def test_wordsliced_almost_inverse_restatement():
+    """src/inverse/faster-inverse.ts:55-60 asserts, on random field elements: k + 1 >= b and k <= 2 n w, s < p,
+    x s = 2^k (mod p).  Same assertions on the restatement, for the reference's own configuration (Pallas, w = 32) and
+    for the limb sizes the GPU variant uses (w = 30: 13 limbs for the 377-bit prime, 9 for the 253-bit one)."""
+    for p, w in ((O.PALLAS.p, 32), (O.BLS12_377.p, 30), (O.ED_ON_BLS12_377.p, 30), (O.BLS12_381.p, 30)):
+        b = p.bit_length()
+        n = -(-b // w)
+        for x in O.prng_ints(f"kat/ws/{w}/{b}", 200, p - 1):
+            x += 1
+            s, k, _ = O.almost_inverse_wordsliced(x, p, w, n)
+            assert k + 1 >= b and k <= 2 * n * w
+            assert abs(s) < p
+            assert (x * s - (1 << k)) % p == 0

@@ -1,7 +1,7 @@
 """Copies the judged summaries of one profiling run (gpurun_out/prof_<tag>/) into profiles/ (tracked)."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 for name, dst in (("trace26", f"{tag}_kernel_stats_2p26.csv"), ("trace20", f"{tag}_kernel_stats_2p20.csv"), ("trace_ed20", f"{tag}_kernel_stats_ed377_2p20.csv")):
@@ -9,7 +9,7 @@ for name, dst in (("trace26", f"{tag}_kernel_stats_2p26.csv"), ("trace20", f"{ta
     if f:
         shutil.copy(f[0], f"profiles/{dst}")
 for name in ("bench_2p26.json", "bench_2p20.json", "bench_ed377_2p20.json", "bench_bls381_2p26.json", "bench_bls381_2p20.json",
-             "ubench_exec.txt", "ubench_occ.txt", "ubench_bt.txt", "ubench_inv.txt"):
+             "ubench_exec.txt", "ubench_occ.txt", "ubench_bt.txt", "ubench_inv.txt", "ubench_int2.txt", "cpu_baseline.json"):
     if os.path.exists(f"{src}/{name}"):
         shutil.copy(f"{src}/{name}", f"profiles/{tag}_{name}")
 out = {}
@@ -26,7 +26,7 @@ for kind in ("fetch", "write", "sq", "grbm"):
     for k in agg:
         agg[k]["launches"] = len(agg[k]["launches"])
     out[kind] = agg
-json.dump({"command": "rocprofv3 --pmc <counters> (one pass per group: FETCH_SIZE | WRITE_SIZE | SQ_* | GRBM_GUI_ACTIVE) -- python3 bench.py --steps 1 --warmup 0 --log2n 24 --no-cpu-baseline",
+json.dump({"command": "rocprofv3 --pmc <counters> (one pass per group: FETCH_SIZE | WRITE_SIZE | SQ_* | GRBM_GUI_ACTIVE) -- python3 bench.py --steps 1 --warmup 0 --log2n 24 --no-cpu-baseline --no-verify (the run holds TWO MSMs: the timed step and the serialised one)",
            "note": "FETCH_SIZE / WRITE_SIZE in KB as reported; gfx950 halves FETCH_SIZE on wide coalesced reads (MI355X_MICROARCH.md). SQ_* cycle counters are in quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs.",
            "counters": out}, open(f"profiles/{tag}_pmc_2p24.json", "w"), indent=1)
 print("collected", tag)

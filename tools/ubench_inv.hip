@@ -1,5 +1,6 @@
-// The three field inversions on the GPU: division steps (fe_inv, the product's), Fermat
-// (a^(p-2)) and Kaliski's almost-inverse (the reference's algorithm, src/wasm/inverse.ts:136-218), each as a chain of
+// The four field inversions on the GPU: division steps (fe_inv, the product's), Fermat
+// (a^(p-2)), Kaliski's almost-inverse (the reference's algorithm, src/wasm/inverse.ts:136-218) and the reference's
+// experimental word-sliced almost-inverse (src/inverse/faster-inverse-wasm.ts:133-343), each as a chain of
 // dependent inversions: latency for a lone wave and throughput with every SIMD holding two waves.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -16,6 +17,7 @@ __global__ void __launch_bounds__(256) k_inv(uint32_t* out) {
     if (WHICH == 0) fe_inv<F>(r, x);
     if (WHICH == 1) fe_inv_fermat<F>(r, x);
     if (WHICH == 2) fe_inv_kaliski<F>(r, x);
+    if (WHICH == 3) fe_inv_wordsliced<F>(r, x);
     for (int i = 0; i < F::NL; i++) x.l[i] = r.l[i] ^ (uint32_t)it;
     fe_reduce_4p<F>(x);
   }
@@ -26,8 +28,8 @@ __global__ void __launch_bounds__(256) k_inv(uint32_t* out) {
 template <class F>
 void run(const char* field, uint32_t* out) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const char* names[] = {"division steps", "Fermat", "Kaliski"};
-  for (int which = 0; which < 3; which++)
+  const char* names[] = {"division steps", "Fermat", "Kaliski", "word-sliced"};
+  for (int which = 0; which < 4; which++)
     for (int cfg = 0; cfg < 2; cfg++) {
       const int blocks = cfg ? 2048 : 1, threads = cfg ? 256 : 64;
       float ms = 0;
@@ -36,6 +38,7 @@ void run(const char* field, uint32_t* out) {
         if (which == 0) k_inv<F, 0><<<blocks, threads>>>(out);
         if (which == 1) k_inv<F, 1><<<blocks, threads>>>(out);
         if (which == 2) k_inv<F, 2><<<blocks, threads>>>(out);
+        if (which == 3) k_inv<F, 3><<<blocks, threads>>>(out);
         hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
       }
