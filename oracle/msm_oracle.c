@@ -336,6 +336,9 @@ int oracle_msm_bls377(const uint8_t* points, const uint8_t* scalars, uint64_t n,
   int nthreads = 1;
 #ifdef _OPENMP
   nthreads = omp_get_max_threads();
+  /* one thread per physical core: with both SMT siblings of every core spinning in libgomp's barriers the 2^18 case ran
+   * 40x slower than on half as many threads (256 logical CPUs, 128 cores on the MI355X host) */
+  { int half = omp_get_num_procs() / 2; if (half >= 8 && nthreads > half) nthreads = half; }
   /* small inputs: a parallel region over 128 threads costs more than the work it splits (K windows x 4 regions each) */
   { uint64_t useful = n2 / 2048 + 1; if ((uint64_t)nthreads > useful) nthreads = (int)useful; }
 #endif
