@@ -406,11 +406,23 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
 
   // sort path: LDS-privatised histogram/ranking.  One level when a window's counters fit the LDS (c <= 16), two
   // levels (coarse bins of 2^15 buckets, then the same LDS sort per bin) up to c = 24, the largest window make_plan accepts.
-  const bool one_level = (size_t)L * 4 <= 128 * 1024;
-  const bool two_level = !one_level;
-  const uint32_t shift = two_level ? (uint32_t)(pl.c - 1 - 15) : 0;   // low bits kept for the second level
+  // Sort path: LDS-privatised histogram / ranking.
+  //   one level  : a window's counters fit the LDS (c <= 16) and the input is small
+  //   radix split: c <= 16, big inputs -- 2^(c-8) coarse bins x 128 buckets, both passes staged through the LDS so that
+  //                every wave store is a full segment (sort_kernels.h); the one-level scatter there sends each 4-byte
+  //                payload to a line of its own (round 1: 7.7x the algorithmic bytes written)
+  //   two levels : c > 16 (coarse bins of 2^15 buckets, then the LDS sort per bin), up to c = 24, the largest window
+  //                make_plan accepts
+  const bool fits_lds = (size_t)L * 4 <= 128 * 1024;
+  long long want_radix = (fits_lds && pl.c - 1 > (int)RX_FINE_BITS && two_n >= (1ull << 22)) ? 1 : 0;   // measured: wins from N = 2^21 up
+  MSM_KNOB(want_radix, "MSM_RADIX", 0);
+  const bool radix = fits_lds && want_radix && pl.c - 1 > (int)RX_FINE_BITS && pl.c - 1 - (int)RX_FINE_BITS <= 8;
+  const bool one_level = fits_lds && !radix;
+  const bool two_level = !fits_lds;
+  const uint32_t fine_bits = two_level ? 15u : radix ? RX_FINE_BITS : 0u;   // bucket bits sorted by the second pass
+  const uint32_t shift = (two_level || radix) ? (uint32_t)(pl.c - 1) - fine_bits : 0;   // = log2 of the coarse bins
   const uint32_t Hn = 1u << shift;                                    // coarse bins per window
-  const uint32_t L2 = two_level ? 32768u : L;                         // buckets per (virtual) window
+  const uint32_t L2 = two_level ? (1u << fine_bits) : L;              // buckets per (virtual) window of the old two-level path
   const uint32_t V = (uint32_t)kc * Hn;                               // virtual windows
   uint32_t sortB = 1;
   uint64_t chunk = two_n;
@@ -423,7 +435,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     uint64_t maxb = std::max<uint64_t>(1, two_n / 8192);
     sortB = (uint32_t)std::min<uint64_t>(want, maxb);
     chunk = (two_n + sortB - 1) / sortB;
-    ctx->ensure(w.block_hist, (size_t)kc * sortB * (two_level ? Hn : L) * 4);
+    ctx->ensure(w.block_hist, (size_t)kc * sortB * (two_level ? Hn : L) * 4 + 64);
   }
   uint64_t chunk2 = 0;      // second level: entries per block, number of active blocks
   uint32_t n_active2 = 0;
@@ -439,9 +451,9 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
                          pl.no_glv ? 0 : 1, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p);
   }
   HIPCHK(hipEventRecord(w.ev[1], s));
-  if (one_level) {
+  if (one_level || radix) {
     hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.block_hist.p,
-                       (const uint32_t*)w.dig.p, two_n, chunk, L, 0u, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                       (const uint32_t*)w.dig.p, two_n, chunk, L, 0u, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
     hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.block_hist.p,
                        (uint32_t*)w.counts.p, sortB, L, (uint32_t)kc, (const uint32_t*)nullptr);
   } else {
@@ -450,7 +462,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     uint32_t* d_cnt = (uint32_t*)w.part.p;            // V coarse counts
     uint32_t* d_part = (uint32_t*)w.part.p + V;       // V + 1 partition starts
     hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)Hn * 4, s, (uint32_t*)w.block_hist.p,
-                       (const uint32_t*)w.dig.p, two_n, chunk, Hn, 15u, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                       (const uint32_t*)w.dig.p, two_n, chunk, Hn, fine_bits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
     hipLaunchKernelGGL(k_colscan, dim3((V + 255) / 256), dim3(256), 0, s, (uint32_t*)w.block_hist.p, d_cnt, sortB, Hn,
                        (uint32_t)kc, (const uint32_t*)nullptr);
     std::vector<uint32_t> h_cnt(V), h_part(V + 1);
@@ -483,13 +495,13 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     ctx->ensure(w.idx2, std::max<uint64_t>(run, 1) * 4);
     hipLaunchKernelGGL(k_scatter_coarse, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)Hn * 4, s, (uint32_t*)w.dig2.p,
                        (uint32_t*)w.idx2.p, (const uint32_t*)d_part, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p,
-                       two_n, chunk, Hn, 15u);
-    // level 2: LDS sort of every coarse bin (a "virtual window" of 2^15 buckets)
+                       two_n, chunk, Hn, fine_bits, 0u);
+    // level 2: LDS sort of every coarse bin (a "virtual window" of 2^fine_bits buckets)
     ctx->ensure(w.block_hist2, (size_t)std::max<uint32_t>(nrows, 1) * L2 * 4);
     HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));
     if (nrows)
       hipLaunchKernelGGL(k_hist, dim3(nrows), dim3(SORT_THREADS), (size_t)L2 * 4, s, (uint32_t*)w.block_hist2.p,
-                         (const uint32_t*)w.dig2.p, (uint64_t)0, chunk2, L2, 0u, (const uint32_t*)d_part, (const uint32_t*)d_tab);
+                         (const uint32_t*)w.dig2.p, (uint64_t)0, chunk2, L2, 0u, (const uint32_t*)d_part, (const uint32_t*)d_tab, 0u);
     hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.block_hist2.p,
                        (uint32_t*)w.counts.p, 0u, L2, V, (const uint32_t*)d_rows);
     HIPCHK(hipStreamSynchronize(s));   // host tables must outlive their copies
@@ -526,14 +538,30 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   // scatter
   ctx->ensure(w.slots, std::max<uint64_t>(total_slots, 2) * 4);
   HIPCHK(hipMemsetAsync(w.slots.p, 0xFF, std::max<uint64_t>(total_slots, 2) * 4, s));
-  if (one_level) {
+  if (radix) {
+    // pass A: coarse split into dig2 / idx2; pass B: one block per virtual window, payloads to their padded slots
+    ctx->ensure(w.part, ((size_t)kc * sortB * Hn + 2 * (size_t)V + 2) * 4);
+    uint32_t* d_blk_off = (uint32_t*)w.part.p;
+    uint32_t* d_vtot = d_blk_off + (size_t)kc * sortB * Hn;
+    uint32_t* d_vstart = d_vtot + V;
+    ctx->ensure(w.dig2, n_entries * 4);
+    ctx->ensure(w.idx2, n_entries * 4);
+    const uint64_t co = (uint64_t)kc * (sortB + 1) * Hn;
+    hipLaunchKernelGGL(k_coarse_offsets, dim3((uint32_t)((co + 255) / 256)), dim3(256), 0, s, d_blk_off, d_vtot,
+                       (const uint32_t*)w.block_hist.p, (const uint32_t*)w.counts.p, sortB, L, Hn, (uint32_t)kc);
+    hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_vstart, (const uint32_t*)d_vtot, V);
+    hipLaunchKernelGGL(k_radix_coarse, dim3(sortB, kc), dim3(RX_THREADS), 0, s, (uint32_t*)w.dig2.p, (uint32_t*)w.idx2.p,
+                       (const uint32_t*)d_vstart, (const uint32_t*)d_blk_off, (const uint32_t*)w.dig.p, two_n, chunk, Hn, shift);
+    hipLaunchKernelGGL(k_radix_fine, dim3(V), dim3(RX_THREADS), 0, s, (uint32_t*)w.slots.p, (const uint32_t*)w.cursor.p,
+                       (const uint32_t*)d_vstart, (const uint32_t*)w.dig2.p, (const uint32_t*)w.idx2.p, V);
+  } else if (one_level) {
     hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.slots.p,
                        (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n,
-                       chunk, L, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                       chunk, L, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
   } else if (n_active2) {
     hipLaunchKernelGGL(k_scatter_lds, dim3(n_active2), dim3(SORT_THREADS), (size_t)L2 * 4, s, (uint32_t*)w.slots.p,
                        (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist2.p, (const uint32_t*)w.dig2.p, (uint64_t)0,
-                       chunk2, L2, (const uint32_t*)w.part.p + V, (const uint32_t*)w.idx2.p, (const uint32_t*)w.blk_tab.p);
+                       chunk2, L2, (const uint32_t*)w.part.p + V, (const uint32_t*)w.idx2.p, (const uint32_t*)w.blk_tab.p, 0u);
   }
   HIPCHK(hipEventRecord(w.ev[2], s));
 

@@ -164,6 +164,28 @@ __global__ void __launch_bounds__(256) k_tail_desc(uint32_t* desc, const uint32_
 
 constexpr int SORT_THREADS = 1024;
 
+// Ranking with few bins (<= 256, `bits` = log2 of their number): the 64 lanes of a wave then mostly hit the same LDS
+// counters and per-lane atomics serialise (round 1 measured the 128-bin pass slower than the 32768-bin one for exactly
+// this reason).  Here the lanes of a wave that share a bin find each other with one ballot per bin bit, the lowest of
+// them adds the group's size with ONE atomic, and every lane gets (old counter + its rank inside the group).
+// bits == 0: plain per-lane atomic.  Must be called by all lanes of the wave (valid = has an entry).
+__device__ __forceinline__ uint32_t lds_rank_add(uint32_t* lds, uint32_t bin, bool valid, uint32_t bits) {
+  if (bits == 0) return valid ? atomicAdd(&lds[bin], 1u) : 0u;
+  uint64_t peers = __ballot(valid);
+  for (uint32_t b = 0; b < bits; b++) {
+    const bool bit = (bin >> b) & 1u;
+    const uint64_t m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+  uint32_t base = 0;
+  if (valid && rank == 0) base = atomicAdd(&lds[bin], (uint32_t)__popcll(peers));
+  const int leader = valid ? __ffsll((long long)peers) - 1 : 0;
+  base = __shfl(base, leader, 64);
+  return base + rank;
+}
+
 // part_start == nullptr: window kk owns digits dig[kk * two_n ..) and block b the slice [b * chunk, (b+1) * chunk).
 // part_start != nullptr (second level of the two-level sort): "window" kk is the partition
 // [part_start[kk], part_start[kk + 1]) of a flat digit array.  bin = (l - 1) >> shift (shift > 0: coarse level).
@@ -171,7 +193,7 @@ constexpr int SORT_THREADS = 1024;
 // (kk, b, first histogram row of kk); partitions differ 50x in size, idle blocks would dominate otherwise.
 __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, const uint32_t* dig, uint64_t two_n,
                                                        uint64_t chunk, uint32_t L, uint32_t shift,
-                                                       const uint32_t* part_start, const uint32_t* blk_tab) {
+                                                       const uint32_t* part_start, const uint32_t* blk_tab, uint32_t agg_bits) {
   extern __shared__ uint32_t lds_hist[];
   uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
   uint64_t hist_row = (uint64_t)kk * B + b;
@@ -193,9 +215,10 @@ __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, con
     end = min(beg + chunk, two_n);
     d = dig + (uint64_t)kk * two_n;
   }
-  for (uint64_t j = beg + threadIdx.x; j < end; j += SORT_THREADS) {
-    uint32_t l = d[j] & 0x7FFFFFFFu;
-    if (l) atomicAdd(&lds_hist[(l - 1) >> shift], 1u);
+  for (uint64_t j0 = beg; j0 < end; j0 += SORT_THREADS) {   // whole waves stay in the loop (lds_rank_add ballots)
+    const uint64_t j = j0 + threadIdx.x;
+    const uint32_t l = j < end ? d[j] & 0x7FFFFFFFu : 0u;
+    (void)lds_rank_add(lds_hist, l ? (l - 1) >> shift : 0u, l != 0, agg_bits);
   }
   __syncthreads();
   uint32_t* out = block_hist + hist_row * L;
@@ -226,7 +249,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(uint32_t* slots, c
                                                               const uint32_t* block_hist, const uint32_t* dig,
                                                               uint64_t two_n, uint64_t chunk, uint32_t L,
                                                               const uint32_t* part_start, const uint32_t* idx,
-                                                              const uint32_t* blk_tab) {
+                                                              const uint32_t* blk_tab, uint32_t agg_bits) {
   extern __shared__ uint32_t lds_pos[];
   uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
   uint64_t hist_row = (uint64_t)kk * B + b;
@@ -250,25 +273,196 @@ __global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(uint32_t* slots, c
     end = min(beg + chunk, two_n);
     d = dig + (uint64_t)kk * two_n;
   }
-  for (uint64_t j = beg + threadIdx.x; j < end; j += SORT_THREADS) {
-    uint32_t v = d[j];
-    uint32_t l = v & 0x7FFFFFFFu;
+  for (uint64_t j0 = beg; j0 < end; j0 += SORT_THREADS) {
+    const uint64_t j = j0 + threadIdx.x;
+    const uint32_t v = j < end ? d[j] : 0u;
+    const uint32_t l = v & 0x7FFFFFFFu;
+    const uint32_t pos = lds_rank_add(lds_pos, l ? l - 1 : 0u, l != 0, agg_bits);
     if (l) {
-      uint32_t pos = atomicAdd(&lds_pos[l - 1], 1u);
       uint32_t entry = idx ? idx[j] : (uint32_t)j;
       slots[pos] = (entry << 1) | (v >> 31);
     }
   }
 }
 
-// First level of the two-level sort (windows with more than 2^15 buckets, c > 16): entries of window kk are
-// partitioned by the high bits of their bucket index into Hn = L >> 15 coarse bins (k_hist with shift = 15 and
+// ---------------------------------------------------------------------------------------------
+// LDS-staged radix split (big inputs at c <= 16; replaces the one-level scatter there).
+//
+// Why: the scatter is bound by the NUMBER of store requests, not by bytes -- a wave of the one-level kernel sends its
+// 64 four-byte payloads to ~64 different cache lines, and ~5 x 10^10 such partial-line stores per second is what the
+// memory system takes (round 1: 7.7x the algorithmic bytes written).  Here every block first sorts a tile of its entries
+// by bin INSIDE the LDS and then copies the tile out with consecutive lanes on consecutive addresses, so a wave store is
+// one or two full segments.  Two passes keep the runs long: pass A splits a window's 2^(c-1) buckets into 2^(c-8) coarse
+// bins (runs of ~32 entries per tile and bin in two 4-byte arrays), pass B sorts every coarse bin by its 128 buckets
+// (runs of ~64 payloads).
+//   k_hist (L bins) + k_colscan : as in the one-level sort -- bucket totals `counts` and, per block, the exclusive
+//                                 prefix over blocks of every bucket (block_hist, in place)
+//   k_coarse_offsets            : per (window, block, coarse bin) the block's first position inside the bin's range,
+//                                 = sum over the bin's 128 buckets of that prefix; per virtual window v = (window, bin)
+//                                 its total
+//   k_vscan                     : exclusive scan of the V totals -> v_start[V + 1]
+//   k_radix_coarse              : pass A, records (fine digit | sign, entry index) -> dig2, idx2
+//   k_radix_fine                : pass B, ONE block per virtual window walks its range tile by tile with running
+//                                 per-bucket cursors in the LDS (no second histogram), payloads -> slots
+// ---------------------------------------------------------------------------------------------
+
+constexpr int RX_THREADS = 1024;
+constexpr int RXA_ITEMS = 7, RXA_TILE = RX_THREADS * RXA_ITEMS;    // pass A: 7168 records of 8 bytes staged per tile (56 KB)
+constexpr int RXB_ITEMS = 12, RXB_TILE = RX_THREADS * RXB_ITEMS;   // pass B: 12288 payloads + bucket bytes (60 KB)
+constexpr uint32_t RX_FINE_BITS = 7;
+
+// exclusive scan of `nbins` (<= 256) LDS counters by the first 256 threads; `tot` counters become `start`
+__device__ __forceinline__ void rx_scan_bins(uint32_t* start, const uint32_t* cnt, uint32_t nbins, uint32_t* lds_wave) {
+  uint32_t v = threadIdx.x < nbins ? cnt[threadIdx.x] : 0u, tot;
+  uint32_t ex = block_excl_scan(v, lds_wave, tot);
+  if (threadIdx.x < nbins) start[threadIdx.x] = ex;
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_coarse_offsets(uint32_t* blk_off, uint32_t* v_tot, const uint32_t* block_hist,
+                                                        const uint32_t* counts, uint32_t B, uint32_t L, uint32_t Hn, uint32_t kc) {
+  // one thread per (kk, b, h): b == B is the extra row that produces the totals from `counts`
+  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t total = (uint64_t)kc * (B + 1) * Hn;
+  if (id >= total) return;
+  const uint32_t h = (uint32_t)(id % Hn);
+  const uint32_t b = (uint32_t)((id / Hn) % (B + 1));
+  const uint32_t kk = (uint32_t)(id / ((uint64_t)Hn * (B + 1)));
+  const uint32_t fine = L / Hn;
+  const uint32_t* src = (b == B) ? counts + (uint64_t)kk * L + (uint64_t)h * fine
+                                 : block_hist + ((uint64_t)kk * B + b) * L + (uint64_t)h * fine;
+  uint32_t sum = 0;
+  for (uint32_t i = 0; i < fine; i += 4) {
+    const uint4 q = *reinterpret_cast<const uint4*>(src + i);
+    sum += q.x + q.y + q.z + q.w;
+  }
+  if (b == B) v_tot[(uint64_t)kk * Hn + h] = sum;
+  else blk_off[((uint64_t)kk * B + b) * Hn + h] = sum;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_vscan(uint32_t* v_start, const uint32_t* v_tot, uint32_t V) {
+  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < V; base += SCAN_THREADS) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < V ? v_tot[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(v, lds_wave, tot) + carry;
+    if (i < V) v_start[i] = ex;
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) v_start[V] = carry;
+}
+
+// pass A.  grid (B, kc); block (b, kk) owns entries [b * chunk, (b + 1) * chunk) of window kk.
+__global__ void __launch_bounds__(RX_THREADS) k_radix_coarse(uint32_t* dig2, uint32_t* idx2, const uint32_t* v_start,
+                                                             const uint32_t* blk_off, const uint32_t* dig, uint64_t two_n,
+                                                             uint64_t chunk, uint32_t Hn, uint32_t hbits) {
+  __shared__ uint2 stage[RXA_TILE];
+  __shared__ uint32_t t_cnt[256], t_start[256], g_base[256], lds_wave[RX_THREADS / 64];
+  const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x, tid = threadIdx.x;
+  if (tid < Hn) g_base[tid] = v_start[(uint64_t)kk * Hn + tid] + blk_off[((uint64_t)kk * B + b) * Hn + tid];
+  const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
+  const uint32_t* d = dig + (uint64_t)kk * two_n;
+  const uint32_t lo_mask = (1u << RX_FINE_BITS) - 1;
+  for (uint64_t t0 = beg; t0 < end; t0 += RXA_TILE) {
+    if (tid < 256) t_cnt[tid] = 0;
+    __syncthreads();
+    uint32_t v[RXA_ITEMS], rk[RXA_ITEMS];
+#pragma unroll
+    for (int i = 0; i < RXA_ITEMS; i++) {
+      const uint64_t j = t0 + (uint64_t)i * RX_THREADS + tid;
+      v[i] = j < end ? d[j] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < RXA_ITEMS; i++) {
+      const uint32_t l = v[i] & 0x7FFFFFFFu;
+      rk[i] = lds_rank_add(t_cnt, l ? (l - 1) >> RX_FINE_BITS : 0u, l != 0, hbits);
+    }
+    __syncthreads();
+    rx_scan_bins(t_start, t_cnt, Hn, lds_wave);
+#pragma unroll
+    for (int i = 0; i < RXA_ITEMS; i++) {
+      const uint32_t l = v[i] & 0x7FFFFFFFu;
+      if (l) {
+        const uint32_t h = (l - 1) >> RX_FINE_BITS;
+        // record: fine digit + 1 (so 0 still means "no entry") | coarse bin << 16 (stripped on the way out) | sign
+        stage[t_start[h] + rk[i]] = make_uint2((((l - 1) & lo_mask) + 1) | (h << 16) | (v[i] & 0x80000000u),
+                                               (uint32_t)(t0 + (uint64_t)i * RX_THREADS + tid));
+      }
+    }
+    __syncthreads();
+    const uint32_t n_tile = t_start[Hn - 1] + t_cnt[Hn - 1];
+    for (uint32_t i = tid; i < n_tile; i += RX_THREADS) {
+      const uint2 r = stage[i];
+      const uint32_t h = (r.x >> 16) & 0xFFu;
+      const uint32_t pos = g_base[h] + (i - t_start[h]);
+      dig2[pos] = r.x & 0x8000FFFFu;
+      idx2[pos] = r.y;
+    }
+    __syncthreads();
+    if (tid < Hn) g_base[tid] += t_cnt[tid];
+  }
+}
+
+// pass B.  One block per virtual window v (heaviest -- the top window's few coarse bins -- first: v = V - 1 - blockIdx.x).
+__global__ void __launch_bounds__(RX_THREADS) k_radix_fine(uint32_t* slots, const uint32_t* cursor, const uint32_t* v_start,
+                                                           const uint32_t* dig2, const uint32_t* idx2, uint32_t V) {
+  constexpr uint32_t NB = 1u << RX_FINE_BITS;
+  __shared__ uint32_t stage[RXB_TILE];
+  __shared__ uint8_t stage_b[RXB_TILE];
+  __shared__ uint32_t t_cnt[NB], t_start[NB], g_cur[NB], lds_wave[RX_THREADS / 64];
+  const uint32_t v = V - 1 - blockIdx.x, tid = threadIdx.x;
+  if (tid < NB) g_cur[tid] = cursor[(uint64_t)v * NB + tid];
+  const uint64_t beg = v_start[v], end = v_start[v + 1];
+  for (uint64_t t0 = beg; t0 < end; t0 += RXB_TILE) {
+    if (tid < NB) t_cnt[tid] = 0;
+    __syncthreads();
+    uint32_t dv[RXB_ITEMS], iv[RXB_ITEMS], rk[RXB_ITEMS];
+#pragma unroll
+    for (int i = 0; i < RXB_ITEMS; i++) {
+      const uint64_t j = t0 + (uint64_t)i * RX_THREADS + tid;
+      dv[i] = j < end ? dig2[j] : 0u;
+      iv[i] = j < end ? idx2[j] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < RXB_ITEMS; i++) {
+      const uint32_t l = dv[i] & 0xFFFFu;
+      rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0, RX_FINE_BITS);
+    }
+    __syncthreads();
+    rx_scan_bins(t_start, t_cnt, NB, lds_wave);
+#pragma unroll
+    for (int i = 0; i < RXB_ITEMS; i++) {
+      const uint32_t l = dv[i] & 0xFFFFu;
+      if (l) {
+        const uint32_t p = t_start[l - 1] + rk[i];
+        stage[p] = (iv[i] << 1) | (dv[i] >> 31);
+        stage_b[p] = (uint8_t)(l - 1);
+      }
+    }
+    __syncthreads();
+    const uint32_t n_tile = t_start[NB - 1] + t_cnt[NB - 1];
+    for (uint32_t i = tid; i < n_tile; i += RX_THREADS) {
+      const uint32_t bk = stage_b[i];
+      slots[g_cur[bk] + (i - t_start[bk])] = stage[i];
+    }
+    __syncthreads();
+    if (tid < NB) g_cur[tid] += t_cnt[tid];
+  }
+}
+
+// First level of the two-level sort: entries of window kk are partitioned by the high bits of their bucket index into
+// Hn = L >> shift coarse bins (windows with more than 2^15 buckets, c > 16: shift = 15; big inputs at c <= 16: shift = 7,
+// i.e. 256 coarse bins x 128 buckets, both passes writing long sequential runs) (k_hist with the same shift and
 // k_colscan provide the offsets); the entry keeps its low 15 bits (+1, so 0 still means "no entry"), its sign and
 // its entry index in two flat arrays.  Every block writes Hn sequential streams, which the L2 can merge -- the
 // direct scatter over 2^21 buckets could not.  The second level is the ordinary LDS sort per coarse bin.
 __global__ void __launch_bounds__(SORT_THREADS) k_scatter_coarse(uint32_t* dig2, uint32_t* idx2, const uint32_t* part_start,
                                                                  const uint32_t* block_hist, const uint32_t* dig,
-                                                                 uint64_t two_n, uint64_t chunk, uint32_t Hn, uint32_t shift) {
+                                                                 uint64_t two_n, uint64_t chunk, uint32_t Hn, uint32_t shift,
+                                                                 uint32_t agg_bits) {
   extern __shared__ uint32_t lds_pos[];
   const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
   const uint32_t* base = block_hist + ((uint64_t)kk * B + b) * Hn;
@@ -277,11 +471,12 @@ __global__ void __launch_bounds__(SORT_THREADS) k_scatter_coarse(uint32_t* dig2,
   const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
   const uint32_t* d = dig + (uint64_t)kk * two_n;
   const uint32_t lo_mask = (1u << shift) - 1;
-  for (uint64_t j = beg + threadIdx.x; j < end; j += SORT_THREADS) {
-    uint32_t v = d[j];
-    uint32_t l = v & 0x7FFFFFFFu;
+  for (uint64_t j0 = beg; j0 < end; j0 += SORT_THREADS) {
+    const uint64_t j = j0 + threadIdx.x;
+    const uint32_t v = j < end ? d[j] : 0u;
+    const uint32_t l = v & 0x7FFFFFFFu;
+    const uint32_t pos = lds_rank_add(lds_pos, l ? (l - 1) >> shift : 0u, l != 0, agg_bits);
     if (l) {
-      uint32_t pos = atomicAdd(&lds_pos[(l - 1) >> shift], 1u);
       dig2[pos] = (((l - 1) & lo_mask) + 1) | (v & 0x80000000u);
       idx2[pos] = (uint32_t)j;
     }
