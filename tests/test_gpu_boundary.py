@@ -124,3 +124,31 @@ def test_device_list_context_on_one_gpu(gpu_ctx, lg):
     assert multi.run(sb)[0].as_tuple() == exp
     multi.pointset_destroy(sid)
     multi.close()
+
+
+def test_two_rank_sharded_bench_in_child_processes():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), here with both ranks on
+    the one GPU of the box and gloo as the process group: every rank computes the window sums of its shard through the
+    HIP path, one all-gather, rank 0 combines and checks the result against the known discrete logs.  Fresh child
+    processes (never a re-exec of this one)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--log2n", "20", "--dist-backend", "gloo", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["verified"] is True, d
+    assert d["config"]["workload"] == "bls12-377-g1-msm-2^20" and "window-shard x2" in d["config"]["parallelism"]
