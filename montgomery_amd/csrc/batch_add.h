@@ -41,6 +41,7 @@ struct BatchArgs {
   uint64_t n_out;           // number of output elements
   uint32_t steps;
   const uint32_t* desc;     // MODE_SEARCH: operand descriptors from k_tail_desc
+  uint64_t sstride;         // lanes per scratch plane (>= T; see ba_store_pre)
 };
 
 constexpr int BA_THREADS = 256;
@@ -217,14 +218,16 @@ __device__ __forceinline__ void ba_load_y(Pk& y1, Pk& y2, const PairLoc<MODE>& L
 }
 
 // prefix product of one (step, lane): 13 limbs as 3 uint4 + 1 dword, each in its own plane of T lanes
-__device__ __forceinline__ void ba_store_pre(const BatchArgs& a, uint32_t i, uint64_t T, uint32_t t, const uint32_t (&l)[NL]) {
+__device__ __forceinline__ void ba_store_pre(const BatchArgs& a, uint32_t i, uint64_t, uint32_t t, const uint32_t (&l)[NL]) {
+  const uint64_t T = a.sstride;
   char* sb = reinterpret_cast<char*>(a.scratch) + (uint64_t)i * T * 52;
 #pragma unroll
   for (int j = 0; j < 3; j++)
     *reinterpret_cast<uint4*>(sb + (uint64_t)j * T * 16 + 16u * t) = make_uint4(l[4 * j], l[4 * j + 1], l[4 * j + 2], l[4 * j + 3]);
   *reinterpret_cast<uint32_t*>(sb + 48ull * T + 4u * t) = l[12];
 }
-__device__ __forceinline__ void ba_load_pre(uint32_t (&l)[NL], const BatchArgs& a, uint32_t i, uint64_t T, uint32_t t) {
+__device__ __forceinline__ void ba_load_pre(uint32_t (&l)[NL], const BatchArgs& a, uint32_t i, uint64_t, uint32_t t) {
+  const uint64_t T = a.sstride;
   const char* sb = reinterpret_cast<const char*>(a.scratch) + (uint64_t)i * T * 52;
 #pragma unroll
   for (int j = 0; j < 3; j++) {

@@ -583,6 +583,8 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       r_stop++;
   }
   // outputs alternate between two buffers: size each for the largest round it receives
+  long long scratch_pad = 0;   // lanes added to the scratch plane stride (experiment: power-of-two strides vs HBM channels)
+  MSM_KNOB(scratch_pad, "MSM_SCRATCH_PAD", 0);
   uint64_t capA = 1, capB = 1;
   {
     int which = 0;
@@ -599,7 +601,8 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     }
   }
   // idle lanes of a round's last step read (and ignore) up to 2 T elements past its end: keep that inside the allocation
-  const size_t tree_slack = (size_t)ctx->n_cu * 4 * 8 * 64 * 2 * 16;
+  // (T, the lanes of a round, is largest in round 1 and grows with the input once the 512 steps per lane are used up)
+  const size_t tree_slack = (size_t)round_geom(ctx, std::max<uint64_t>(total_slots / 2, 1), true, lone).T * 2 * 16 + 4096;
   ctx->ensure(w.bufA, capA * elem_bytes + tree_slack);
   ctx->ensure(w.bufB, capB * elem_bytes + tree_slack);
   uint4* buf[2] = {(uint4*)w.bufA.p, (uint4*)w.bufB.p};
@@ -614,7 +617,8 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     for (uint32_t r = 1; r <= logG; r++) {
       uint64_t n_out = n_in / 2;
       RoundGeom g = round_geom(ctx, n_out, r == 1 || te, lone);   // no inversion on the Edwards path: always two waves
-      if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * g.T * 4);
+      const uint64_t sstride = g.T + scratch_pad;
+      if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * sstride * 4);
       BatchArgs a{};
       a.points = (const uint32_t*)ctx->rows.p + p_lo * (te ? (uint64_t)te::TE_ROW_WORDS : (uint64_t)ROW_WORDS);
       a.slots = (const uint32_t*)w.slots.p;
@@ -623,6 +627,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       a.out = buf[cur];
       a.out_cap = cap[cur];
       a.scratch = (uint32_t*)w.scratch.p;
+      a.sstride = sstride;
       a.n_out = n_out;
       a.steps = g.steps;
       if (r == 1) {
@@ -643,13 +648,15 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     for (int r = 1; r <= r_stop; r++) {
       uint64_t n_out = w.h_info[3 + r];
       RoundGeom g = round_geom(ctx, n_out, te);
-      if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * g.T * 4);
+      const uint64_t sstride = g.T + scratch_pad;
+      if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * sstride * 4);
       BatchArgs a{};
       a.in = buf[cur ^ 1];
       a.in_cap = cap[cur ^ 1];
       a.out = buf[cur];
       a.out_cap = cap[cur];
       a.scratch = (uint32_t*)w.scratch.p;
+      a.sstride = sstride;
       a.n_out = n_out;
       a.steps = g.steps;
       if (n_out) {
@@ -1616,6 +1623,7 @@ int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t
     a.out = (uint4*)outb.p;
     a.out_cap = n;
     a.scratch = (uint32_t*)scr.p;
+    a.sstride = gm.T;
     a.n_out = n;
     a.steps = gm.steps;
     W_LAUNCH_MODE(ctx, k_batch_add, MODE_GATHER, dim3(gm.grid), dim3(256), 0, ctx->stream, a);
@@ -1736,6 +1744,7 @@ int msm_test_batch_add_mode(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, ui
     a.out = (uint4*)outb.p;
     a.out_cap = (uint64_t)steps * T;
     a.scratch = (uint32_t*)scr.p;
+    a.sstride = T;
     a.n_out = n;
     a.steps = steps;
     if (mode == MODE_SEARCH) {
