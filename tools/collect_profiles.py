@@ -5,16 +5,16 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 for name, dst in (("trace26", f"{tag}_kernel_stats_2p26.csv"), ("trace20", f"{tag}_kernel_stats_2p20.csv"), ("trace_ed20", f"{tag}_kernel_stats_ed377_2p20.csv")):
-    f = glob.glob(f"{src}/{name}/*/*_kernel_stats.csv")
+    f = sorted(glob.glob(f"{src}/{name}/*/*_kernel_stats.csv"), key=os.path.getmtime)   # gpurun merges: keep the newest run
     if f:
-        shutil.copy(f[0], f"profiles/{dst}")
+        shutil.copy(f[-1], f"profiles/{dst}")
 for name in ("bench_2p26.json", "bench_2p20.json", "bench_ed377_2p20.json", "bench_bls381_2p26.json", "bench_bls381_2p20.json",
              "ubench_exec.txt", "ubench_occ.txt", "ubench_bt.txt", "ubench_inv.txt", "ubench_int2.txt", "cpu_baseline.json"):
     if os.path.exists(f"{src}/{name}"):
         shutil.copy(f"{src}/{name}", f"profiles/{tag}_{name}")
 out = {}
 for kind in ("fetch", "write", "sq", "grbm"):
-    fs = glob.glob(f"{src}/pmc_{kind}/*/*_counter_collection.csv")
+    fs = sorted(glob.glob(f"{src}/pmc_{kind}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1:]
     if not fs:
         continue
     agg = collections.OrderedDict()
