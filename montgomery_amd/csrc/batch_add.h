@@ -217,6 +217,30 @@ __device__ __forceinline__ void ba_load_y(Pk& y1, Pk& y2, const PairLoc<MODE>& L
   }
 }
 
+// The second operand of a pair once more (x and y, sign applied): only for the patch of "first operand is the identity",
+// which trailing padding never produces -- it needs a cancellation P - P earlier in the tree.
+template <class F, int MODE>
+__device__ __forceinline__ void ba_load_b(Pk& x2, Pk& y2, const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t) {
+  if constexpr (MODE == MODE_GATHER) {
+    ba_load3_wide(x2, L.pb);
+    ba_load3_wide(y2, L.pb + 48);
+    pk_cond_neg<F>(y2, L.flags & 8u);
+    pk_cond_sub_p<F>(y2);
+  } else if constexpr (MODE == MODE_REGULAR) {
+    ba_load3(x2, L.base + 16, 32u * t, a.in_cap * 16);
+    ba_load3(y2, L.base + 3 * a.in_cap * 16 + 16, 32u * t, a.in_cap * 16);
+  } else {
+    const uint64_t s = a.in_cap * 16;
+    const char* p = reinterpret_cast<const char*>(a.in) + L.a + (L.b_absent ? 0 : 16);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const uint4 v = *reinterpret_cast<const uint4*>(p + j * s), u = *reinterpret_cast<const uint4*>(p + (j + 3) * s);
+      x2.w[4 * j] = v.x; x2.w[4 * j + 1] = v.y; x2.w[4 * j + 2] = v.z; x2.w[4 * j + 3] = v.w;
+      y2.w[4 * j] = u.x; y2.w[4 * j + 1] = u.y; y2.w[4 * j + 2] = u.z; y2.w[4 * j + 3] = u.w;
+    }
+  }
+}
+
 // prefix product of one (step, lane): 13 limbs as 3 uint4 + 1 dword, each in its own plane of T lanes
 __device__ __forceinline__ void ba_store_pre(const BatchArgs& a, uint32_t i, uint64_t, uint32_t t, const uint32_t (&l)[NL]) {
   const uint64_t T = a.sstride;
@@ -301,6 +325,11 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
   // lane t owns the pairs e = t + i * T; all lanes walk all `steps` steps (a uniform loop: the step's bases stay in
   // SGPRs), lanes past the end of the round idle through it with den = 1 and no stores
   auto is_active = [&](uint32_t i) { return (uint64_t)i * T + t < a.n_out; };
+#ifdef BA_X_NOMEM   // experiment: every step uses the addresses of step 0 (cache hits; results are garbage): the ALU time alone
+#define BA_STEP(i) 0u
+#else
+#define BA_STEP(i) (i)
+#endif
 
   Fe<F> acc;
   fe_set_one<F>(acc);
@@ -316,10 +345,10 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
       Fe<F> den;
       ba_denominator<F, MODE, false>(den, x1, x2, nullptr, nullptr, L, a, t, is_active(i));
       if (i + 1 < steps) {   // the next pair's x: its registers are free now, the multiplication covers the latency
-        ba_locate<MODE>(L, a, i + 1, T, t, is_active(i + 1));
+        ba_locate<MODE>(L, a, BA_STEP(i + 1), T, t, is_active(i + 1));
         ba_load_x<MODE>(x1, x2, L, a, t);
       }
-      ba_store_pre(a, i, T, t, acc.l);
+      ba_store_pre(a, BA_STEP(i), T, t, acc.l);
       BA_FENCE();
       BA_MUL(acc, acc, den);
       BA_FENCE();
@@ -358,9 +387,9 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
     PairLoc<MODE> L, Ln;
     Pk x1, x2, y1, y2, nx1, nx2;
     Fe<F> pre, npre;
-    ba_locate<MODE>(L, a, steps - 1, T, t, is_active(steps - 1));
+    ba_locate<MODE>(L, a, BA_STEP(steps - 1), T, t, is_active(steps - 1));
     ba_load_x<MODE>(x1, x2, L, a, t);
-    ba_load_pre(pre.l, a, steps - 1, T, t);
+    ba_load_pre(pre.l, a, BA_STEP(steps - 1), T, t);
     ba_load_y<F, MODE>(y1, y2, L, a, t);
     Ln = L;
 #pragma unroll 1
@@ -394,9 +423,9 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
       // The next pair's x and prefix product are requested here, three multiplications before they are needed:
       // 37 registers that are free from now on (the widest point of the step, inv * den with d and num waiting, is behind)
       if (i > 0) {
-        ba_locate<MODE>(Ln, a, (uint32_t)i - 1, T, t, is_active((uint32_t)i - 1));
+        ba_locate<MODE>(Ln, a, BA_STEP((uint32_t)i - 1), T, t, is_active((uint32_t)i - 1));
         ba_load_x<MODE>(nx1, nx2, Ln, a, t);
-        ba_load_pre(npre.l, a, (uint32_t)i - 1, T, t);
+        ba_load_pre(npre.l, a, BA_STEP((uint32_t)i - 1), T, t);
       }
       BA_FENCE();
       Fe<F> m;
@@ -429,23 +458,32 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
       if (MODE == MODE_GATHER) pk_reduce_product<F>(y1);
       pk_sub_mod<F>(y3, y3, y1);
       pk_reduce_product<F>(y3);
-      if (__any(kind & ~BA_DOUBLE)) {                 // identity operands, P - P, idle lanes: patch the output
-        park_get(x1, 0);
-        park_get(x2, 1);
-        ba_load_y<F, MODE>(y1, y2, L, a, t);
-        if (MODE == MODE_GATHER) { pk_reduce_product<F>(y1); pk_reduce_product<F>(y2); }
+      // Patches.  Padding behind a bucket's last element makes "second operand missing" (copy A) and "both missing"
+      // (identity) ordinary at large windows, where a wave spans several buckets: both are selects on registers that
+      // are still at hand.  Only "first operand is the identity" fetches the second operand again.
+      if (__any(kind & ~BA_DOUBLE)) {
         const bool ca = kind & BA_COPY_A, cb = kind & BA_COPY_B, z = kind & BA_ZERO;
+        park_get(x1, 0);
 #pragma unroll
         for (int j = 0; j < NW; j++) {
-          x3.w[j] = z ? INF_WORD : ca ? x1.w[j] : cb ? x2.w[j] : x3.w[j];
-          y3.w[j] = z ? 0u : ca ? y1.w[j] : cb ? y2.w[j] : y3.w[j];
+          x3.w[j] = z ? INF_WORD : ca ? x1.w[j] : x3.w[j];
+          y3.w[j] = z ? 0u : ca ? y1.w[j] : y3.w[j];
+        }
+        if (__any(cb)) {
+          Pk bx, by;
+          ba_load_b<F, MODE>(bx, by, L, a, t);
+#pragma unroll
+          for (int j = 0; j < NW; j++) {
+            x3.w[j] = cb ? bx.w[j] : x3.w[j];
+            y3.w[j] = cb ? by.w[j] : y3.w[j];
+          }
         }
       }
       asm volatile("" ::: "memory");
       BA_FENCE();
       if (i > 0) ba_load_y<F, MODE>(y1, y2, Ln, a, t);   // the next pair's y: in flight during the stores and d = inv * pre
       if (!(kind & BA_SKIP)) {
-        char* ob = reinterpret_cast<char*>(a.out + (uint64_t)i * T);
+        char* ob = reinterpret_cast<char*>(a.out + (uint64_t)BA_STEP(i) * T);
         ba_store3(ob, 16u * t, a.out_cap * 16, x3);
         ba_store3(ob + 3 * a.out_cap * 16, 16u * t, a.out_cap * 16, y3);
       }

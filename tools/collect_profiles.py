@@ -26,6 +26,17 @@ for kind in ("fetch", "write", "sq", "grbm"):
     for k in agg:
         agg[k]["launches"] = len(agg[k]["launches"])
     out[kind] = agg
+    if kind == "grbm":
+        # the clock each kernel actually held (DVFS give-back, MI355X_MICROARCH.md): GRBM_GUI_ACTIVE / 8 XCDs / wall time,
+        # over dispatches of at least 0.3 ms (the quotient reads high on shorter ones)
+        clk = collections.OrderedDict()
+        for r in csv.DictReader(open(fs[0])):
+            dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if r["Counter_Name"] != "GRBM_GUI_ACTIVE" or dur < 300000:
+                continue
+            c = clk.setdefault(r["Kernel_Name"].split("(")[0], [0.0, 0, 0])
+            c[0] += float(r["Counter_Value"]); c[1] += dur; c[2] += 1
+        out["effective_clock_ghz"] = {k: {"dispatches": n, "wall_ms": round(d / 1e6, 3), "ghz": round(c / 8 / d, 3)} for k, (c, d, n) in clk.items()}
 json.dump({"command": "rocprofv3 --pmc <counters> (one pass per group: FETCH_SIZE | WRITE_SIZE | SQ_* | GRBM_GUI_ACTIVE) -- python3 bench.py --steps 1 --warmup 0 --log2n 24 --no-cpu-baseline --no-verify (the run holds TWO MSMs: the timed step and the serialised one)",
            "note": "FETCH_SIZE / WRITE_SIZE in KB as reported; gfx950 halves FETCH_SIZE on wide coalesced reads (MI355X_MICROARCH.md). SQ_* cycle counters are in quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs.",
            "counters": out}, open(f"profiles/{tag}_pmc_2p24.json", "w"), indent=1)

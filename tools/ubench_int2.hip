@@ -63,6 +63,11 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint64_t* stamps, uint32
       if (OP == 30) asm volatile("v_cmp_lt_u32 %2, %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(lo[i]) : "v"(a), "s"(sm));
       if (OP == 31) { lo[i] = (lo[i] < a) ? lo[i] + b : lo[i] ^ a; }
       if (OP == 26) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(lo[i]) : "v"(a));
+      // dependent accumulation chains, as a column of a product-scanning multiplier issues them (1, 2, 4 independent chains)
+      if (OP == 40) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b) : "vcc");
+      if (OP == 41) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i & 1]) : "v"(a), "v"(b) : "vcc");
+      if (OP == 42) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i & 3]) : "v"(a), "v"(b) : "vcc");
+      if (OP == 43) asm volatile("v_add_u32 %0, %0, %1" : "+v"(lo[0]) : "v"(a));
       if (OP == 27) asm volatile("v_bfe_u32 %0, %0, 3, 30" : "+v"(lo[i]));
     }
   }
@@ -123,6 +128,10 @@ int main() {
     run<5>("v_and_b32", w, out, stamps);
     run<13>("v_mov_b32", w, out, stamps);
     run<0>("v_mad_u64_u32", w, out, stamps);
+    run<40>("mad64 1 chain", w, out, stamps);
+    run<41>("mad64 2 chains", w, out, stamps);
+    run<42>("mad64 4 chains", w, out, stamps);
+    run<43>("add_u32 1 chain", w, out, stamps);
     run<12>("v_mad_i64_i32", w, out, stamps);
     run<1>("v_mul_lo_u32", w, out, stamps);
     run<6>("v_add3_u32", w, out, stamps);
