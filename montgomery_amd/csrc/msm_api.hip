@@ -320,7 +320,10 @@ struct RoundGeom {
 // 31.5 -> 29.2 ms).  With two groups on two streams the other stream already fills the gaps and 512 is better.
 RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather = false, bool lone = false) {
   uint64_t target = (uint64_t)ctx->n_cu * 4 * MSM_BA_WAVES * 64;  // as many lanes as the kernel's launch bounds keep resident
-  uint64_t half_below = 0;  // steps at full width below which a non-gather round runs on half as many lanes (to be retuned)
+  // steps at full width below which a non-gather round runs on half as many lanes: every lane pays one inversion per
+  // round (~13 pair additions' worth), and one wave per SIMD already gets 89 % of the multiplier's two-wave rate
+  // (tools/ubench_mul2.hip).  Measured with the round-2 kernel: 2^20 4.05 -> 3.91 ms, 2^22 12.9 -> 12.4, neutral elsewhere.
+  uint64_t half_below = 128;
   MSM_KNOB(half_below, "MSM_HALF_BELOW", 0);
   if (!gather && n_out < target * half_below) target /= 2;
   uint32_t max_steps = (lone && n_out >= target * 512) ? 128 : 512;
