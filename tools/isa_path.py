@@ -1,46 +1,47 @@
 #!/usr/bin/env python3
-"""Main-path opcode count of one loop of a kernel's assembly: starts at a label, follows every forward conditional
-branch as TAKEN (the wave-uniform side branches of k_batch_add guard rare cases and are skipped by their
-s_cbranch_*z), stops when it is back at the label.   usage: isa_path.py file.s kernel_substring label [--scc-falls] [-v]"""
-import collections, re, sys
+"""Straight-line segments of one kernel's assembly: every stretch of instructions between two labels / branches, with its
+VALU and v_mad_u64_u32 counts and the branch that ends it.  The wave-uniform side branches of k_batch_add (identity
+operands, P + P, the rare excess over p) show up as segments "after" an s_cbranch_*z; adding up the others gives the
+instructions a wave really issues per step (isa_hist.py counts whole labelled blocks, rare tails included).
+
+usage: isa_path.py file.s kernel_substring [--sum SEG,SEG,...]   (SEG = index printed in the first column)"""
+import re, sys
+
 
 def main():
-    path, key, label = sys.argv[1:4]
-    verbose = "-v" in sys.argv
-    scc_falls = "--scc-falls" in sys.argv   # treat s_cbranch_scc* as not taken
+    path, key = sys.argv[1:3]
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l.split(":")[0])
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
-    pos = {l.split(":")[0]: i for i, l in enumerate(lines[start:end], start) if re.match(r"^\.LBB\d+_\d+:", l)}
-    i = pos[label]
-    hist = collections.Counter()
-    n = 0
-    while i < end:
-        s = lines[i].split(";")[0].strip()
-        i += 1
-        if not s or s.startswith(".") or s.endswith(":"):
+    segs = []   # [name, valu, mad, vmem, salu, terminator]
+    cur = ["<entry>", 0, 0, 0, 0, ""]
+    for i in range(start + 1, end + 1):
+        l = lines[i]
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        s = l.split(";")[0].strip()
+        if m:
+            segs.append(cur)
+            cur = [m.group(1), 0, 0, 0, 0, ""]
+            continue
+        if not s or s.startswith("."):
             continue
         op = s.split()[0]
-        m = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", s)
-        b = re.match(r"s_branch\s+(\.LBB\d+_\d+)", s)
-        hist[op] += 1
-        n += 1
-        if verbose: print(s)
-        if m and "scc" in s.split()[0] and scc_falls:
-            continue         # uniform loop control (i > 0, steps left): not the rare-case guards
-        if m or b:
-            tgt = pos[(m or b).group(1)]
-            if tgt <= pos[label] or n > 20000:      # back at the header: one trip done
-                break
-            i = tgt
-        elif i < end and lines[i].startswith(label + ":"):
-            break
-    valu = sum(c for o, c in hist.items() if o.startswith("v_"))
-    mad = hist["v_mad_u64_u32"]
-    print(f"{label}: {n} instructions, VALU {valu}, v_mad_u64_u32 {mad}, other VALU {valu - mad}, "
-          f"VMEM {sum(c for o, c in hist.items() if o.startswith(('global_', 'buffer_', 'scratch_', 'flat_')))}, "
-          f"SALU {sum(c for o, c in hist.items() if o.startswith('s_'))}")
-    for o, c in hist.most_common(40):
-        print(f"  {o:28s} {c}")
+        if op.startswith("v_"): cur[1] += 1
+        if op == "v_mad_u64_u32": cur[2] += 1
+        if op.startswith(("global_", "buffer_", "scratch_", "flat_", "ds_")): cur[3] += 1
+        if op.startswith("s_") and not op.startswith(("s_cbranch", "s_branch")): cur[4] += 1
+        if op.startswith("s_cbranch") or op == "s_branch":
+            cur[5] = s
+            segs.append(cur)
+            cur = [cur[0].split()[0] + " (after the branch)", 0, 0, 0, 0, ""]
+    segs.append(cur)
+    segs = [s for s in segs if s[1] or s[3] or s[5]]
+    for n, (name, valu, mad, vmem, salu, term) in enumerate(segs):
+        print(f"{n:3d} {name:34s} VALU {valu:5d}  mad64 {mad:4d}  other {valu - mad:4d}  VMEM {vmem:3d}  SALU {salu:3d}   {term}")
+    if "--sum" in sys.argv:
+        pick = [int(x) for x in sys.argv[sys.argv.index("--sum") + 1].split(",")]
+        v = sum(segs[i][1] for i in pick); m = sum(segs[i][2] for i in pick)
+        print(f"sum over {pick}: VALU {v}, v_mad_u64_u32 {m}, other VALU {v - m}, VMEM {sum(segs[i][3] for i in pick)}, SALU {sum(segs[i][4] for i in pick)}")
+
 
 main()
