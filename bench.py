@@ -38,6 +38,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 # waves per SIMD (4.6 real cycles per wave-instruction at 2.35 GHz); 28.2e12 at the two waves per SIMD k_batch_add runs with
 INT_MAD_PEAK = 33.4e12
 INT_MAD_AT_2_WAVES = 28.2e12
+# Clock the chip holds under k_batch_add (GRBM_GUI_ACTIVE / 8 / wall time, profiles/r02_pmc_2p24.json: 1.79 GHz in the
+# regular rounds, 2.00 in the gather round, half the pairs each) against the 2.39 GHz the micro-benchmark kernels hold
+HELD_CLOCK_GHZ = 1.89
+UBENCH_CLOCK_GHZ = 2.39
 # HBM bytes per pair addition from the PMC passes committed in profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE runs at
 # 2^24, regular rounds; FETCH_SIZE doubled: gfx950 halves wide coalesced reads) -- see profiles/README.md
 PAIR_TRAFFIC_BYTES_PMC = 488
@@ -277,6 +281,8 @@ def main():
                 "frac": xi["n_pairs"] * PAIR_ALGO_BYTES / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "int_mad_frac": xi["n_pairs"] * PAIR_MADS / (x_ms * 1e-3) / INT_MAD_PEAK,
                 "int_mad_frac_at_2_waves_per_simd": xi["n_pairs"] * PAIR_MADS / (x_ms * 1e-3) / INT_MAD_AT_2_WAVES,
+                "int_mad_frac_at_held_clock": xi["n_pairs"] * PAIR_MADS / (x_ms * 1e-3) / (INT_MAD_PEAK * HELD_CLOCK_GHZ / UBENCH_CLOCK_GHZ),
+                "held_clock_ghz": HELD_CLOCK_GHZ,
                 "phase_ms": xi["phase_ms"],
                 # the counting sort (histogram + scans + scatter): 2 N K entries, each read twice as a 4-byte digit and
                 # written once as a 4-byte payload to a random slot of its bucket
@@ -348,8 +354,9 @@ def main():
                 "exclusive": excl,
                 "note": "achieved = pair additions x 288 algorithmic bytes / event-timed accumulation time; the launches of the two "
                         "window-group streams overlap, 'exclusive' = the same kernels with the streams serialised (one untimed step). "
-                        "The kernel moves ~490 B per pair addition (prefix-product scratch, second read of x) and is bound by that "
-                        "traffic: with the multiplications compiled out it runs in 83 % of its time (DESIGN.md section 5)",
+                        "The kernel moves ~490 B per pair addition (prefix-product scratch, second read of x); its traffic alone "
+                        "(multiplications compiled out) and its instruction stream alone (memory compiled out) each take ~83 % of "
+                        "its time, and the chip holds 1.8-2.0 GHz under it (DESIGN.md section 5)",
             },
             "phase_ms": phase,
             "pcie_inclusive": pcie,
