@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
   hipMemset(table, 1, bytes);
   uint32_t* out; hipMalloc(&out, 1 << 22);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const int blocks = 512, steps = 400;   // 2 blocks per CU: the tree kernel's occupancy
+  const int blocks = argc > 2 ? atoi(argv[2]) : 512, steps = 400 * 512 / blocks;   // 512 = 2 blocks per CU: the tree kernel's occupancy
   const double useful = (double)blocks * 256 * steps * 192;
   auto run = [&](int pattern, uint64_t range_bytes, uint64_t win_bytes) {
     const uint64_t rl = range_bytes / 128, wl = win_bytes / 128;
