@@ -61,3 +61,8 @@ ab:
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -c $(CSRC)/msm_api.hip -o ab_builds/$(NAME)/msm_api.o; wait
 	$(HIPCC) --offload-arch=$(ARCH) -shared -pthread ab_builds/$(NAME)/*.o -o ab_builds/libmsm_$(NAME).so
 	rm -rf ab_builds/$(NAME)
+
+# micro-benchmarks quoted in DESIGN.md (run on the GPU box; outputs are committed under profiles/)
+UBENCH := ubench_int2 ubench_inv ubench_mul2 ubench_mad3 ubench_gather ubench_carry
+ubench:
+	for u in $(UBENCH); do $(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -Iinclude -I$(CSRC) tools/$$u.hip -o tools/$$u 2>&1 | grep -E "error" ; done; true

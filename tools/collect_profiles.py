@@ -9,7 +9,8 @@ for name, dst in (("trace26", f"{tag}_kernel_stats_2p26.csv"), ("trace20", f"{ta
     if f:
         shutil.copy(f[-1], f"profiles/{dst}")
 for name in ("bench_2p26.json", "bench_2p20.json", "bench_ed377_2p20.json", "bench_bls381_2p26.json", "bench_bls381_2p20.json",
-             "ubench_exec.txt", "ubench_occ.txt", "ubench_bt.txt", "ubench_inv.txt", "ubench_int2.txt", "cpu_baseline.json"):
+             "ubench_exec.txt", "ubench_occ.txt", "ubench_bt.txt", "ubench_inv.txt", "ubench_int2.txt", "ubench_mul2.txt", "ubench_mad3.txt",
+             "ubench_gather.txt", "ubench_carry.txt", "cpu_baseline.json"):
     if os.path.exists(f"{src}/{name}"):
         shutil.copy(f"{src}/{name}", f"profiles/{tag}_{name}")
 out = {}

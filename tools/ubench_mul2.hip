@@ -1,5 +1,5 @@
-// The field multiplier at the tree kernel's occupancy (2 waves per SIMD, 256-thread blocks): SIMD cycles per product.
-// Build twice: as is (MADs pinned row by row, field.h) and with -DFE_PLAIN_MAD (hipcc's own column-by-column order).
+// The field multiplier as compiled, at 1 / 2 / 4 resident waves per SIMD (256-thread blocks): SIMD cycles per product,
+// and the same with 8 / 16 / 32 products per loop iteration (up to 113 KB of code: does instruction fetch keep up?).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../montgomery_amd/csrc/curve.h"
