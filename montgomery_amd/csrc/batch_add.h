@@ -56,7 +56,11 @@ constexpr int BA_THREADS = 256;
 #else
 #define BA_MUL(r, x, y) fe_mul<F>(r, x, y)
 #define BA_SQR(r, x) fe_sqr<F>(r, x)
+#ifdef BA_X_NOINV   // experiment: the shared inversion compiled out (wrong sums): what the inversions cost per round
+#define BA_INV(r, x) r = x
+#else
 #define BA_INV(r, x) fe_inv<F>(r, x)
+#endif
 #endif
 #ifndef MSM_BA_WAVES
 #define MSM_BA_WAVES 2      // resident waves per SIMD the register allocation is held to (2: 256 VGPRs, 3: 168 + LDS parking)

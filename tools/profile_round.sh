@@ -15,7 +15,7 @@ python bench.py --curve bls12-381 --steps 10 --warmup 2 > $OUT/bench_bls381_2p26
 python bench.py --curve bls12-381 --steps 10 --warmup 2 --log2n 20 > $OUT/bench_bls381_2p20.json 2>> $OUT/bench_381.err
 python tools/cpu_series.py $OUT/cpu_baseline.json > $OUT/cpu_series.log 2>&1
 for u in ubench_int2 ubench_inv ubench_mul2 ubench_mad3 ubench_carry; do [ -x tools/$u ] && ./tools/$u > $OUT/$u.txt 2>&1; done
-[ -x tools/ubench_gather ] && { ./tools/ubench_gather 16 512; for b in 256 1024 2048; do echo "workgroups $b"; ./tools/ubench_gather 16 $b | grep -E "range    16384 MB  wave window (       0|     256) MB"; done; } > $OUT/ubench_gather.txt 2>&1
+[ -x tools/ubench_gather ] && { ./tools/ubench_gather 16 512; for b in 256 1024 2048; do echo "workgroups $b"; ./tools/ubench_gather 16 $b | grep -E "range    16384 MB  wave window (       0|     256) MB"; done; } > $OUT/ubench_gather.txt 2>/dev/null
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace26 -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $OUT/trace26.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace20 -- python3 $REPO/bench.py --steps 5 --warmup 1 --log2n 20 --no-cpu-baseline --no-verify > $OUT/trace20.log 2>&1
