@@ -156,7 +156,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=5)   # 15 runs, the first 5 discarded: scripts/msm-weierstrass.ts:27-50
     ap.add_argument("--log2n", type=int, default=26)
     ap.add_argument("--c", type=int, default=0)
     ap.add_argument("--cpu-log2n", type=int, default=24)

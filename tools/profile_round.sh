@@ -8,11 +8,11 @@ REPO=$PWD
 export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-python bench.py --steps 10 --warmup 2 > $OUT/bench_2p26.json 2> $OUT/bench_2p26.err
-python bench.py --steps 10 --warmup 2 --log2n 20 --no-cpu-baseline > $OUT/bench_2p20.json 2> $OUT/bench_2p20.err
-python bench.py --curve ed377 --steps 10 --warmup 2 --log2n 20 > $OUT/bench_ed377_2p20.json 2> $OUT/bench_ed.err
-python bench.py --curve bls12-381 --steps 10 --warmup 2 > $OUT/bench_bls381_2p26.json 2> $OUT/bench_381.err
-python bench.py --curve bls12-381 --steps 10 --warmup 2 --log2n 20 > $OUT/bench_bls381_2p20.json 2>> $OUT/bench_381.err
+python bench.py --steps 10 --warmup 5 > $OUT/bench_2p26.json 2> $OUT/bench_2p26.err
+python bench.py --steps 10 --warmup 5 --log2n 20 --no-cpu-baseline > $OUT/bench_2p20.json 2> $OUT/bench_2p20.err
+python bench.py --curve ed377 --steps 10 --warmup 5 --log2n 20 > $OUT/bench_ed377_2p20.json 2> $OUT/bench_ed.err
+python bench.py --curve bls12-381 --steps 10 --warmup 5 > $OUT/bench_bls381_2p26.json 2> $OUT/bench_381.err
+python bench.py --curve bls12-381 --steps 10 --warmup 5 --log2n 20 > $OUT/bench_bls381_2p20.json 2>> $OUT/bench_381.err
 python tools/cpu_series.py $OUT/cpu_baseline.json > $OUT/cpu_series.log 2>&1
 for u in ubench_int2 ubench_inv ubench_mul2 ubench_mad3 ubench_carry; do [ -x tools/$u ] && ./tools/$u > $OUT/$u.txt 2>&1; done
 [ -x tools/ubench_gather ] && { ./tools/ubench_gather 16 512; for b in 256 1024 2048; do echo "workgroups $b"; ./tools/ubench_gather 16 $b | grep -E "range    16384 MB  wave window (       0|     256) MB"; done; } > $OUT/ubench_gather.txt 2>/dev/null
