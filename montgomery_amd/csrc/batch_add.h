@@ -10,14 +10,15 @@
 //     backward sweep: d = inv * pre_i (= 1 / den_i), inv *= den_i, m = num * d, x3 = m^2 - x1 - x2,
 //                     y3 = m (x1 - x3) - y1                                              (4 M + 1 S per pair)
 //
-// Shape of the code (round 2): the kernel is issue-bound on the vector ALU, whose cost per wave-instruction depends
-// on the instruction class AND on the resident waves per SIMD (tools/ubench_int2.hip, profiles/r02_ubench_int.txt):
-// v_mad_u64_u32 5.6 / 5.3 cycles at 2 / 4 waves, carry-chain and three-source instructions the same, plain two-source
-// 32-bit instructions 3.8 / 2.8.  Hence
-//   * the lane state is kept small enough for more resident waves (launch bounds below): no register double buffer of
-//     the next pair; loads are issued as soon as their registers die and the other waves of the SIMD cover the latency;
+// Shape of the code (round 2).  What the measurements say: the instruction stream alone and the
+// memory traffic alone each take ~83 % of the kernel's time; the multiplier is bound by the v_mad_u64_u32 pipe and gains
+// nothing from more than two resident waves (tools/ubench_mul2.hip); the chip holds 1.8-2.0 GHz under this load.  Hence
+//   * two waves per SIMD, everything in registers: no register double buffer of the next pair; the next pair's x and
+//     prefix product are requested three multiplications ahead into registers that are dead by then, its y after the
+//     last use of y1;
 //   * all lanes run the common case (two finite points, different x) straight-line; identity operands, P + P and
-//     P - P are patched in wave-uniform side branches that almost no wave enters;
+//     P - P are handled in wave-uniform side branches; "second operand missing" and "both missing" -- ordinary behind
+//     a bucket's last element -- are selects on live registers, only "first operand is the identity" reloads;
 //   * linear operations stay on packed 32-bit words with carry chains and lazily reduced results
 //     (a - b + p instead of a conditional add), multiplication results are only reduced when the rare excess
 //     over p actually occurs (a product is < p (1 + 2^-11));
