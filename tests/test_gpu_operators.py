@@ -188,3 +188,32 @@ def test_batch_add_plane_modes_and_step_counts(gpu_ctx, mode, steps):
         got = out[96 * i : 96 * i + 96]
         exp = memo[key]
         assert got == (b"\0" * 96 if exp is None else exp[0].to_bytes(48, "little") + exp[1].to_bytes(48, "little")), (mode, steps, i)
+
+
+def test_batch_add_gather_mode_every_kind_of_pair(gpu_ctx):
+    """The same mix through MODE_GATHER (operands fetched from point rows by slot): generic pairs, P + P, P - P, a
+    missing second operand (copy A: a register select), a missing first operand (copy B: the one patch that fetches
+    again) and two missing operands, several per wave."""
+    p = C377.p
+    n = 5003
+    base, _ = O.random_points_bls377("gpu/modes/gather", 40)
+    g, h = [], []
+    for i in range(n):
+        P, Q = base[i % 40], base[(i * 11 + 5) % 40]
+        k = i % 19
+        if k == 3: Q = P
+        elif k == 6: Q = O.aff_neg(P, p)
+        elif k == 9: Q = None
+        elif k == 12: P = None
+        elif k == 15: P, Q = None, None
+        g.append(P)
+        h.append(Q)
+    enc = lambda P: b"\0" * 96 if P is None else P[0].to_bytes(48, "little") + P[1].to_bytes(48, "little")
+    out = gpu_ctx.test_batch_add(b"".join(map(enc, g)), b"".join(map(enc, h)))
+    memo = {}
+    for i in range(n):
+        key = (g[i], h[i])
+        if key not in memo:
+            memo[key] = O.aff_add(g[i], h[i], p)
+        exp = memo[key]
+        assert out[96 * i : 96 * i + 96] == (b"\0" * 96 if exp is None else exp[0].to_bytes(48, "little") + exp[1].to_bytes(48, "little")), i
