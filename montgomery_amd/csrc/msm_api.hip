@@ -895,8 +895,10 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   GroupStats st;
   const int pw = ctx->is_te() ? 32 : 36;
   words.assign((size_t)(k_hi - k_lo) * pw, 0);
-  // window groups: as large as the workspace budget allows; for big inputs two of them, so that the two
-  // workspaces/streams overlap one group's sort and bucket reduction with the other's accumulation
+  // window groups: as large as the workspace budget allows; for big inputs two of them on two streams.  The streams
+  // run in step (both sort, both gather, ...): what the second one buys is two tree kernels sharing the chip -- forward
+  // (memory-heavy) and backward (issue-heavy) sweeps of different waves mix, the small last rounds fill each other's
+  // idle CUs -- not a sort hidden under an accumulation
   int wpg = std::min(windows_per_group(ctx, n, pl), 128);
   const int nwin = k_hi - k_lo;
   // measured on MI355X: two groups win 14 % at 2^23 / 2^24, 3 % at 2^22, nothing at 2^21 -- below that the fixed
