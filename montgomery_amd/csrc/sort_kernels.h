@@ -215,7 +215,27 @@ __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, con
     end = min(beg + chunk, two_n);
     d = dig + (uint64_t)kk * two_n;
   }
-  for (uint64_t j0 = beg; j0 < end; j0 += SORT_THREADS) {   // whole waves stay in the loop (lds_rank_add ballots)
+  // 16-byte loads, two per thread and trip, while the slice allows it (one dword per thread and trip left the kernel
+  // waiting on single 256-byte wave loads: 1.2 ms per window group at 2^26, 1.75 TB/s); whole waves stay in both loops
+  // (lds_rank_add ballots)
+  uint64_t j0 = beg;
+  if (end > beg && ((reinterpret_cast<uintptr_t>(d + beg) & 15u) == 0)) {
+    const uint4* dv = reinterpret_cast<const uint4*>(d + beg);
+    const uint64_t nvec = (end - beg) / 4;
+    for (uint64_t q0 = 0; q0 < nvec; q0 += 2 * SORT_THREADS) {
+      const uint64_t qa = q0 + threadIdx.x, qb = qa + SORT_THREADS;
+      const uint4 va = qa < nvec ? dv[qa] : make_uint4(0, 0, 0, 0);
+      const uint4 vb = qb < nvec ? dv[qb] : make_uint4(0, 0, 0, 0);
+      const uint32_t w[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const uint32_t l = w[i] & 0x7FFFFFFFu;
+        (void)lds_rank_add(lds_hist, l ? (l - 1) >> shift : 0u, l != 0, agg_bits);
+      }
+    }
+    j0 = beg + nvec * 4;
+  }
+  for (; j0 < end; j0 += SORT_THREADS) {
     const uint64_t j = j0 + threadIdx.x;
     const uint32_t l = j < end ? d[j] & 0x7FFFFFFFu : 0u;
     (void)lds_rank_add(lds_hist, l ? (l - 1) >> shift : 0u, l != 0, agg_bits);
@@ -236,8 +256,15 @@ __global__ void __launch_bounds__(256) k_colscan(uint32_t* block_hist, uint32_t*
     p = block_hist + (uint64_t)row_tab[kk] * L + l;
     B = row_tab[kk + 1] - row_tab[kk];
   }
-  uint32_t run = 0;
-  for (uint32_t b = 0; b < B; b++) {
+  uint32_t run = 0, b = 0;
+  for (; b + 8 <= B; b += 8) {   // eight loads in flight per thread (one at a time made this a chain of B latencies)
+    uint32_t v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = p[(uint64_t)(b + i) * L];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { p[(uint64_t)(b + i) * L] = run; run += v[i]; }
+  }
+  for (; b < B; b++) {
     uint32_t v = p[(uint64_t)b * L];
     p[(uint64_t)b * L] = run;
     run += v;
@@ -307,6 +334,9 @@ __global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(uint32_t* slots, c
 // ---------------------------------------------------------------------------------------------
 
 constexpr int RX_THREADS = 1024;
+#ifndef RXA_WAVES
+#define RXA_WAVES 8   // pass A: two workgroups per CU (60 KB of LDS each) -- one loads its tile while the other ranks
+#endif
 constexpr int RXA_ITEMS = 7, RXA_TILE = RX_THREADS * RXA_ITEMS;    // pass A: 7168 records of 8 bytes staged per tile (56 KB)
 constexpr int RXB_ITEMS = 12, RXB_TILE = RX_THREADS * RXB_ITEMS;   // pass B: 12288 payloads + bucket bytes (60 KB)
 constexpr uint32_t RX_FINE_BITS = 7;
@@ -356,7 +386,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_vscan(uint32_t* v_start, const
 }
 
 // pass A.  grid (B, kc); block (b, kk) owns entries [b * chunk, (b + 1) * chunk) of window kk.
-__global__ void __launch_bounds__(RX_THREADS) k_radix_coarse(uint32_t* dig2, uint32_t* idx2, const uint32_t* v_start,
+__global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t* dig2, uint32_t* idx2, const uint32_t* v_start,
                                                              const uint32_t* blk_off, const uint32_t* dig, uint64_t two_n,
                                                              uint64_t chunk, uint32_t Hn, uint32_t hbits) {
   __shared__ uint2 stage[RXA_TILE];
@@ -370,15 +400,18 @@ __global__ void __launch_bounds__(RX_THREADS) k_radix_coarse(uint32_t* dig2, uin
     if (tid < 256) t_cnt[tid] = 0;
     __syncthreads();
     uint32_t v[RXA_ITEMS], rk[RXA_ITEMS];
+    const uint32_t left = (uint32_t)min<uint64_t>(end - t0, RXA_TILE);   // 32-bit tile-relative indices: fewer registers
+    const uint32_t* dt = d + t0;
 #pragma unroll
     for (int i = 0; i < RXA_ITEMS; i++) {
-      const uint64_t j = t0 + (uint64_t)i * RX_THREADS + tid;
-      v[i] = j < end ? d[j] : 0u;
+      const uint32_t j = (uint32_t)i * RX_THREADS + tid;
+      v[i] = j < left ? dt[j] : 0u;
     }
 #pragma unroll
     for (int i = 0; i < RXA_ITEMS; i++) {
       const uint32_t l = v[i] & 0x7FFFFFFFu;
       rk[i] = lds_rank_add(t_cnt, l ? (l - 1) >> RX_FINE_BITS : 0u, l != 0, hbits);
+      __builtin_amdgcn_sched_barrier(0);   // one ranking at a time: interleaved, the seven of them cost 16 more registers
     }
     __syncthreads();
     rx_scan_bins(t_start, t_cnt, Hn, lds_wave);
