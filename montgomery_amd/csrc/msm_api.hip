@@ -555,7 +555,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_vstart, (const uint32_t*)d_vtot, V);
     hipLaunchKernelGGL(k_radix_coarse, dim3(sortB, kc), dim3(RX_THREADS), 0, s, (uint32_t*)w.dig2.p, (uint32_t*)w.idx2.p,
                        (const uint32_t*)d_vstart, (const uint32_t*)d_blk_off, (const uint32_t*)w.dig.p, two_n, chunk, Hn, shift);
-    hipLaunchKernelGGL(k_radix_fine, dim3(V), dim3(RX_THREADS), 0, s, (uint32_t*)w.slots.p, (const uint32_t*)w.cursor.p,
+    hipLaunchKernelGGL(k_radix_fine, dim3(V), dim3(RXB_THREADS), 0, s, (uint32_t*)w.slots.p, (const uint32_t*)w.cursor.p,
                        (const uint32_t*)d_vstart, (const uint32_t*)w.dig2.p, (const uint32_t*)w.idx2.p, V);
   } else if (one_level) {
     hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.slots.p,

@@ -338,7 +338,10 @@ constexpr int RX_THREADS = 1024;
 #define RXA_WAVES 8   // pass A: two workgroups per CU (60 KB of LDS each) -- one loads its tile while the other ranks
 #endif
 constexpr int RXA_ITEMS = 7, RXA_TILE = RX_THREADS * RXA_ITEMS;    // pass A: 7168 records of 8 bytes staged per tile (56 KB)
-constexpr int RXB_ITEMS = 12, RXB_TILE = RX_THREADS * RXB_ITEMS;   // pass B: 12288 payloads + bucket bytes (60 KB)
+#ifndef RXB_THREADS
+#define RXB_THREADS 512   // pass B: 512-thread workgroups, two resident per CU (its ~108 VGPRs allow four waves per SIMD): one walks
+#endif                    // its virtual window's next tile in while the other ranks (1024 threads: one workgroup per CU, 2.46 ms)
+constexpr int RXB_ITEMS = 12, RXB_TILE = RXB_THREADS * RXB_ITEMS;   // payloads + bucket bytes staged per tile (30 KB)
 constexpr uint32_t RX_FINE_BITS = 7;
 
 // exclusive scan of `nbins` (<= 256) LDS counters by the first 256 threads; `tot` counters become `start`
@@ -440,12 +443,12 @@ __global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t
 }
 
 // pass B.  One block per virtual window v (heaviest -- the top window's few coarse bins -- first: v = V - 1 - blockIdx.x).
-__global__ void __launch_bounds__(RX_THREADS) k_radix_fine(uint32_t* slots, const uint32_t* cursor, const uint32_t* v_start,
+__global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, const uint32_t* cursor, const uint32_t* v_start,
                                                            const uint32_t* dig2, const uint32_t* idx2, uint32_t V) {
   constexpr uint32_t NB = 1u << RX_FINE_BITS;
   __shared__ uint32_t stage[RXB_TILE];
   __shared__ uint8_t stage_b[RXB_TILE];
-  __shared__ uint32_t t_cnt[NB], t_start[NB], g_cur[NB], lds_wave[RX_THREADS / 64];
+  __shared__ uint32_t t_cnt[NB], t_start[NB], g_cur[NB], lds_wave[RXB_THREADS / 64];
   const uint32_t v = V - 1 - blockIdx.x, tid = threadIdx.x;
   if (tid < NB) g_cur[tid] = cursor[(uint64_t)v * NB + tid];
   const uint64_t beg = v_start[v], end = v_start[v + 1];
@@ -455,7 +458,7 @@ __global__ void __launch_bounds__(RX_THREADS) k_radix_fine(uint32_t* slots, cons
     uint32_t dv[RXB_ITEMS], iv[RXB_ITEMS], rk[RXB_ITEMS];
 #pragma unroll
     for (int i = 0; i < RXB_ITEMS; i++) {
-      const uint64_t j = t0 + (uint64_t)i * RX_THREADS + tid;
+      const uint64_t j = t0 + (uint64_t)i * RXB_THREADS + tid;
       dv[i] = j < end ? dig2[j] : 0u;
       iv[i] = j < end ? idx2[j] : 0u;
     }
@@ -477,7 +480,7 @@ __global__ void __launch_bounds__(RX_THREADS) k_radix_fine(uint32_t* slots, cons
     }
     __syncthreads();
     const uint32_t n_tile = t_start[NB - 1] + t_cnt[NB - 1];
-    for (uint32_t i = tid; i < n_tile; i += RX_THREADS) {
+    for (uint32_t i = tid; i < n_tile; i += RXB_THREADS) {
       const uint32_t bk = stage_b[i];
       slots[g_cur[bk] + (i - t_start[bk])] = stage[i];
     }
