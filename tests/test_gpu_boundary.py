@@ -126,6 +126,37 @@ def test_device_list_context_on_one_gpu(gpu_ctx, lg):
     multi.close()
 
 
+def _sharded_bench(world, log2n):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--log2n", str(log2n), "--dist-backend", "gloo", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_four_and_eight_rank_window_shards_on_one_gpu(world):
+    """The driver's SCALE shapes (--gpus 4, --gpus 8: two windows / one window per rank at c = 16, K = 8), all ranks on the
+    one GPU of the box with gloo as the process group; rank 0 verifies the combined result against the discrete logs."""
+    d = _sharded_bench(world, 18)
+    assert d["n_gpus"] == world and d["verified"] is True, d
+    assert f"window-shard x{world}" in d["config"]["parallelism"]
+
+
 def test_two_rank_sharded_bench_in_child_processes():
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), here with both ranks on
     the one GPU of the box and gloo as the process group: every rank computes the window sums of its shard through the
