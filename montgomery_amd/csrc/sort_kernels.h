@@ -219,9 +219,18 @@ __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, con
   // waiting on single 256-byte wave loads: 1.2 ms per window group at 2^26, 1.75 TB/s); whole waves stay in both loops
   // (lds_rank_add ballots)
   uint64_t j0 = beg;
-  if (end > beg && ((reinterpret_cast<uintptr_t>(d + beg) & 15u) == 0)) {
-    const uint4* dv = reinterpret_cast<const uint4*>(d + beg);
-    const uint64_t nvec = (end - beg) / 4;
+  if (end > beg) {
+    // up to three entries in front of the first 16-byte boundary (odd N, odd slice starts)
+    const uint64_t head = min<uint64_t>(end - beg, (16u - (uint32_t)(reinterpret_cast<uintptr_t>(d + beg) & 15u)) % 16u / 4u);
+    if (head) {   // uniform: all lanes of the block take part (lds_rank_add ballots)
+      const uint32_t l = threadIdx.x < head ? d[beg + threadIdx.x] & 0x7FFFFFFFu : 0u;
+      (void)lds_rank_add(lds_hist, l ? (l - 1) >> shift : 0u, l != 0, agg_bits);
+      j0 = beg + head;
+    }
+  }
+  if (end > j0) {
+    const uint4* dv = reinterpret_cast<const uint4*>(d + j0);
+    const uint64_t nvec = (end - j0) / 4;
     for (uint64_t q0 = 0; q0 < nvec; q0 += 2 * SORT_THREADS) {
       const uint64_t qa = q0 + threadIdx.x, qb = qa + SORT_THREADS;
       const uint4 va = qa < nvec ? dv[qa] : make_uint4(0, 0, 0, 0);
@@ -233,7 +242,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, con
         (void)lds_rank_add(lds_hist, l ? (l - 1) >> shift : 0u, l != 0, agg_bits);
       }
     }
-    j0 = beg + nvec * 4;
+    j0 += nvec * 4;
   }
   for (; j0 < end; j0 += SORT_THREADS) {
     const uint64_t j = j0 + threadIdx.x;
