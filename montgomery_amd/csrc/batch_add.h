@@ -43,7 +43,11 @@ struct BatchArgs {
   uint32_t steps;
   const uint32_t* desc;     // MODE_SEARCH: operand descriptors from k_tail_desc
   uint64_t sstride;         // lanes per scratch plane (>= T; see ba_store_pre)
+  const uint16_t* oidx;     // MODE_GATHER, chunk-ordered pairs (k_chunk_order): pair e writes element (e & ~(CO_PAIRS - 1)) + oidx[e]
+  uint32_t* out_rows;       // MODE_GATHER: if set, results leave as 128-byte element rows [x | y | 0] (element k at byte 128 k) instead
+                            // of planes; a round with slots == nullptr reads such rows back (pair e = rows 2e, 2e + 1)
 };
+constexpr uint32_t CO_PAIRS = 4096;   // pairs per block of k_chunk_order (sort_kernels.h)
 
 constexpr int BA_THREADS = 256;
 // Phase fence: hipcc's scheduler otherwise interleaves independent multiplications of one step (inv * den with num * d,
@@ -164,7 +168,13 @@ template <>
 __device__ __forceinline__ void ba_locate<MODE_GATHER>(PairLoc<MODE_GATHER>& L, const BatchArgs& a, uint32_t i, uint64_t T, uint32_t t,
                                                         bool active) {
   uint2 pp = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-  if (active) pp = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.slots) + 8ull * i * T + 8u * t);
+  if (active) {
+    if (a.slots) pp = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.slots) + 8ull * i * T + 8u * t);
+    else {   // element rows written by the round before: element k is "entry" k of a row table, payload = k << 1
+      const uint32_t e4 = (uint32_t)(((uint64_t)i * T + t) << 2);
+      pp = make_uint2(e4, e4 + 2u);
+    }
+  }
   const bool aa = pp.x == 0xFFFFFFFFu, bb = pp.y == 0xFFFFFFFFu;
   // absent operands read row 0 (valid memory) and are then ignored: no divergent loads
 #ifdef BA_X_ROWMASK   // experiment: all gathers inside a 256 MB window of the table (wrong sums, timing of perfect locality)
@@ -400,6 +410,9 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
 #pragma unroll 1
     for (int i = (int)steps - 1; i >= 0; i--) {
       const bool active = is_active((uint32_t)i);
+      const uint64_t e_cur = (uint64_t)BA_STEP(i) * T + t;
+      uint32_t o_local = 0;
+      if (MODE == MODE_GATHER && a.oidx && active) o_local = a.oidx[e_cur];
       Fe<F> d, den, num;
       BA_MUL(d, inv, pre);                         // 1 / den_i
       BA_FENCE();
@@ -488,9 +501,25 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
       BA_FENCE();
       if (i > 0) ba_load_y<F, MODE>(y1, y2, Ln, a, t);   // the next pair's y: in flight during the stores and d = inv * pre
       if (!(kind & BA_SKIP)) {
+        if (MODE == MODE_GATHER && a.out_rows) {
+          // Uniform: chunk-ordered round 1.  The pair's element index comes from the table, and the element leaves as ONE whole
+          // 128-byte line: a permuted store of 16-byte plane pieces leaves every line partly written by several workgroups (on
+          // different XCDs), and the memory side then reads, merges and rewrites each of them (measured: round 1 68 -> 107 ms).
+          const uint64_t o = a.oidx ? (e_cur & ~(uint64_t)(CO_PAIRS - 1)) + o_local : e_cur;
+          uint4* row = reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.out_rows) + o * 128);
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            row[j] = make_uint4(x3.w[4 * j], x3.w[4 * j + 1], x3.w[4 * j + 2], x3.w[4 * j + 3]);
+            row[3 + j] = make_uint4(y3.w[4 * j], y3.w[4 * j + 1], y3.w[4 * j + 2], y3.w[4 * j + 3]);
+          }
+          row[6] = make_uint4(0, 0, 0, 0);
+          row[7] = make_uint4(0, 0, 0, 0);
+        } else
+        {
         char* ob = reinterpret_cast<char*>(a.out + (uint64_t)BA_STEP(i) * T);
         ba_store3(ob, 16u * t, a.out_cap * 16, x3);
         ba_store3(ob + 3 * a.out_cap * 16, 16u * t, a.out_cap * 16, y3);
+        }
       }
       x1 = nx1; x2 = nx2; pre = npre; L = Ln;
     }

@@ -175,13 +175,13 @@ struct msm_ctx {
   // window group runs under the ALU-bound accumulation of the other
   struct Workspace {
     DevBuf dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, columns2, rows_sum, bucket_proj, bufA, bufB,
-        scratch, columns, partials, part, dig2, idx2, block_hist2, blk_tab, blk_tab2;
+        scratch, columns, partials, part, dig2, idx2, idx3, blk_tab2, slots2, oidx, rows1;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     uint32_t* h_info = nullptr;   // pinned, 64 words
     uint32_t* h_part = nullptr;   // pinned, window sums read-back
-    DevBuf* all[23] = {&dig, &counts, &cursor, &tail_off, &info, &slots, &block_hist, &scan_partial, &desc, &columns2, &rows_sum,
-                       &bucket_proj, &bufA, &bufB, &scratch, &columns, &partials, &part, &dig2, &idx2, &block_hist2, &blk_tab, &blk_tab2};
+    DevBuf* all[25] = {&dig, &counts, &cursor, &tail_off, &info, &slots, &block_hist, &scan_partial, &desc, &columns2, &rows_sum,
+                       &bucket_proj, &bufA, &bufB, &scratch, &columns, &partials, &part, &dig2, &idx2, &idx3, &blk_tab2, &slots2, &oidx, &rows1};
   };
   static constexpr int N_WS = 2;
   Workspace ws[N_WS];
@@ -273,6 +273,7 @@ int pick_window(bool te, uint64_t n, int glv_max_bits) {
 
 struct Plan {
   int c, K, L_log;
+  int bits = 0;          // b + 1: scalar bits the windows cover (the top window holds bits - (K - 1) c of them)
   uint32_t L;
   bool no_glv;
   bool strict = false;   // msm_opts.strict: scalars >= q fail the call instead of being reduced
@@ -292,6 +293,7 @@ int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
   if (pl.no_glv && c < 4) return MSM_ERR_ARG;   // keeps K <= 64
   pl.c = c;
   pl.K = (b + 1 + c - 1) / c;  // K = ceil((b + 1) / c), src/msm-batched-affine.ts:90, src/msm-basic.ts:59
+  pl.bits = b + 1;
   pl.L_log = c - 1;
   pl.L = 1u << (c - 1);
   return MSM_OK;
@@ -407,26 +409,40 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   ctx->ensure(w.tail_off, (size_t)34 * (nb + 1) * 4);
   ctx->ensure(w.info, 64 * 4);
 
-  // sort path: LDS-privatised histogram/ranking.  One level when a window's counters fit the LDS (c <= 16), two
-  // levels (coarse bins of 2^15 buckets, then the same LDS sort per bin) up to c = 24, the largest window make_plan accepts.
-  // Sort path: LDS-privatised histogram / ranking.
+  // Sort path: LDS-privatised histogram / ranking, every pass staged through the LDS so that a wave store is a full segment
+  // (sort_kernels.h; a direct scatter sends each 4-byte payload to a line of its own: round 1 wrote 7.7x the algorithmic bytes).
   //   one level  : a window's counters fit the LDS (c <= 16) and the input is small
-  //   radix split: c <= 16, big inputs -- 2^(c-8) coarse bins x 128 buckets, both passes staged through the LDS so that
-  //                every wave store is a full segment (sort_kernels.h); the one-level scatter there sends each 4-byte
-  //                payload to a line of its own (round 1: 7.7x the algorithmic bytes written)
-  //   two levels : c > 16 (coarse bins of 2^15 buckets, then the LDS sort per bin), up to c = 24, the largest window
-  //                make_plan accepts
+  //   two passes : c <= 16, big inputs -- 2^(c-8) coarse bins x 128 buckets
+  //   three passes: c > 16 (up to c = 24, the largest window make_plan accepts) -- coarse bins x mid bins x 128 (256) buckets
+  const int cbits = pl.c - 1;   // bits of a bucket index
   const bool fits_lds = (size_t)L * 4 <= 128 * 1024;
-  long long want_radix = (fits_lds && pl.c - 1 > (int)RX_FINE_BITS && two_n >= (1ull << 22)) ? 1 : 0;   // measured: wins from N = 2^21 up
+  long long want_radix = (fits_lds && cbits > (int)RX_FINE_BITS && two_n >= (1ull << 22)) ? 1 : 0;   // measured: wins from N = 2^21 up
   MSM_KNOB(want_radix, "MSM_RADIX", 0);
-  const bool radix = fits_lds && want_radix && pl.c - 1 > (int)RX_FINE_BITS && pl.c - 1 - (int)RX_FINE_BITS <= 8;
+  const bool radix = fits_lds && want_radix && cbits > (int)RX_FINE_BITS && cbits - (int)RX_FINE_BITS <= 8;
   const bool one_level = fits_lds && !radix;
-  const bool two_level = !fits_lds;
-  const uint32_t fine_bits = two_level ? 15u : radix ? RX_FINE_BITS : 0u;   // bucket bits sorted by the second pass
-  const uint32_t shift = (two_level || radix) ? (uint32_t)(pl.c - 1) - fine_bits : 0;   // = log2 of the coarse bins
-  const uint32_t Hn = 1u << shift;                                    // coarse bins per window
-  const uint32_t L2 = two_level ? (1u << fine_bits) : L;              // buckets per (virtual) window of the old two-level path
-  const uint32_t V = (uint32_t)kc * Hn;                               // virtual windows
+  const bool three_pass = !fits_lds;
+  const uint32_t fb = three_pass ? (cbits >= 23 ? 8u : 7u) : RX_FINE_BITS;   // bucket bits sorted by the last pass (full windows)
+  const uint32_t shift = radix ? (uint32_t)cbits - fb : 0;                  // two passes: log2 of the coarse bins
+  const uint32_t Hn = 1u << shift;
+  const uint32_t Lp = three_pass ? 1u << ((uint32_t)cbits - fb) : Hn;        // fine windows (blocks of the last pass) per window
+  const uint32_t V = (uint32_t)kc * Lp;
+  WinSplit ws{};
+  if (three_pass) {
+    if (kc > 16) throw MsmFail{MSM_ERR_INTERNAL, "more than 16 windows in a group of a window size above 16"};
+    const int lp_log = cbits - (int)fb;
+    for (int kk = 0; kk < kc; kk++) {
+      // bits the digits of this window really have: the top window of a scalar is usually short (sort_kernels.h, WinSplit)
+      const int eff = std::max(1, std::min(cbits, pl.bits - (k_lo + kk) * pl.c));
+      const int fbk = std::max(0, eff - lp_log);
+      const int hi = eff - fbk;
+      ws.fb[kk] = (uint8_t)fbk;
+      ws.ab[kk] = (uint8_t)std::min(8, hi);
+      ws.mb[kk] = (uint8_t)(hi - ws.ab[kk]);
+    }
+  } else if (radix) {
+    if (kc > 16) throw MsmFail{MSM_ERR_INTERNAL, "more than 16 windows in a radix-split group"};
+    for (int kk = 0; kk < kc; kk++) { ws.ab[kk] = (uint8_t)shift; ws.fb[kk] = (uint8_t)fb; }
+  }
   uint32_t sortB = 1;
   uint64_t chunk = two_n;
   {
@@ -438,10 +454,11 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     uint64_t maxb = std::max<uint64_t>(1, two_n / 8192);
     sortB = (uint32_t)std::min<uint64_t>(want, maxb);
     chunk = (two_n + sortB - 1) / sortB;
-    ctx->ensure(w.block_hist, (size_t)kc * sortB * (two_level ? Hn : L) * 4 + 64);
+    ctx->ensure(w.block_hist, (size_t)kc * sortB * (three_pass ? Lp : L) * 4 + 64);
   }
-  uint64_t chunk2 = 0;      // second level: entries per block, number of active blocks
-  uint32_t n_active2 = 0;
+  const uint32_t* d_v2start = nullptr;   // three passes: starts of the fine windows in the record arrays
+  const uint32_t* d_rec_dig = nullptr;   // records read by the last pass
+  const uint32_t* d_rec_idx = nullptr;
 
   HIPCHK(hipEventRecord(w.ev[0], s));
   {
@@ -454,60 +471,39 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
                          pl.no_glv ? 0 : 1, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p);
   }
   HIPCHK(hipEventRecord(w.ev[1], s));
-  if (one_level || radix) {
+  if (!three_pass) {
     hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.block_hist.p,
-                       (const uint32_t*)w.dig.p, two_n, chunk, L, 0u, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
+                       (const uint32_t*)w.dig.p, two_n, chunk, L, ws, 0u, 0u);
     hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.block_hist.p,
-                       (uint32_t*)w.counts.p, sortB, L, (uint32_t)kc, (const uint32_t*)nullptr);
+                       (uint32_t*)w.counts.p, sortB, L, (uint32_t)kc);
   } else {
-    // level 1: coarse histogram -> partition offsets (host scan of V counters) -> partitioned (digit, entry) arrays
-    ctx->ensure(w.part, (size_t)(2 * V + 2) * 4);
-    uint32_t* d_cnt = (uint32_t*)w.part.p;            // V coarse counts
-    uint32_t* d_part = (uint32_t*)w.part.p + V;       // V + 1 partition starts
-    hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)Hn * 4, s, (uint32_t*)w.block_hist.p,
-                       (const uint32_t*)w.dig.p, two_n, chunk, Hn, fine_bits, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
-    hipLaunchKernelGGL(k_colscan, dim3((V + 255) / 256), dim3(256), 0, s, (uint32_t*)w.block_hist.p, d_cnt, sortB, Hn,
-                       (uint32_t)kc, (const uint32_t*)nullptr);
-    std::vector<uint32_t> h_cnt(V), h_part(V + 1);
-    HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)V * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    // partition starts, and the table of active (partition, block) pairs of the second level: partitions differ a lot
-    // in size (the top window has few, heavy coarse bins), so blocks are enumerated, not laid out on a 2-D grid
-    chunk2 = 1ull << 20;
-    uint64_t run = 0;
-    std::vector<uint32_t> h_tab, h_rows(V + 1);
-    uint32_t nrows = 0;
-    for (uint32_t v = 0; v < V; v++) {
-      h_part[v] = (uint32_t)run;
-      run += h_cnt[v];
-      h_rows[v] = nrows;
-      uint32_t bv = (uint32_t)((h_cnt[v] + chunk2 - 1) / chunk2);
-      for (uint32_t b = 0; b < bv; b++) { h_tab.push_back(v); h_tab.push_back(b); h_tab.push_back(nrows); }
-      nrows += bv;
-    }
-    h_part[V] = (uint32_t)run;
-    h_rows[V] = nrows;
-    n_active2 = nrows;
-    ctx->ensure(w.blk_tab, (size_t)(h_tab.size() + V + 2) * 4 + 16);
-    uint32_t* d_tab = (uint32_t*)w.blk_tab.p;
-    uint32_t* d_rows = d_tab + h_tab.size();
-    HIPCHK(hipMemcpyAsync(d_part, h_part.data(), (size_t)(V + 1) * 4, hipMemcpyHostToDevice, s));
-    if (!h_tab.empty()) HIPCHK(hipMemcpyAsync(d_tab, h_tab.data(), h_tab.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_rows, h_rows.data(), (size_t)(V + 1) * 4, hipMemcpyHostToDevice, s));
-    ctx->ensure(w.dig2, std::max<uint64_t>(run, 1) * 4);
-    ctx->ensure(w.idx2, std::max<uint64_t>(run, 1) * 4);
-    hipLaunchKernelGGL(k_scatter_coarse, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)Hn * 4, s, (uint32_t*)w.dig2.p,
-                       (uint32_t*)w.idx2.p, (const uint32_t*)d_part, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p,
-                       two_n, chunk, Hn, fine_bits, 0u);
-    // level 2: LDS sort of every coarse bin (a "virtual window" of 2^fine_bits buckets)
-    ctx->ensure(w.block_hist2, (size_t)std::max<uint32_t>(nrows, 1) * L2 * 4);
+    // totals of the fine windows -> their starts (= the starts of the mid and coarse bins too); pass A; pass M; bucket sizes
+    const size_t n_off = (size_t)kc * sortB * 256;
+    ctx->ensure(w.part, ((size_t)2 * V + 2 + n_off) * 4);
+    uint32_t* d_v2tot = (uint32_t*)w.part.p;
+    uint32_t* d_vs = d_v2tot + V;
+    uint32_t* d_blk_off = d_vs + V + 1;
+    ctx->ensure(w.dig2, n_entries * 4);
+    ctx->ensure(w.idx2, n_entries * 4);
+    ctx->ensure(w.idx3, n_entries * 4);
+    hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)Lp * 4, s, (uint32_t*)w.block_hist.p,
+                       (const uint32_t*)w.dig.p, two_n, chunk, Lp, ws, 1u, 0u);
+    hipLaunchKernelGGL(k_colscan, dim3((V + 255) / 256), dim3(256), 0, s, (uint32_t*)w.block_hist.p, d_v2tot, sortB, Lp,
+                       (uint32_t)kc);
+    hipLaunchKernelGGL(k_coarse_offsets3, dim3((uint32_t)((n_off + 255) / 256)), dim3(256), 0, s, d_blk_off,
+                       (const uint32_t*)w.block_hist.p, sortB, Lp, (uint32_t)kc, ws);
+    hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_vs, (const uint32_t*)d_v2tot, V);
+    hipLaunchKernelGGL(k_radix_coarse, dim3(sortB, kc), dim3(RX_THREADS), 0, s, (uint32_t*)w.dig2.p, (uint32_t*)w.idx2.p,
+                       (const uint32_t*)d_vs, (const uint32_t*)d_blk_off, (const uint32_t*)w.dig.p, two_n, chunk, Lp, 256u, ws);
+    // the digits are dead now: the second record array reuses their buffer
+    hipLaunchKernelGGL(k_radix_mid, dim3(256, kc), dim3(RXB_THREADS), 0, s, (uint32_t*)w.dig.p, (uint32_t*)w.idx3.p,
+                       (const uint32_t*)d_vs, (const uint32_t*)w.dig2.p, (const uint32_t*)w.idx2.p, Lp, ws);
     HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));
-    if (nrows)
-      hipLaunchKernelGGL(k_hist, dim3(nrows), dim3(SORT_THREADS), (size_t)L2 * 4, s, (uint32_t*)w.block_hist2.p,
-                         (const uint32_t*)w.dig2.p, (uint64_t)0, chunk2, L2, 0u, (const uint32_t*)d_part, (const uint32_t*)d_tab, 0u);
-    hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.block_hist2.p,
-                       (uint32_t*)w.counts.p, 0u, L2, V, (const uint32_t*)d_rows);
-    HIPCHK(hipStreamSynchronize(s));   // host tables must outlive their copies
+    hipLaunchKernelGGL(k_fine_hist, dim3(V), dim3(256), 0, s, (uint32_t*)w.counts.p, (const uint32_t*)d_vs,
+                       (const uint32_t*)w.dig.p, Lp, L, ws);
+    d_v2start = d_vs;
+    d_rec_dig = (const uint32_t*)w.dig.p;
+    d_rec_idx = (const uint32_t*)w.idx3.p;
   }
   int RT = 0;
   uint64_t total_slots = 0;
@@ -554,17 +550,42 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
                        (const uint32_t*)w.block_hist.p, (const uint32_t*)w.counts.p, sortB, L, Hn, (uint32_t)kc);
     hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_vstart, (const uint32_t*)d_vtot, V);
     hipLaunchKernelGGL(k_radix_coarse, dim3(sortB, kc), dim3(RX_THREADS), 0, s, (uint32_t*)w.dig2.p, (uint32_t*)w.idx2.p,
-                       (const uint32_t*)d_vstart, (const uint32_t*)d_blk_off, (const uint32_t*)w.dig.p, two_n, chunk, Hn, shift);
+                       (const uint32_t*)d_vstart, (const uint32_t*)d_blk_off, (const uint32_t*)w.dig.p, two_n, chunk, Hn, Hn, ws);
     hipLaunchKernelGGL(k_radix_fine, dim3(V), dim3(RXB_THREADS), 0, s, (uint32_t*)w.slots.p, (const uint32_t*)w.cursor.p,
-                       (const uint32_t*)d_vstart, (const uint32_t*)w.dig2.p, (const uint32_t*)w.idx2.p, V);
+                       (const uint32_t*)d_vstart, (const uint32_t*)w.dig2.p, (const uint32_t*)w.idx2.p, Lp, L, ws);
   } else if (one_level) {
     hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.slots.p,
                        (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n,
-                       chunk, L, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
-  } else if (n_active2) {
-    hipLaunchKernelGGL(k_scatter_lds, dim3(n_active2), dim3(SORT_THREADS), (size_t)L2 * 4, s, (uint32_t*)w.slots.p,
-                       (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist2.p, (const uint32_t*)w.dig2.p, (uint64_t)0,
-                       chunk2, L2, (const uint32_t*)w.part.p + V, (const uint32_t*)w.idx2.p, (const uint32_t*)w.blk_tab.p, 0u);
+                       chunk, L, 0u);
+  } else {
+    hipLaunchKernelGGL(k_radix_fine, dim3(V), dim3(RXB_THREADS), 0, s, (uint32_t*)w.slots.p, (const uint32_t*)w.cursor.p,
+                       d_v2start, d_rec_dig, d_rec_idx, Lp, L, ws);
+  }
+  // Big windows over a big table: walk round 1 chunk by chunk of the point rows (k_chunk_order, sort_kernels.h).  Needed once
+  // the 128 slots of a wave span more than ~1 GB of rows: 64 L rows of 256 bytes, i.e. from c = 18 with more than 2^22 points.
+  const uint32_t* round1_slots = (const uint32_t*)w.slots.p;
+  const uint16_t* round1_oidx = nullptr;
+  bool chunked = false;   // round 1 walks chunk-ordered pairs and writes element rows, round 2 reads them
+  {
+    long long chunk_rows_log = 22;   // 2^22 rows of 256 bytes = 1 GB
+    MSM_KNOB(chunk_rows_log, "MSM_CHUNK_LOG", 10);
+    long long want_chunks = (!te && pl.c >= 18 && n > (1ull << chunk_rows_log)) ? 1 : 0;
+    MSM_KNOB(want_chunks, "MSM_CHUNKED", 0);
+    const uint64_t nch = (n + (1ull << chunk_rows_log) - 1) >> chunk_rows_log;
+    // (round 2 must be an index-free round to read the element rows round 1 then writes: logG >= 2)
+    if (want_chunks && !te && logG >= 2 && total_slots >= 2 && nch >= 2 && nch + 1 <= (uint64_t)CO_MAX_KEYS) {
+      const uint64_t n_pairs = total_slots / 2;
+      ctx->ensure(w.slots2, total_slots * 4);
+      ctx->ensure(w.oidx, n_pairs * 2);
+      ctx->ensure(w.rows1, n_pairs * 128 + 256);
+      hipLaunchKernelGGL(k_chunk_order, dim3((uint32_t)((n_pairs + CO_PAIRS - 1) / CO_PAIRS)), dim3(CO_THREADS), 0, s,
+                         (uint2*)w.slots2.p, (uint16_t*)w.oidx.p, (const uint2*)w.slots.p, n_pairs, (uint32_t)chunk_rows_log,
+                         (uint32_t)nch + 1);
+      round1_slots = (const uint32_t*)w.slots2.p;
+      round1_oidx = (const uint16_t*)w.oidx.p;
+      if (MSM_KNOB_SET("MSM_CHUNK_NOSTORE")) round1_oidx = nullptr;   // experiment (wrong sums): chunk-ordered loads, natural stores
+      chunked = true;
+    }
   }
   HIPCHK(hipEventRecord(w.ev[2], s));
 
@@ -594,6 +615,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     uint64_t cnt = total_slots;
     for (uint32_t r = 1; r <= logG; r++) {
       cnt /= 2;
+      if (r == 1 && chunked) continue;   // element rows (w.rows1), not planes
       (which ? capB : capA) = std::max<uint64_t>(which ? capB : capA, cnt);
       which ^= 1;
     }
@@ -619,12 +641,13 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   if (total_slots > 0) {
     for (uint32_t r = 1; r <= logG; r++) {
       uint64_t n_out = n_in / 2;
-      RoundGeom g = round_geom(ctx, n_out, r == 1 || te, lone);   // no inversion on the Edwards path: always two waves
+      RoundGeom g = round_geom(ctx, n_out, r == 1 || (r == 2 && chunked) || te, lone);   // no inversion on the Edwards path: always two waves
       const uint64_t sstride = g.T + scratch_pad;
       if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * sstride * 4);
       BatchArgs a{};
       a.points = (const uint32_t*)ctx->rows.p + p_lo * (te ? (uint64_t)te::TE_ROW_WORDS : (uint64_t)ROW_WORDS);
-      a.slots = (const uint32_t*)w.slots.p;
+      a.slots = r == 1 ? round1_slots : (const uint32_t*)w.slots.p;
+      a.oidx = r == 1 ? round1_oidx : nullptr;
       a.in = buf[cur ^ 1];
       a.in_cap = cap[cur ^ 1];
       a.out = buf[cur];
@@ -633,20 +656,24 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       a.sstride = sstride;
       a.n_out = n_out;
       a.steps = g.steps;
-      if (r == 1) {
+      const bool rows_out = r == 1 && chunked, rows_in = r == 2 && chunked;
+      if (rows_out) a.out_rows = (uint32_t*)w.rows1.p;
+      if (rows_in) { a.points = (const uint32_t*)w.rows1.p; a.slots = nullptr; }
+      if (r == 1 || rows_in) {
         if (te) hipLaunchKernelGGL(te::k_te_add<MODE_GATHER>, dim3(g.grid), dim3(256), 0, s, a);
         else W_LAUNCH_MODE(ctx, k_batch_add, MODE_GATHER, dim3(g.grid), dim3(256), 0, s, a);
-        HIPCHK(hipEventRecord(w.ev[6], s));
+        if (r == 1) HIPCHK(hipEventRecord(w.ev[6], s));
       } else {
         if (te) hipLaunchKernelGGL(te::k_te_add<MODE_REGULAR>, dim3(g.grid), dim3(256), 0, s, a);
         else W_LAUNCH_MODE(ctx, k_batch_add, MODE_REGULAR, dim3(g.grid), dim3(256), 0, s, a);
       }
       st.n_pairs += n_out;
+      n_in = n_out;
+      round++;
+      if (rows_out) continue;   // the plane buffers have not been touched yet
       fin = buf[cur];
       fin_cap = cap[cur];
       cur ^= 1;
-      n_in = n_out;
-      round++;
     }
     for (int r = 1; r <= r_stop; r++) {
       uint64_t n_out = w.h_info[3 + r];
@@ -802,9 +829,16 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
 
 // how many windows fit one group under the workspace budget
 int windows_per_group(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
-  // per window: digits 8n, slots ~8n(+pad), bufA ~ n*96, bufB ~ n*48, scratch ~ n*52
-  long double per = ctx->is_te() ? (long double)n * (4 + 5 + 64 + 32) + (long double)pl.L * 4 * 40
-                                 : (long double)n * (8 + 9 + 96 + 48 + 56) + (long double)pl.L * 4 * 40;
+  // bytes per window and point (Weierstrass: 2 entries per point): digits 8, record arrays of the radix passes 16 (+ 8 for the
+  // third pass of windows above 2^15 buckets), slots ~9, tree buffers 96 + 48, prefix scratch 56; a chunk-ordered round 1
+  // (c >= 18) adds its reordered slots, the index table and the 128-byte element rows, and its plane buffers start one round
+  // later.  Per window and bucket: counters, cursors, up to 34 offset tables, and the block histograms of the sort.
+  const bool te = ctx->is_te();
+  const bool big = pl.c > 16;
+  long double per_point = te ? (4 + 8 + 5 + 64 + 32) : (8 + 16 + 9 + 96 + 48 + 56);
+  if (big && !te) per_point += 8 + 9 + 2 + 128 - 72;
+  const long double hist_bins = big ? (long double)(pl.L >> 7) : (long double)pl.L;
+  long double per = (long double)n * per_point + (long double)pl.L * 4 * 40 + hist_bins * 4 * (2.0L * ctx->n_cu);
   int w = (int)std::max<long double>(1, (long double)ctx->ws_budget / msm_ctx::N_WS / per);
   return std::min(w, pl.K);
 }

@@ -1,5 +1,6 @@
-// Curve-independent kernels of the MSM pipeline: bucket-size scans, the LDS-privatised counting sort (one level for
-// c <= 16, two levels up to the largest accepted window c = 24) and the operand descriptors of the tail rounds.
+// Curve-independent kernels of the MSM pipeline: bucket-size scans, the LDS-privatised counting sort (one level for small
+// inputs, LDS-staged two-pass split for c <= 16, three-pass split up to the largest accepted window c = 24) and the operand
+// descriptors of the tail rounds.
 // (reference phases: integrateBucketCounts src/msm-batched-affine.ts:423-447, sortPoints :456-502)
 // Included by msm_api.hip only; the curve-templated kernels live in msm_kernels.h.
 #pragma once
@@ -164,6 +165,17 @@ __global__ void __launch_bounds__(256) k_tail_desc(uint32_t* desc, const uint32_
 
 constexpr int SORT_THREADS = 1024;
 
+// How window kk's bucket index (l - 1) is cut for the LDS-staged passes: | ab coarse bits | mb mid bits | fb fine bits |.
+// Two-pass split (c <= 16): mb = 0, fb = 7.  Three-pass split (c > 16): the cut is made on the window's EFFECTIVE bits -- the
+// top window of a scalar usually holds fewer than c - 1 bits, its digits then fill only the low end of the bucket range, and
+// with a fixed cut all of them would land in a handful of coarse bins and fine windows (= blocks of the later passes).  A
+// window of eff bits keeps as many fine windows as a full one has (2^(c-1-7), fewer buckets each: fb = eff - (c - 1 - 7), 0
+// if there are not even that many buckets), ab <= 8 of the bits above them are the coarse bins, mb the rest.
+struct WinSplit {
+  uint8_t ab[16], mb[16], fb[16];
+};
+
+
 // Ranking with few bins (<= 256, `bits` = log2 of their number): the 64 lanes of a wave then mostly hit the same LDS
 // counters and per-lane atomics serialise (round 1 measured the 128-bin pass slower than the 32768-bin one for exactly
 // this reason).  Here the lanes of a wave that share a bin find each other with one ballot per bin bit, the lowest of
@@ -186,35 +198,19 @@ __device__ __forceinline__ uint32_t lds_rank_add(uint32_t* lds, uint32_t bin, bo
   return base + rank;
 }
 
-// part_start == nullptr: window kk owns digits dig[kk * two_n ..) and block b the slice [b * chunk, (b+1) * chunk).
-// part_start != nullptr (second level of the two-level sort): "window" kk is the partition
-// [part_start[kk], part_start[kk + 1]) of a flat digit array.  bin = (l - 1) >> shift (shift > 0: coarse level).
-// blk_tab != nullptr (with part_start): 1-D grid over the ACTIVE (partition, block) pairs listed in blk_tab as
-// (kk, b, first histogram row of kk); partitions differ 50x in size, idle blocks would dominate otherwise.
+// Window kk owns digits dig[kk * two_n ..) and block b the slice [b * chunk, (b+1) * chunk); L = number of bins;
+// bin = l - 1, or (l - 1) >> ws.fb[kk] with fine_windows set (the three-pass split counts its fine windows).
 __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, const uint32_t* dig, uint64_t two_n,
-                                                       uint64_t chunk, uint32_t L, uint32_t shift,
-                                                       const uint32_t* part_start, const uint32_t* blk_tab, uint32_t agg_bits) {
+                                                       uint64_t chunk, uint32_t L, WinSplit ws, uint32_t fine_windows,
+                                                       uint32_t agg_bits) {
   extern __shared__ uint32_t lds_hist[];
-  uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
-  uint64_t hist_row = (uint64_t)kk * B + b;
-  if (blk_tab) {
-    kk = blk_tab[3 * blockIdx.x];
-    b = blk_tab[3 * blockIdx.x + 1];
-    hist_row = (uint64_t)blk_tab[3 * blockIdx.x + 2] + b;
-  }
+  const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
+  const uint32_t shift = fine_windows ? ws.fb[kk] : 0u;
+  const uint64_t hist_row = (uint64_t)kk * B + b;
   for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) lds_hist[l] = 0;
   __syncthreads();
-  uint64_t beg, end;
-  const uint32_t* d;
-  if (part_start) {
-    beg = (uint64_t)part_start[kk] + (uint64_t)b * chunk;
-    end = min(beg + chunk, (uint64_t)part_start[kk + 1]);
-    d = dig;
-  } else {
-    beg = (uint64_t)b * chunk;
-    end = min(beg + chunk, two_n);
-    d = dig + (uint64_t)kk * two_n;
-  }
+  const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
+  const uint32_t* d = dig + (uint64_t)kk * two_n;
   // 16-byte loads, two per thread and trip, while the slice allows it (one dword per thread and trip left the kernel
   // waiting on single 256-byte wave loads: 1.2 ms per window group at 2^26, 1.75 TB/s); whole waves stay in both loops
   // (lds_rank_add ballots)
@@ -254,17 +250,11 @@ __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, con
   for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) out[l] = lds_hist[l];
 }
 
-// row_tab != nullptr: partition kk owns histogram rows [row_tab[kk], row_tab[kk + 1]) (variable block counts)
-__global__ void __launch_bounds__(256) k_colscan(uint32_t* block_hist, uint32_t* counts, uint32_t B, uint32_t L,
-                                                 uint32_t k_cnt, const uint32_t* row_tab) {
+__global__ void __launch_bounds__(256) k_colscan(uint32_t* block_hist, uint32_t* counts, uint32_t B, uint32_t L, uint32_t k_cnt) {
   uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= (uint64_t)k_cnt * L) return;
   uint32_t kk = (uint32_t)(id / L), l = (uint32_t)(id - (uint64_t)kk * L);
   uint32_t* p = block_hist + (uint64_t)kk * B * L + l;
-  if (row_tab) {
-    p = block_hist + (uint64_t)row_tab[kk] * L + l;
-    B = row_tab[kk + 1] - row_tab[kk];
-  }
   uint32_t run = 0, b = 0;
   for (; b + 8 <= B; b += 8) {   // eight loads in flight per thread (one at a time made this a chain of B latencies)
     uint32_t v[8];
@@ -283,41 +273,21 @@ __global__ void __launch_bounds__(256) k_colscan(uint32_t* block_hist, uint32_t*
 
 __global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(uint32_t* slots, const uint32_t* cursor,
                                                               const uint32_t* block_hist, const uint32_t* dig,
-                                                              uint64_t two_n, uint64_t chunk, uint32_t L,
-                                                              const uint32_t* part_start, const uint32_t* idx,
-                                                              const uint32_t* blk_tab, uint32_t agg_bits) {
+                                                              uint64_t two_n, uint64_t chunk, uint32_t L, uint32_t agg_bits) {
   extern __shared__ uint32_t lds_pos[];
-  uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
-  uint64_t hist_row = (uint64_t)kk * B + b;
-  if (blk_tab) {
-    kk = blk_tab[3 * blockIdx.x];
-    b = blk_tab[3 * blockIdx.x + 1];
-    hist_row = (uint64_t)blk_tab[3 * blockIdx.x + 2] + b;
-  }
-  const uint32_t* base = block_hist + hist_row * L;
+  const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
+  const uint32_t* base = block_hist + ((uint64_t)kk * B + b) * L;
   const uint32_t* cur = cursor + (uint64_t)kk * L;
   for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) lds_pos[l] = cur[l] + base[l];
   __syncthreads();
-  uint64_t beg, end;
-  const uint32_t* d;
-  if (part_start) {
-    beg = (uint64_t)part_start[kk] + (uint64_t)b * chunk;
-    end = min(beg + chunk, (uint64_t)part_start[kk + 1]);
-    d = dig;
-  } else {
-    beg = (uint64_t)b * chunk;
-    end = min(beg + chunk, two_n);
-    d = dig + (uint64_t)kk * two_n;
-  }
+  const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
+  const uint32_t* d = dig + (uint64_t)kk * two_n;
   for (uint64_t j0 = beg; j0 < end; j0 += SORT_THREADS) {
     const uint64_t j = j0 + threadIdx.x;
     const uint32_t v = j < end ? d[j] : 0u;
     const uint32_t l = v & 0x7FFFFFFFu;
     const uint32_t pos = lds_rank_add(lds_pos, l ? l - 1 : 0u, l != 0, agg_bits);
-    if (l) {
-      uint32_t entry = idx ? idx[j] : (uint32_t)j;
-      slots[pos] = (entry << 1) | (v >> 31);
-    }
+    if (l) slots[pos] = ((uint32_t)j << 1) | (v >> 31);
   }
 }
 
@@ -397,17 +367,19 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_vscan(uint32_t* v_start, const
   if (threadIdx.x == 0) v_start[V] = carry;
 }
 
-// pass A.  grid (B, kc); block (b, kk) owns entries [b * chunk, (b + 1) * chunk) of window kk.
+// pass A.  grid (B, kc); block (b, kk) owns entries [b * chunk, (b + 1) * chunk) of window kk.  Coarse bin h of window kk
+// starts at v_start[kk * vs_stride + (h << mb)]; this block's share of it at + blk_off[(kk * B + b) * bo_stride + h].
 __global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t* dig2, uint32_t* idx2, const uint32_t* v_start,
                                                              const uint32_t* blk_off, const uint32_t* dig, uint64_t two_n,
-                                                             uint64_t chunk, uint32_t Hn, uint32_t hbits) {
+                                                             uint64_t chunk, uint32_t vs_stride, uint32_t bo_stride, WinSplit ws) {
   __shared__ uint2 stage[RXA_TILE];
   __shared__ uint32_t t_cnt[256], t_start[256], g_base[256], lds_wave[RX_THREADS / 64];
   const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x, tid = threadIdx.x;
-  if (tid < Hn) g_base[tid] = v_start[(uint64_t)kk * Hn + tid] + blk_off[((uint64_t)kk * B + b) * Hn + tid];
+  const uint32_t hbits = ws.ab[kk], mb = ws.mb[kk], Hn = 1u << hbits, low_bits = ws.fb[kk] + mb;
+  if (tid < Hn) g_base[tid] = v_start[(uint64_t)kk * vs_stride + ((uint64_t)tid << mb)] + blk_off[((uint64_t)kk * B + b) * bo_stride + tid];
   const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
   const uint32_t* d = dig + (uint64_t)kk * two_n;
-  const uint32_t lo_mask = (1u << RX_FINE_BITS) - 1;
+  const uint32_t lo_mask = (1u << low_bits) - 1;
   for (uint64_t t0 = beg; t0 < end; t0 += RXA_TILE) {
     if (tid < 256) t_cnt[tid] = 0;
     __syncthreads();
@@ -422,7 +394,7 @@ __global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t
 #pragma unroll
     for (int i = 0; i < RXA_ITEMS; i++) {
       const uint32_t l = v[i] & 0x7FFFFFFFu;
-      rk[i] = lds_rank_add(t_cnt, l ? (l - 1) >> RX_FINE_BITS : 0u, l != 0, hbits);
+      rk[i] = lds_rank_add(t_cnt, l ? (l - 1) >> low_bits : 0u, l != 0, hbits ? hbits : 1u);   // 0 bits would mean per-lane atomics
       __builtin_amdgcn_sched_barrier(0);   // one ranking at a time: interleaved, the seven of them cost 16 more registers
     }
     __syncthreads();
@@ -431,8 +403,8 @@ __global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t
     for (int i = 0; i < RXA_ITEMS; i++) {
       const uint32_t l = v[i] & 0x7FFFFFFFu;
       if (l) {
-        const uint32_t h = (l - 1) >> RX_FINE_BITS;
-        // record: fine digit + 1 (so 0 still means "no entry") | coarse bin << 16 (stripped on the way out) | sign
+        const uint32_t h = (l - 1) >> low_bits;
+        // record: low bits + 1 (so 0 still means "no entry"; <= 2^15) | coarse bin << 16 (stripped on the way out) | sign
         stage[t_start[h] + rk[i]] = make_uint2((((l - 1) & lo_mask) + 1) | (h << 16) | (v[i] & 0x80000000u),
                                                (uint32_t)(t0 + (uint64_t)i * RX_THREADS + tid));
       }
@@ -451,16 +423,38 @@ __global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t
   }
 }
 
-// pass B.  One block per virtual window v (heaviest -- the top window's few coarse bins -- first: v = V - 1 - blockIdx.x).
+// pass B.  One block per fine window: block v = kk * Lp + f owns the 2^fb buckets from f << fb of window kk (heaviest -- the
+// top window's few coarse bins on the two-pass path -- first: v = V - 1 - blockIdx.x).  Records: (bucket's low fb bits) + 1 |
+// sign << 31, entry index.  A window with fb = 0 has one bucket per fine window and possibly very few of them (a top window
+// of a handful of bits): ranking is the identity there, and all Lp blocks of the window copy an equal slice of its records.
 __global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, const uint32_t* cursor, const uint32_t* v_start,
-                                                           const uint32_t* dig2, const uint32_t* idx2, uint32_t V) {
-  constexpr uint32_t NB = 1u << RX_FINE_BITS;
+                                                           const uint32_t* dig2, const uint32_t* idx2, uint32_t Lp, uint32_t L,
+                                                           WinSplit ws) {
+  constexpr uint32_t NBMAX = 256;
   __shared__ uint32_t stage[RXB_TILE];
   __shared__ uint8_t stage_b[RXB_TILE];
-  __shared__ uint32_t t_cnt[NB], t_start[NB], g_cur[NB], lds_wave[RXB_THREADS / 64];
-  const uint32_t v = V - 1 - blockIdx.x, tid = threadIdx.x;
-  if (tid < NB) g_cur[tid] = cursor[(uint64_t)v * NB + tid];
+  __shared__ uint32_t t_cnt[NBMAX], t_start[NBMAX], g_cur[NBMAX], lds_wave[RXB_THREADS / 64];
+  const uint32_t v = gridDim.x - 1 - blockIdx.x, tid = threadIdx.x;
+  const uint32_t kk = v / Lp, f = v - kk * Lp;
+  const uint32_t fbits = ws.fb[kk], NB = 1u << fbits;
+  if (fbits == 0) {
+    const uint32_t nfw = 1u << (ws.ab[kk] + ws.mb[kk]);          // fine windows (= buckets) in use
+    const uint32_t* vs = v_start + (uint64_t)kk * Lp;
+    const uint64_t wbeg = vs[0], wlen = (uint64_t)vs[nfw] - wbeg;
+    const uint64_t beg = wbeg + wlen * f / Lp, end = wbeg + wlen * (f + 1) / Lp;
+    for (uint64_t j = beg + tid; j < end; j += RXB_THREADS) {
+      uint32_t lo = 0, hi = nfw;                                  // bucket of record j: last fine window starting at or before it
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (vs[mid] <= j) lo = mid; else hi = mid;
+      }
+      slots[cursor[(uint64_t)kk * L + lo] + (uint32_t)(j - vs[lo])] = (idx2[j] << 1) | (dig2[j] >> 31);
+    }
+    return;
+  }
   const uint64_t beg = v_start[v], end = v_start[v + 1];
+  if (beg == end) return;
+  if (tid < NB) g_cur[tid] = cursor[(uint64_t)kk * L + ((uint64_t)f << fbits) + tid];
   for (uint64_t t0 = beg; t0 < end; t0 += RXB_TILE) {
     if (tid < NB) t_cnt[tid] = 0;
     __syncthreads();
@@ -474,7 +468,7 @@ __global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, con
 #pragma unroll
     for (int i = 0; i < RXB_ITEMS; i++) {
       const uint32_t l = dv[i] & 0xFFFFu;
-      rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0, RX_FINE_BITS);
+      rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0, fbits);
     }
     __syncthreads();
     rx_scan_bins(t_start, t_cnt, NB, lds_wave);
@@ -498,36 +492,194 @@ __global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, con
   }
 }
 
-// First level of the two-level sort: entries of window kk are partitioned by the high bits of their bucket index into
-// Hn = L >> shift coarse bins (windows with more than 2^15 buckets, c > 16: shift = 15; big inputs at c <= 16: shift = 7,
-// i.e. 256 coarse bins x 128 buckets, both passes writing long sequential runs) (k_hist with the same shift and
-// k_colscan provide the offsets); the entry keeps its low 15 bits (+1, so 0 still means "no entry"), its sign and
-// its entry index in two flat arrays.  Every block writes Hn sequential streams, which the L2 can merge -- the
-// direct scatter over 2^21 buckets could not.  The second level is the ordinary LDS sort per coarse bin.
-__global__ void __launch_bounds__(SORT_THREADS) k_scatter_coarse(uint32_t* dig2, uint32_t* idx2, const uint32_t* part_start,
-                                                                 const uint32_t* block_hist, const uint32_t* dig,
-                                                                 uint64_t two_n, uint64_t chunk, uint32_t Hn, uint32_t shift,
-                                                                 uint32_t agg_bits) {
-  extern __shared__ uint32_t lds_pos[];
-  const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
-  const uint32_t* base = block_hist + ((uint64_t)kk * B + b) * Hn;
-  for (uint32_t h = threadIdx.x; h < Hn; h += SORT_THREADS) lds_pos[h] = part_start[kk * Hn + h] + base[h];
-  __syncthreads();
-  const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
-  const uint32_t* d = dig + (uint64_t)kk * two_n;
-  const uint32_t lo_mask = (1u << shift) - 1;
-  for (uint64_t j0 = beg; j0 < end; j0 += SORT_THREADS) {
-    const uint64_t j = j0 + threadIdx.x;
-    const uint32_t v = j < end ? d[j] : 0u;
-    const uint32_t l = v & 0x7FFFFFFFu;
-    const uint32_t pos = lds_rank_add(lds_pos, l ? (l - 1) >> shift : 0u, l != 0, agg_bits);
-    if (l) {
-      dig2[pos] = (((l - 1) & lo_mask) + 1) | (v & 0x80000000u);
-      idx2[pos] = (uint32_t)j;
+// ---------------------------------------------------------------------------------------------
+// Three-pass split for windows of more than 2^15 buckets (c > 16), where one window's counters no longer fit the LDS.
+//   k_hist (shift = fb)    : per block the histogram over the 2^(c-1-fb) groups of 2^fb buckets ("fine windows")
+//   k_colscan, k_vscan     : totals per fine window -> v2_start (these are also the starts of the mid and coarse bins)
+//   k_coarse_offsets3      : per (window, block, coarse bin) the block's first position in the bin
+//   k_radix_coarse         : pass A by the top ab bits -> (dig2, idx2), records keep mb + fb low bits
+//   k_radix_mid            : pass M, one block per coarse bin, by the next mb bits -> (dig3, idx3), records keep fb bits
+//   k_fine_hist            : bucket sizes, one block per fine window (the scans of the padded slot offsets need them)
+//   k_radix_fine           : pass B as above, payloads to their padded slots
+// ---------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_coarse_offsets3(uint32_t* blk_off, const uint32_t* block_hist, uint32_t B, uint32_t Lp,
+                                                         uint32_t kc, WinSplit ws) {
+  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (uint64_t)kc * B * 256) return;
+  const uint32_t h = (uint32_t)(id & 255u);
+  const uint64_t row = id >> 8;   // kk * B + b
+  const uint32_t kk = (uint32_t)(row / B);
+  const uint32_t mb = ws.mb[kk];
+  uint32_t sum = 0;
+  if (h < (1u << ws.ab[kk])) {
+    const uint32_t* src = block_hist + row * Lp + ((uint64_t)h << mb);
+    for (uint32_t i = 0; i < (1u << mb); i++) sum += src[i];
+  }
+  blk_off[id] = sum;
+}
+
+// pass M.  grid (256, kc): block (h, kk) owns coarse bin h of window kk = the fine windows [h << mb, (h + 1) << mb).
+// A window without mid bits (mb = 0) keeps its order: all 256 blocks copy an equal slice of its records.
+__global__ void __launch_bounds__(RXB_THREADS) k_radix_mid(uint32_t* dig3, uint32_t* idx3, const uint32_t* v2_start,
+                                                          const uint32_t* dig2, const uint32_t* idx2, uint32_t Lp, WinSplit ws) {
+  constexpr uint32_t NBMAX = 128;
+  __shared__ uint2 stage[RXB_TILE];
+  __shared__ uint8_t stage_b[RXB_TILE];
+  __shared__ uint32_t t_cnt[NBMAX], t_start[NBMAX], g_cur[NBMAX], lds_wave[RXB_THREADS / 64];
+  const uint32_t kk = blockIdx.y, h = gridDim.x - 1 - blockIdx.x, tid = threadIdx.x;   // high bins (sparse in a short top window) last
+  const uint32_t mb = ws.mb[kk], NB = 1u << mb, fb = ws.fb[kk];
+  const uint32_t fmask = (1u << fb) - 1;
+  if (mb == 0) {
+    const uint32_t* vs = v2_start + (uint64_t)kk * Lp;
+    const uint64_t wbeg = vs[0], wlen = (uint64_t)vs[1u << ws.ab[kk]] - wbeg;
+    const uint64_t beg = wbeg + wlen * h / gridDim.x, end = wbeg + wlen * (h + 1) / gridDim.x;
+    for (uint64_t j = beg + tid; j < end; j += RXB_THREADS) {
+      const uint32_t d = dig2[j], l = d & 0xFFFFu;   // every record of the range is an entry (l >= 1)
+      dig3[j] = (((l - 1) & fmask) + 1) | (d & 0x80000000u);
+      idx3[j] = idx2[j];
     }
+    return;
+  }
+  if (h >= (1u << ws.ab[kk])) return;
+  const uint32_t* vs = v2_start + (uint64_t)kk * Lp + ((uint64_t)h << mb);
+  const uint64_t beg = vs[0], end = vs[NB];
+  if (beg == end) return;
+  if (tid < NB) g_cur[tid] = vs[tid];
+  for (uint64_t t0 = beg; t0 < end; t0 += RXB_TILE) {
+    if (tid < NB) t_cnt[tid] = 0;
+    __syncthreads();
+    uint32_t dv[RXB_ITEMS], iv[RXB_ITEMS], rk[RXB_ITEMS];
+#pragma unroll
+    for (int i = 0; i < RXB_ITEMS; i++) {
+      const uint64_t j = t0 + (uint64_t)i * RXB_THREADS + tid;
+      dv[i] = j < end ? dig2[j] : 0u;
+      iv[i] = j < end ? idx2[j] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < RXB_ITEMS; i++) {
+      const uint32_t l = dv[i] & 0xFFFFu;
+      rk[i] = lds_rank_add(t_cnt, l ? (l - 1) >> fb : 0u, l != 0, mb);
+    }
+    __syncthreads();
+    rx_scan_bins(t_start, t_cnt, NB, lds_wave);
+#pragma unroll
+    for (int i = 0; i < RXB_ITEMS; i++) {
+      const uint32_t l = dv[i] & 0xFFFFu;
+      if (l) {
+        const uint32_t m = (l - 1) >> fb, p = t_start[m] + rk[i];
+        stage[p] = make_uint2((((l - 1) & fmask) + 1) | (dv[i] & 0x80000000u), iv[i]);
+        stage_b[p] = (uint8_t)m;
+      }
+    }
+    __syncthreads();
+    const uint32_t n_tile = t_start[NB - 1] + t_cnt[NB - 1];
+    for (uint32_t i = tid; i < n_tile; i += RXB_THREADS) {
+      const uint32_t bk = stage_b[i];
+      const uint32_t pos = g_cur[bk] + (i - t_start[bk]);
+      const uint2 r = stage[i];
+      dig3[pos] = r.x;
+      idx3[pos] = r.y;
+    }
+    __syncthreads();
+    if (tid < NB) g_cur[tid] += t_cnt[tid];
   }
 }
 
+// bucket sizes of fine window v = kk * Lp + f (2^fb buckets from f << fb) from its records; `counts` is zeroed before
+// (a short top window does not reach the upper buckets)
+__global__ void __launch_bounds__(256) k_fine_hist(uint32_t* counts, const uint32_t* v2_start, const uint32_t* dig3, uint32_t Lp,
+                                                   uint32_t L, WinSplit ws) {
+  __shared__ uint32_t hist[256];
+  const uint32_t v = blockIdx.x, tid = threadIdx.x;
+  const uint32_t kk = v / Lp, f = v - kk * Lp, fb = ws.fb[kk], NB = 1u << fb;
+  const uint64_t beg = v2_start[v], end = v2_start[v + 1];
+  if (beg == end) return;
+  uint32_t* out = counts + (uint64_t)kk * L + ((uint64_t)f << fb);
+  if (fb == 0) {   // one bucket
+    if (tid == 0) out[0] = (uint32_t)(end - beg);
+    return;
+  }
+  hist[tid] = 0;
+  __syncthreads();
+  for (uint64_t j = beg + tid; j < end; j += 256) {
+    const uint32_t l = dig3[j] & 0xFFFFu;
+    if (l) atomicAdd(&hist[l - 1], 1u);
+  }
+  __syncthreads();
+  if (tid < NB) out[tid] = hist[tid];
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_chunk_order: round 1 of the tree gathers its operands from the point rows, and scattered 128-byte line reads run 2.3x
+// slower once the 64 lanes of one load instruction spread over more than ~1 GB of the table (tools/ubench_gather2.hip:
+// 30 G lines/s inside 1 GB windows, 20 inside 2 GB, 13 over 16 GB, however the table is allocated).  A bucket's payloads
+// are in point order, so at c = 16 a wave's 64 pairs cover 1/32 of the table -- but 1/4 at c = 19 and all of it at c = 22.
+// This pass restores the locality for big windows without touching the sort: every block of CO_PAIRS consecutive pairs of
+// the bucket-sorted slots (~100 buckets at c = 22) is stably partitioned by the 1 GB chunk of the table its first operand
+// lives in.  Round 1 then walks the pairs in that order -- consecutive lanes read inside one chunk -- and writes each sum
+// to the element index the pair had before (oidx), so round 2 still finds a bucket's elements side by side.  Pairs of
+// pads (both operands missing) go last.
+// ---------------------------------------------------------------------------------------------
+
+constexpr int CO_THREADS = 256, CO_PPT = CO_PAIRS / CO_THREADS;   // 16 consecutive pairs per thread
+constexpr int CO_MAX_KEYS = 65;                                   // up to 64 chunks + the pads
+
+__global__ void __launch_bounds__(CO_THREADS) k_chunk_order(uint2* pairs_out, uint16_t* oidx, const uint2* pairs_in, uint64_t n_pairs,
+                                                            uint32_t row_shift, uint32_t nkeys) {
+  __shared__ uint2 stage[CO_PAIRS];
+  __shared__ uint16_t stage_o[CO_PAIRS];
+  __shared__ uint16_t cnt[CO_MAX_KEYS * CO_THREADS];   // [key][thread]
+  __shared__ uint32_t lds_wave[CO_THREADS / 64];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t base = (uint64_t)blockIdx.x * CO_PAIRS;
+  const uint32_t n_valid = (uint32_t)min<uint64_t>(CO_PAIRS, n_pairs - base);
+  for (uint32_t i = tid; i < nkeys * CO_THREADS; i += CO_THREADS) cnt[i] = 0;
+  uint2 pr[CO_PPT];
+  uint32_t key[CO_PPT];
+#pragma unroll
+  for (int q = 0; q < CO_PPT / 2; q++) {   // 16 pairs = 8 x 16 bytes per thread
+    const uint32_t j = tid * CO_PPT + 2 * q;
+    uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (j + 1 < n_valid) v = *reinterpret_cast<const uint4*>(pairs_in + base + j);
+    else if (j < n_valid) { const uint2 u = pairs_in[base + j]; v.x = u.x; v.y = u.y; }
+    pr[2 * q] = make_uint2(v.x, v.y);
+    pr[2 * q + 1] = make_uint2(v.z, v.w);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CO_PPT; j++) {
+    // first operand present: its chunk; else the second one's; both missing: the last key
+    const uint32_t pa = pr[j].x != 0xFFFFFFFFu ? pr[j].x : pr[j].y;
+    key[j] = pa != 0xFFFFFFFFu ? min((pa >> 2) >> row_shift, nkeys - 2) : nkeys - 1;
+    cnt[key[j] * CO_THREADS + tid]++;
+  }
+  __syncthreads();
+  // exclusive scan of the flattened [key][thread] counters: thread t owns the nkeys consecutive entries from t * nkeys
+  {
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < nkeys; i++) sum += cnt[tid * nkeys + i];
+    uint32_t tot;
+    uint32_t ex = block_excl_scan(sum, lds_wave, tot);
+    for (uint32_t i = 0; i < nkeys; i++) {
+      const uint32_t c = cnt[tid * nkeys + i];
+      cnt[tid * nkeys + i] = (uint16_t)ex;
+      ex += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CO_PPT; j++) {
+    const uint32_t p = cnt[key[j] * CO_THREADS + tid]++;
+    stage[p] = pr[j];
+    stage_o[p] = (uint16_t)(tid * CO_PPT + j);
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < n_valid; i += CO_THREADS) {
+    pairs_out[base + i] = stage[i];
+    oidx[base + i] = stage_o[i];
+  }
+}
 
 // point rows (k_points_from_wire) -> tree planes, element e of the planes = row e: test input of the plane-reading modes
 __global__ void __launch_bounds__(256) k_test_rows_to_planes(uint4* planes, uint64_t cap, const uint32_t* rows, uint32_t n) {

@@ -383,22 +383,38 @@ def test_config1_inputs_2p14_on_gpu(gpu_ctx):
     assert res.as_tuple() == O.aff_scale(sum(s * ks[i & 255] for i, s in enumerate(sc)) % C.q, G, P_MOD), info
 
 
-def test_large_windows_two_level_sort_and_fallbacks(gpu_ctx):
-    """Window sizes beyond the one-level LDS sort: c = 17..24 take the two-level sort (coarse bins + per-bin LDS
-    sort); every path must give the same group element (known discrete logs at 2^16)."""
+def test_large_windows_three_pass_sort(gpu_ctx):
+    """Window sizes whose counters do not fit the LDS: c = 17..24 take the three-pass split (coarse / mid / fine bins, short
+    top windows cut on their effective bits); every path must give the same group element (known discrete logs at 2^16)."""
     n = 1 << 16
     a = O.scalars_from_bytes(gpu_ctx.generate_points(n, seed=41, want_scalars=True))
     dev, sb = gpu_ctx.generate_scalars(n, seed=42, to_host=True)
     s = O.scalars_from_bytes(sb)
     G = (C.gx, C.gy)
     exp = O.aff_scale(sum(x * y for x, y in zip(a, s)) % C.q, G, P_MOD)
-    for c in (16, 17, 19, 22, 24):
+    for c in (16, 17, 18, 19, 20, 21, 22, 23, 24):   # top windows of 15, 8, 1, 13, 7, 1, 17, 12 and 7 bits
         res, info = gpu_ctx.run_device(dev, n, c=c)
         assert res.as_tuple() == exp, (c, info)
         assert info["c"] == c and info["K"] == -(-127 // c)
     # serialised window groups (used for exclusive roofline timing) give the same answer
     res, _ = gpu_ctx.run_device(dev, n, serial=True)
     assert res.as_tuple() == exp
+
+
+@pytest.mark.parametrize("c", [19, 20, 22])
+def test_big_windows_chunk_ordered_round1(gpu_ctx, c_oracle, c):
+    """2^23 points (a 2 GB row table) with windows of 2^18 .. 2^21 buckets: the three-pass split at size, round 1 walking
+    its pairs chunk by chunk of the table (k_chunk_order) and leaving element rows, round 2 reading them back.  The result
+    must be the group element of the known discrete logs, whatever the window size."""
+    n = 1 << 23
+    a = gpu_ctx.generate_points(n, seed=2323 + c, want_scalars=True, raw=True)
+    dev, s = gpu_ctx.generate_scalars(n, seed=3232 + c, to_host=True, raw=True)
+    res, info = gpu_ctx.run_device(dev, n, c=c)
+    k = c_oracle.dot_mod(a, s, n, C.q)
+    assert info["c"] == c
+    assert res.as_tuple() == O.aff_scale(k, (C.gx, C.gy), P_MOD), info
+    res16, _ = gpu_ctx.run_device(dev, n)
+    assert res16.as_tuple() == res.as_tuple()
 
 
 def test_skewed_buckets_tail_rounds(gpu_ctx, c_oracle):
