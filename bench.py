@@ -6,9 +6,12 @@
 One "step" = one MSM over resident base points with FRESH scalars already in HBM (the reference's
 protocol: points pre-loaded, new random scalars every run, scripts/msm-weierstrass.ts:12-51).
 N = 1: the whole MSM on one GPU.  N > 1 (launched by torch.distributed.run, one rank per GPU): the
-same MSM sharded by scalar window -- every rank holds all points and scalars, computes the window
-sums P_k of its windows, ONE RCCL all-gather of K x 144 bytes, rank 0 does the Horner combination
-(SURVEY.md section 8e).  Total work is fixed as N grows: scaling = "strong".
+same MSM sharded across the ranks -- `--split windows`: by scalar window (every rank holds all points and
+scalars and computes the window sums P_k of its windows); `--split points`: every rank runs all K windows
+on its share of the points and needs only that share of the scalars; `auto` takes the one the single-GPU
+proxy (tools/shard_time.py) times faster.  Either way ONE RCCL all-gather of K x 144
+bytes per rank, rank 0 does the Horner combination.  Total work is fixed as N grows:
+scaling = "strong".
 
 Prints ONE JSON line on rank 0 with the driver's contract plus
   `roofline`      dominant kernel k_batch_add, HIP-event timed inside the library on its own stream,
@@ -218,6 +221,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the known-discrete-log check of the last timed result")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the in-process runs of BASELINE configs[1] (2^20 BLS12-377) and configs[3] (2^20 Ed-on-BLS12-377)")
+    ap.add_argument("--split", choices=["auto", "windows", "points"], default="auto",
+                    help="N > 1: shard the MSM by scalar window or by points (auto: montgomery_amd.distributed.choose_split)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (functional check of the sharded path on one GPU)")
     ap.add_argument("--curve", choices=["bls12-377", "bls12-381", "ed377"], default="bls12-377",
                     help="ed377 = BASELINE configs[3]: twisted Edwards msmBasic path (single GPU, use --log2n 20); "
@@ -247,7 +252,7 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     from montgomery_amd.api import AffineResult, MsmContext
-    from montgomery_amd.distributed import sharded_msm, window_shards
+    from montgomery_amd.distributed import choose_split, point_shards, sharded_msm, sharded_msm_points, window_shards
 
     n = 1 << args.log2n
     if args.curve == "ed377":
@@ -261,6 +266,7 @@ def main():
     a_host = ctx.generate_points(n, seed=20261002, want_scalars=(verify and rank == 0), raw=True)
     c, K = ctx.plan(n, args.c or None)
     shards = window_shards(K, world)
+    split = "none" if world == 1 else (choose_split(n, world, K) if args.split == "auto" else args.split)
 
     dev = torch.device("cuda", local_rank)
     # fresh scalars per step, generated on the GPU before the timed region (resident in HBM); at most MAX_SCALAR_SETS
@@ -274,12 +280,24 @@ def main():
         if world == 1:
             return ctx.run_device(scal[i % n_sets].data_ptr(), n, c=c)
         box = {}
+        ddev = dev if args.dist_backend == "nccl" else "cpu"
 
         def my_window_sums(lo, hi):
             parts, box["info"] = ctx.window_sums(scal[i % n_sets].data_ptr(), n, lo, hi, c=c, on_device=True)
             return parts
 
-        out = sharded_msm(my_window_sums, K, c, device=dev if args.dist_backend == "nccl" else "cpu", curve=ctx.curve)
+        def my_point_sums(first, count):   # all K windows over this rank's share of the points: only its scalars are read
+            parts, box["info"] = ctx.window_sums(scal[i % n_sets].data_ptr() + 32 * first, count, 0, K, c=c, on_device=True,
+                                                 point_lo=first)
+            return parts
+
+        tm = {}
+        if split == "points":
+            out = sharded_msm_points(my_point_sums, n, K, c, device=ddev, curve=ctx.curve, timing=tm)
+        else:
+            out = sharded_msm(my_window_sums, K, c, device=ddev, curve=ctx.curve, timing=tm)
+        if box.get("info") is not None:
+            box["info"]["all_gather_ms"] = tm.get("all_gather_ms")
         res = None
         if out is not None:
             xy = out[1]
@@ -310,6 +328,19 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    ranks_info = None
+    if world > 1:   # outside the timed region: what every rank spent where, so that a scaling run explains itself
+        mine = [x for x in infos if x]
+        summary = {"rank": rank, "shard": (list(point_shards(n, world)[rank]) if split == "points" else list(shards[rank])),
+                   "steps_with_work": len(mine)}
+        if mine:
+            summary["phase_ms"] = {k: sum(x["phase_ms"][k] for x in mine) / len(mine) for k in mine[0]["phase_ms"]}
+            ag = [x["all_gather_ms"] for x in mine if x.get("all_gather_ms") is not None]
+            summary["all_gather_ms"] = sum(ag) / len(ag) if ag else None
+            summary["step_ms"] = sum(step_ms) / len(step_ms)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, summary)
+        ranks_info = gathered
     if rank == 0:
         infos = [x for x in infos if x]
         acc_ms = sum(x["phase_ms"]["accumulate"] for x in infos)
@@ -379,7 +410,9 @@ def main():
                 "log2_n": args.log2n,
                 "window_bits": c,
                 "windows": K,
-                "parallelism": "single-gpu" if world == 1 else f"window-shard x{world}, one RCCL all-gather of {K}x144 B",
+                "parallelism": "single-gpu" if world == 1 else (
+                    f"window-shard x{world}, one RCCL all-gather of {K}x144 B" if split == "windows" else
+                    f"points-shard x{world} (all {K} windows on n/{world} points per rank), one RCCL all-gather of {K}x144 B per rank"),
                 "points": "P_i = a_i*G generated on GPU (resident)",
                 "scalars": f"uniform < q, fresh per step ({n_sets} distinct sets cycled), resident in HBM before the timed region",
             },
@@ -423,6 +456,7 @@ def main():
                         "(DESIGN.md section 5)",
             },
             "phase_ms": phase,
+            "ranks": ranks_info,
             "pcie_inclusive": pcie,
             "result_is_infinity": bool(last.isZero) if last is not None else None,
         }

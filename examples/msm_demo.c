@@ -22,8 +22,9 @@ int main(int argc, char** argv) {
   int rc = msm_ctx_create(&ctx, curve, 0);
   if (rc) die(NULL, "msm_ctx_create (no usable GPU? there is no CPU fallback)", rc);
   if ((rc = msm_generate_points(ctx, n, 42, NULL))) die(ctx, "msm_generate_points", rc);
-  void* d_scalars = NULL; /* NULL: the library's own device buffer */
-  if ((rc = msm_generate_scalars(ctx, n, 43, &d_scalars, NULL))) die(ctx, "msm_generate_scalars", rc);
+  void* d_scalars = NULL; /* one device buffer per scalar handle, owned by the context until msm_device_free */
+  if ((rc = msm_device_alloc(ctx, n * 32, &d_scalars))) die(ctx, "msm_device_alloc", rc);
+  if ((rc = msm_generate_scalars(ctx, n, 43, d_scalars, NULL))) die(ctx, "msm_generate_scalars", rc);
 
   msm_opts opts;
   msm_result a, b, c3;

@@ -61,7 +61,11 @@ typedef struct msm_opts {
                            (src/parallel.ts:69-87, src/msm-basic.ts:56-91).  Same group element, 2x the additions */
   int32_t strict;       /* != 0: a scalar >= q fails the call with MSM_ERR_SCALAR.  Default: such scalars are reduced mod q
                            (the reference specifies inputs < q, src/curve-random.ts:151-194, and does not check) */
-  int32_t reserved[1];
+  uint32_t point_lo;    /* the call covers the resident points [point_lo, point_lo + n): scalars[i] belongs to point
+                           point_lo + i.  The points-split shard of a multi-GPU run: rank g runs all K windows
+                           on its n / G points, msm_combine_groups adds the G partial sums of every window */
+  int32_t by_window;    /* multi-device contexts (msm_ctx_create_multi): != 0 shards an MSM by scalar window, every device then
+                           needs all n scalars; default 0: by points, device d gets the scalars of its n / G points only */
 } msm_opts;
 
 #define MSM_N_PHASES 8
@@ -130,11 +134,19 @@ int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const 
 int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts,
                     uint8_t* partials_out, msm_result* stats);
 
+/* msm_run on a multi-device context with the scalars already PLACED: dev_scalars[d] is a device pointer on devices[d]
+ * holding the n_d x 32 bytes of that device's points [n d / G, n (d + 1) / G) (points split), so no peer copy happens
+ * inside the call.  On a single-device context dev_scalars[0] is the whole scalar array. */
+int msm_run_placed(msm_ctx* ctx, const void* const* dev_scalars, uint64_t n, const msm_opts* opts, msm_result* out);
+
 /* S = sum_k 2^(c k) P_k over all K windows, then to affine (src/msm-batched-affine.ts:322-333,
  * src/curve-projective.ts:335-349).  Host arithmetic only: `ctx` may be NULL. */
 int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm_result* out);
 /* The same without a context: `curve` names the constants.  No GPU is touched. */
 int msm_combine_curve(int curve, const uint8_t* partials, int32_t K, int32_t c, msm_result* out);
+/* Points-split runs: `partials` holds G groups of K window sums (group g = the sums of the g-th share of the points, as
+ * msm_window_sums wrote them); P_k = sum over the groups, then as msm_combine_curve. */
+int msm_combine_groups(int curve, const uint8_t* partials, int32_t G, int32_t K, int32_t c, msm_result* out);
 
 /* Window plan for n points: the c the library would pick and the resulting K. */
 int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_out, int32_t* K_out);
@@ -143,10 +155,10 @@ int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_ou
  * n resident points P_i = a_i * G and, if `a_out` is non-null, the n scalars a_i (32-byte LE) so a
  * caller can verify sum s_i P_i = (sum s_i a_i) G in O(n). */
 int msm_generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out);
-/* n uniformly random scalars < q.  If *dev_ptr_out is NULL on entry they go to a device buffer owned by
- * the context (valid until the next call) whose address is returned; otherwise *dev_ptr_out must be a
- * caller-owned device buffer of n * 32 bytes.  host_out (optional) receives a copy. */
-int msm_generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void** dev_ptr_out, uint8_t* host_out);
+/* n uniformly random scalars < q (`randomScalars`, src/curve-random.ts:151-194) into `dev_dst`, a caller-owned device buffer
+ * of n * 32 bytes (msm_device_alloc, or any device allocation of the caller), and / or into `host_out` (n * 32 bytes).
+ * Either may be NULL, not both. */
+int msm_generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void* dev_dst, uint8_t* host_out);
 
 /* Read resident points [first, first + count) back in wire format (tests, CPU-baseline sampling). */
 int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy);

@@ -114,13 +114,16 @@ async function compute_msm_on(curve, coordBytes, inputPoints, inputScalars) {
   if (Buffer.isBuffer(inputPoints) || inputPoints instanceof Uint8Array) pbytes = Buffer.from(inputPoints);
   else pbytes = Buffer.concat(inputPoints.map((P) => (P.isZero ? Buffer.alloc(pointBytes) : Buffer.concat([bigintToLeBytes(BigInt(P.x), coordBytes), bigintToLeBytes(BigInt(P.y), coordBytes)]))));
   const pp = curve.Parallel.getPointer(pbytes.length);
-  const sp = curve.Parallel.getScalarPointer(sbytes.length);
-  await curve.Parallel.pointsFromBytes(pp, pbytes, n);
-  await curve.Parallel.scalarsFromBytes(sp, sbytes, n);
-  const same = n > 1 && pbytes.slice(0, pointBytes).equals(pbytes.slice(pointBytes, 2 * pointBytes));
-  const { result } = same ? await curve.Parallel.msm(sp, pp, n) : await curve.Parallel.msmUnsafe(sp, pp, n);
-  pp.free();
-  return { x: result.x, y: result.y, isZero: result.isZero };
+  try {   // the point set is freed whatever the conversion or the MSM throws (bad point, HIP error): `curve` outlives the call
+    const sp = curve.Parallel.getScalarPointer(sbytes.length);
+    await curve.Parallel.pointsFromBytes(pp, pbytes, n);
+    await curve.Parallel.scalarsFromBytes(sp, sbytes, n);
+    const same = n > 1 && pbytes.slice(0, pointBytes).equals(pbytes.slice(pointBytes, 2 * pointBytes));
+    const { result } = same ? await curve.Parallel.msm(sp, pp, n) : await curve.Parallel.msmUnsafe(sp, pp, n);
+    return { x: result.x, y: result.y, isZero: result.isZero };
+  } finally {
+    pp.free();
+  }
 }
 
 module.exports = { hip, Weierstrass, TwistedEdwards, bls12377Params, bls12381Params, pallasParams, edOnBls12377Params, compute_msm_on, compute_msm: compute_msm_on, leBytesToBigint, bigintToLeBytes };

@@ -30,12 +30,13 @@ EXPORTS = (
     "msm_ctx_create_multi", "msm_ctx_device_count", "msm_pointset_create", "msm_pointset_select", "msm_pointset_destroy",
     "msm_device_alloc", "msm_device_free", "msm_device_upload",
     "msm_test_fp_raw", "msm_test_curve_op", "msm_test_batch_add_mode",
+    "msm_run_placed", "msm_combine_groups",
 )
 
 
 class MsmOpts(C.Structure):
     _fields_ = [("c", C.c_int32), ("unsafe", C.c_int32), ("k_lo", C.c_int32), ("k_hi", C.c_int32), ("serial", C.c_int32),
-                ("no_glv", C.c_int32), ("strict", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("no_glv", C.c_int32), ("strict", C.c_int32), ("point_lo", C.c_uint32), ("by_window", C.c_int32)]
 
 
 class MsmResult(C.Structure):
@@ -82,9 +83,11 @@ def load() -> C.CDLL:
     lib.msm_combine.argtypes = [vp, vp, i32, i32, C.POINTER(MsmResult)]
     lib.msm_combine_curve.argtypes = [i32, vp, i32, i32, C.POINTER(MsmResult)]
     lib.msm_combine_curve.restype = i32
+    lib.msm_combine_groups.argtypes = [i32, vp, i32, i32, i32, C.POINTER(MsmResult)]
+    lib.msm_run_placed.argtypes = [vp, C.POINTER(vp), u64, C.POINTER(MsmOpts), C.POINTER(MsmResult)]
     lib.msm_plan.argtypes = [vp, u64, C.POINTER(MsmOpts), C.POINTER(i32), C.POINTER(i32)]
     lib.msm_generate_points.argtypes = [vp, u64, u64, vp]
-    lib.msm_generate_scalars.argtypes = [vp, u64, u64, C.POINTER(vp), vp]
+    lib.msm_generate_scalars.argtypes = [vp, u64, u64, vp, vp]
     lib.msm_get_points.argtypes = [vp, u64, u64, vp]
     lib.msm_test_fp.argtypes = [vp, C.c_int, vp, vp, vp, u64]
     lib.msm_test_glv.argtypes = [vp, vp, vp, u64]

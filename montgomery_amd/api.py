@@ -170,6 +170,7 @@ class MsmContext:
         self._cur_set = 0
         self._set_sizes: Dict[int, int] = {0: 0}
         self.coord_bytes = 32 if curve == _lib.CURVE_ED_ON_BLS12_377 else 48
+        self._gen_buf, self._gen_cap = 0, 0   # device buffer of generate_scalars(into=0)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -254,14 +255,21 @@ class MsmContext:
         return bytes(out) if out is not None else (b"" if want_scalars else None)
 
     def generate_scalars(self, n: int, seed: int = 1, to_host: bool = False, into: int = 0, raw: bool = False):
-        """n random scalars < q on the device.  `into`: caller-owned device pointer (n * 32 bytes), 0 = library buffer.
+        """n random scalars < q on the device.  `into`: caller-owned device pointer (n * 32 bytes); 0 = a device buffer this
+        object allocates (msm_device_alloc) and keeps until the next such call or close().
         to_host: also return a host copy (bytes; the ctypes array itself with raw=True)."""
-        dev = C.c_void_p(into or None)
+        if not into:
+            if self._gen_buf and self._gen_cap < 32 * n:
+                self.device_free(self._gen_buf)
+                self._gen_buf = 0
+            if not self._gen_buf:
+                self._gen_buf, self._gen_cap = self.device_alloc(max(32 * n, 32)), max(32 * n, 32)
+            into = self._gen_buf
         out = (C.c_uint8 * (32 * n))() if to_host and n else None
-        self._check(self._lib.msm_generate_scalars(self._h, n, seed, C.byref(dev), out))
+        self._check(self._lib.msm_generate_scalars(self._h, n, seed, C.c_void_p(into), out))
         if out is not None and raw:
-            return int(dev.value or 0), out
-        return int(dev.value or 0), (bytes(out) if out is not None else None)
+            return int(into), out
+        return int(into), (bytes(out) if out is not None else None)
 
     def get_points(self, first: int, count: int) -> bytes:
         step = 2 * self.coord_bytes
@@ -282,21 +290,36 @@ class MsmContext:
         self._check(self._lib.msm_plan(self._h, n, C.byref(opts), C.byref(cc), C.byref(kk)))
         return cc.value, kk.value
 
-    def run(self, scalars: BytesLike, c: Optional[int] = None, unsafe: bool = False, no_glv: bool = False) -> Tuple[AffineResult, Dict]:
+    def run(self, scalars: BytesLike, c: Optional[int] = None, unsafe: bool = False, no_glv: bool = False,
+            by_window: bool = False) -> Tuple[AffineResult, Dict]:
         if len(scalars) % 32:
             raise MsmError(_lib.MSM_ERR_ARG, f"scalar buffer length {len(scalars)} is not a multiple of 32")
         n = len(scalars) // 32
         # a ctypes array is handed over as it is (no 2 GB copies at 2^26), anything else is copied once
         buf = scalars if isinstance(scalars, C.Array) else (C.c_uint8 * max(len(scalars), 1)).from_buffer_copy(bytes(scalars) or b"\0")
-        return self._run(buf, n, 0, c, unsafe, no_glv=no_glv)
+        return self._run(buf, n, 0, c, unsafe, no_glv=no_glv, by_window=by_window)
 
     def run_device(self, dev_ptr: int, n: int, c: Optional[int] = None, unsafe: bool = False, serial: bool = False,
-                   no_glv: bool = False) -> Tuple[AffineResult, Dict]:
-        return self._run(C.c_void_p(dev_ptr), n, 1, c, unsafe, serial, no_glv)
+                   no_glv: bool = False, by_window: bool = False, point_lo: int = 0) -> Tuple[AffineResult, Dict]:
+        """by_window: a device-list context shards by scalar window instead of by points.  point_lo: the MSM covers the
+        resident points [point_lo, point_lo + n) (scalar i belongs to point point_lo + i)."""
+        return self._run(C.c_void_p(dev_ptr), n, 1, c, unsafe, serial, no_glv, by_window, point_lo)
+
+    def run_placed(self, dev_ptrs: Sequence[int], n: int, c: Optional[int] = None) -> Tuple[AffineResult, Dict]:
+        """Device-list context, scalars already placed: dev_ptrs[d] on devices[d] holds the scalars of that device's share
+        [n d / G, n (d + 1) / G) of the points (msm_run_placed)."""
+        arr = (C.c_void_p * len(dev_ptrs))(*[C.c_void_p(int(p)) for p in dev_ptrs])
+        opts, res = MsmOpts(c=c or 0), MsmResult()
+        self._check(self._lib.msm_run_placed(self._h, arr, n, C.byref(opts), C.byref(res)))
+        nb = self.coord_bytes
+        out = AffineResult(int.from_bytes(bytes(res.x)[:nb], "little"), int.from_bytes(bytes(res.y)[:nb], "little"),
+                           bool(res.is_infinity))
+        return out, _result_to_dict(res)
 
     def _run(self, ptr, n: int, on_device: int, c: Optional[int], unsafe: bool, serial: bool = False,
-             no_glv: bool = False) -> Tuple[AffineResult, Dict]:
-        opts = MsmOpts(c=c or 0, unsafe=int(unsafe), serial=int(serial), no_glv=int(no_glv))
+             no_glv: bool = False, by_window: bool = False, point_lo: int = 0) -> Tuple[AffineResult, Dict]:
+        opts = MsmOpts(c=c or 0, unsafe=int(unsafe), serial=int(serial), no_glv=int(no_glv), by_window=int(by_window),
+                       point_lo=point_lo)
         res = MsmResult()
         self._check(self._lib.msm_run(self._h, ptr, n, on_device, C.byref(opts), C.byref(res)))
         nb = self.coord_bytes
@@ -308,11 +331,12 @@ class MsmContext:
         return out, _result_to_dict(res)
 
     def window_sums(self, scalars: Union[BytesLike, int], n: int, k_lo: int, k_hi: int, c: Optional[int] = None,
-                    on_device: bool = False) -> Tuple[bytes, Dict]:
-        """Partition sums P_k, k in [k_lo, k_hi): (k_hi - k_lo) x 144 bytes (X, Y, Z)."""
+                    on_device: bool = False, point_lo: int = 0, by_window: bool = False) -> Tuple[bytes, Dict]:
+        """Partition sums P_k, k in [k_lo, k_hi), over the resident points [point_lo, point_lo + n) (scalar i belongs to
+        point point_lo + i): (k_hi - k_lo) x 144 bytes (X, Y, Z)."""
         if k_hi <= k_lo or k_lo < 0:   # (0, 0) would mean "all windows" to the C side and overrun the 144-byte buffer below
             raise MsmError(_lib.MSM_ERR_ARG, f"empty or negative window range [{k_lo}, {k_hi})")
-        opts = MsmOpts(c=c or 0, k_lo=k_lo, k_hi=k_hi)
+        opts = MsmOpts(c=c or 0, k_lo=k_lo, k_hi=k_hi, point_lo=point_lo, by_window=int(by_window))
         res = MsmResult()
         out = (C.c_uint8 * (144 * max(k_hi - k_lo, 1)))()
         if on_device:
@@ -413,6 +437,12 @@ class PointPtr:
         if ctx is not None and self.set_id > 0 and getattr(ctx, "_h", None):
             ctx.pointset_destroy(self.set_id)
 
+    def __enter__(self) -> "PointPtr":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
     def __del__(self):
         try:
             self.close()
@@ -432,6 +462,12 @@ class ScalarPtr:
         if ctx is not None and self.dev_ptr and getattr(ctx, "_h", None):
             ctx.device_free(self.dev_ptr)
         self.dev_ptr = 0
+
+    def __enter__(self) -> "ScalarPtr":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
 
     def __del__(self):
         try:
@@ -531,37 +567,40 @@ class _Parallel:
 class Weierstrass:
     """Curve module as `Weierstraß.create(params)` returns it (src/parallel.ts:147-160), MSM path only."""
 
-    def __init__(self, params: WeierstrassParams, device: int = 0):
+    def __init__(self, params: WeierstrassParams, device: int = 0, devices: Optional[Sequence[int]] = None):
+        """`devices`: a device list instead of one device -- every device holds the point set and `Parallel.msm` shards the
+        windows over them (msm_ctx_create_multi); the counterpart of the reference's thread count, src/parallel.ts:40-66."""
         if params.label not in _WEIERSTRASS_CURVE_IDS:
             raise MsmError(_lib.MSM_ERR_ARG, f"curve {params.label!r} has no device constants "
                                              f"(have {sorted(_WEIERSTRASS_CURVE_IDS)})")
         self.params = params
-        self.context = MsmContext(_WEIERSTRASS_CURVE_IDS[params.label], device)
+        self.context = MsmContext(_WEIERSTRASS_CURVE_IDS[params.label], device, devices=devices)
         self.Parallel = _Parallel(self.context, params)
 
     @classmethod
-    def create(cls, params: WeierstrassParams, device: int = 0) -> "Weierstrass":
-        return cls(params, device)
+    def create(cls, params: WeierstrassParams, device: int = 0, devices: Optional[Sequence[int]] = None) -> "Weierstrass":
+        return cls(params, device, devices)
 
 
-def create_weierstrass(params: WeierstrassParams = BLS12_377_PARAMS, device: int = 0) -> Weierstrass:
-    return Weierstrass.create(params, device)
+def create_weierstrass(params: WeierstrassParams = BLS12_377_PARAMS, device: int = 0,
+                       devices: Optional[Sequence[int]] = None) -> Weierstrass:
+    return Weierstrass.create(params, device, devices)
 
 
 class TwistedEdwards:
     """Curve module as `TwistedEdwards.create(params)` returns it (src/parallel.ts:179-289), MSM path only:
     `Parallel.msm` is `msmBasic` (src/msm-basic.ts:45-164) on extended points."""
 
-    def __init__(self, params: TwistedEdwardsParams, device: int = 0):
+    def __init__(self, params: TwistedEdwardsParams, device: int = 0, devices: Optional[Sequence[int]] = None):
         if params.label != "ed-on-bls12-377":
             raise MsmError(_lib.MSM_ERR_ARG, f"curve {params.label!r} has no device constants (only ed-on-bls12-377)")
         self.params = params
-        self.context = MsmContext(_lib.CURVE_ED_ON_BLS12_377, device)
+        self.context = MsmContext(_lib.CURVE_ED_ON_BLS12_377, device, devices=devices)
         self.Parallel = _Parallel(self.context, params)
 
     @classmethod
-    def create(cls, params: TwistedEdwardsParams, device: int = 0) -> "TwistedEdwards":
-        return cls(params, device)
+    def create(cls, params: TwistedEdwardsParams, device: int = 0, devices: Optional[Sequence[int]] = None) -> "TwistedEdwards":
+        return cls(params, device, devices)
 
 
 class _LazyCurve:
@@ -600,10 +639,10 @@ def compute_msm_ed(inputPoints, inputScalars, curve: Optional[TwistedEdwards] = 
     else:
         pbytes = b"".join(int(P["x"]).to_bytes(32, "little") + int(P["y"]).to_bytes(32, "little") for P in inputPoints)
     par = cv.Parallel
-    pp, sp = par.getPointer(len(pbytes)), par.getScalarPointer(len(sbytes))
-    par.pointsFromBytes(pp, pbytes, n)
-    par.scalarsFromBytes(sp, sbytes, n)
-    res = par.msm(sp, pp, n)["result"]
+    with par.getPointer(len(pbytes)) as pp, par.getScalarPointer(len(sbytes)) as sp:   # freed on every path, errors included
+        par.pointsFromBytes(pp, pbytes, n)
+        par.scalarsFromBytes(sp, sbytes, n)
+        res = par.msm(sp, pp, n)["result"]
     return {"x": res.x, "y": res.y}
 
 
@@ -630,11 +669,10 @@ def compute_msm(inputPoints, inputScalars, curve: Optional[Weierstrass] = None) 
                 chunks.append(int(P["x"]).to_bytes(48, "little") + int(P["y"]).to_bytes(48, "little"))
         pbytes = b"".join(chunks)
     par = cv.Parallel
-    pp = par.getPointer(len(pbytes))
-    sp = par.getScalarPointer(len(sbytes))
-    par.pointsFromBytes(pp, pbytes, n)
-    par.scalarsFromBytes(sp, sbytes, n)
-    same = n > 1 and pbytes[:96] == pbytes[96:192]
-    out = par.msm(sp, pp, n) if same else par.msmUnsafe(sp, pp, n)
-    res = out["result"]
+    with par.getPointer(len(pbytes)) as pp, par.getScalarPointer(len(sbytes)) as sp:   # freed on every path, errors included
+        par.pointsFromBytes(pp, pbytes, n)
+        par.scalarsFromBytes(sp, sbytes, n)
+        same = n > 1 and pbytes[:96] == pbytes[96:192]
+        out = par.msm(sp, pp, n) if same else par.msmUnsafe(sp, pp, n)
+        res = out["result"]
     return {"x": res.x, "y": res.y}

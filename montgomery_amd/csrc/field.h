@@ -3,7 +3,7 @@
 // Replaces the reference's generated-WebAssembly field backend:
 //   multiply / square      src/wasm/multiply-montgomery.ts:58-215
 //   add / sub / reduce     src/wasm/field-arithmetic.ts:32-166
-//   inverse                src/wasm/inverse.ts:191-218 (here: Fermat chain, see fe_inv)
+//   inverse                src/wasm/inverse.ts:191-218 (here: division steps, fe_inv; Fermat / Kaliski / word-sliced kept as cross-checks)
 //   packed-bytes codecs    src/wasm/field-helpers.ts:211-301
 //
 // Register form ("Fe"): NL limbs of 30 bits, radix R = 2^(30*NL) (2^390 for the 377-bit prime,

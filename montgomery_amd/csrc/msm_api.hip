@@ -380,9 +380,10 @@ void host_to_partial(const msm_ctx* ctx, const msm_host::Proj6& P, uint32_t* out
 // Partition sums P_k for windows [k_lo, k_hi) over the points [p_lo, p_lo + n) -> w.h_part[(k - k_lo) * 36 ...]
 // scalars: device pointer, n x 8 words.
 void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars_all, uint64_t p_lo, uint64_t n, const Plan& pl,
-                      int k_lo, int k_hi, uint32_t* h_partials_out, GroupStats& st) {
+                      int k_lo, int k_hi, uint32_t* h_partials_out, GroupStats& st, uint64_t p_off = 0) {
   hipStream_t s = w.stream;
-  const uint32_t* d_scalars = d_scalars_all + p_lo * 8;
+  const uint32_t* d_scalars = d_scalars_all + p_lo * 8;   // scalar i of the call <-> resident point p_off + i
+  p_lo += p_off;
   const int kc = k_hi - k_lo;
   const bool lone = pl.lone;
   const uint32_t L = pl.L;
@@ -625,9 +626,10 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       which ^= 1;
     }
   }
-  // idle lanes of a round's last step read (and ignore) up to 2 T elements past its end: keep that inside the allocation
-  // (T, the lanes of a round, is largest in round 1 and grows with the input once the 512 steps per lane are used up)
-  const size_t tree_slack = (size_t)round_geom(ctx, std::max<uint64_t>(total_slots / 2, 1), true, lone).T * 2 * 16 + 4096;
+  // Idle lanes of a plane-reading round read (and ignore) elements past the end of its input: a round of n_out pairs runs
+  // steps * T lanes-steps with T = 256 ceil(ceil(n_out / steps) / 256), so fewer than 257 * steps pairs -- 2 elements of 16
+  // bytes per plane each -- lie beyond n_out, whatever the grid (hence the CU count) is.  steps <= 512.
+  const size_t tree_slack = (size_t)2 * 257 * 512 * 16 + 4096;
   ctx->ensure(w.bufA, capA * elem_bytes + tree_slack);
   ctx->ensure(w.bufB, capB * elem_bytes + tree_slack);
   uint4* buf[2] = {(uint4*)w.bufA.p, (uint4*)w.bufB.p};
@@ -903,6 +905,21 @@ msm_host::Ext6 te_partial_to_host(const msm_ctx* ctx, const uint32_t* w) {
   return P;
 }
 
+// host extended point -> the device window-sum form (X, Y, Z, T: 8 words each, radix 2^270): x 2^384 -> x 2^270
+void te_host_to_partial(const msm_ctx* ctx, const msm_host::Ext6& P, uint32_t* out32) {
+  const auto& C = ctx->hte;
+  const msm_host::Fe6 k = C.F.pow2(270);
+  const msm_host::Fe6* co[4] = {&P.X, &P.Y, &P.Z, &P.T};
+  for (int j = 0; j < 4; j++) {
+    msm_host::Fe6 t;
+    C.F.mul(t, *co[j], k);
+    for (int i = 0; i < 4; i++) {
+      out32[8 * j + 2 * i] = (uint32_t)t.v[i];
+      out32[8 * j + 2 * i + 1] = (uint32_t)(t.v[i] >> 32);
+    }
+  }
+}
+
 void te_horner_to_affine(const msm_ctx* ctx, const std::vector<uint32_t>& words, int K, int c, msm_result* out) {
   std::vector<msm_host::Ext6> P(K);
   for (int k = 0; k < K; k++) P[k] = te_partial_to_host(ctx, &words[(size_t)k * 32]);
@@ -920,8 +937,9 @@ int stage_scalars(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, 
   return MSM_OK;
 }
 
+// windows [k_lo, k_hi) over the resident points [p_off, p_off + n); scalars[i] belongs to point p_off + i
 int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, int k_lo, int k_hi,
-                     const Plan& pl, std::vector<uint32_t>& words, msm_result* stats) {
+                     const Plan& pl, std::vector<uint32_t>& words, msm_result* stats, uint64_t p_off = 0) {
   const uint32_t* d_scal = nullptr;
   HIPCHK(hipEventRecord(ctx->ev[8], ctx->stream));
   stage_scalars(ctx, scalars, n, on_device, &d_scal);
@@ -969,7 +987,7 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       std::vector<uint32_t> part((size_t)(kb - ka) * pw);
       Plan pg = pl;
       pg.lone = groups.size() == 1 && kb - ka == 1;
-      run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, part.data(), sts[slot]);
+      run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, part.data(), sts[slot], p_off);
       if (split_points) split_part[gi] = part;
       else memcpy(&words[(size_t)(ka - k_lo) * pw], part.data(), part.size() * 4);
     }
@@ -1035,38 +1053,55 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
 }
 
 
-// Multi-device context: the window range [k_lo, k_hi) is cut into contiguous shards, one per device (windows are
-// independent until the Horner step, src/msm-batched-affine.ts:312-333); device d runs window_sums_impl on its own
-// context from its own host thread, the partition sums (36 words per window) come back to the caller's thread.
-// Scalars: a host buffer is uploaded by every device itself; a device buffer (it lives on devices[0]) is copied
-// peer-to-peer into the other devices' staging buffers first.
-int multi_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, int k_lo, int k_hi,
-                      const Plan& pl, std::vector<uint32_t>& words, msm_result* stats) {
+// Multi-device context: one MSM over the devices of the list, each from its own host thread on its own context.
+//   by points (default): device d runs ALL windows [k_lo, k_hi) on its share [n d / G, n (d + 1) / G) of the points and needs
+//     only that share of the scalars; the G sums of every window are added on the host (G - 1 projective additions each);
+//   by window (msm_opts.by_window): the window range is cut into contiguous shards (windows are independent until the Horner
+//     step, src/msm-batched-affine.ts:312-333), every device needs all n scalars.
+// Scalars: `placed` != nullptr -- one device pointer per device, already on that device (by points: the device's share);
+// else a host buffer, of which every device uploads what it needs, or a device buffer on devices[0], of which the other
+// devices first copy their part peer-to-peer -- all devices at once, each from its own thread, under device 0's shard.
+int multi_window_sums(msm_ctx* ctx, const void* scalars, const void* const* placed, uint64_t n, int on_device, const msm_opts* opts,
+                      int k_lo, int k_hi, const Plan& pl, std::vector<uint32_t>& words, msm_result* stats, uint64_t p_off) {
   const int ndev = 1 + (int)ctx->children.size();
   const int nwin = k_hi - k_lo, pw = ctx->is_te() ? 32 : 36;
+  const bool by_window = opts && opts->by_window;
   words.assign((size_t)nwin * pw, 0);
-  std::vector<int> lo(ndev), hi(ndev);
+  std::vector<int> lo(ndev, k_lo), hi(ndev, k_hi);
+  std::vector<uint64_t> p0(ndev, 0), pn(ndev, n);
   for (int d = 0, k = k_lo; d < ndev; d++) {
-    const int cnt = nwin / ndev + (d < nwin % ndev ? 1 : 0);
-    lo[d] = k;
-    hi[d] = k + cnt;
-    k += cnt;
+    if (by_window) {
+      const int cnt = nwin / ndev + (d < nwin % ndev ? 1 : 0);
+      lo[d] = k;
+      hi[d] = k + cnt;
+      k += cnt;
+    } else {
+      p0[d] = n * (uint64_t)d / ndev;
+      pn[d] = n * (uint64_t)(d + 1) / ndev - p0[d];
+    }
   }
   std::vector<std::vector<uint32_t>> part(ndev);
   std::vector<msm_result> st(ndev);
   for (auto& r : st) memset(&r, 0, sizeof r);
   auto shard = [&](int d) {
-    if (hi[d] <= lo[d]) return;
+    if (hi[d] <= lo[d] || pn[d] == 0) return;
     msm_ctx* c = d == 0 ? ctx : ctx->children[d - 1];
     HIPCHK(hipSetDevice(c->device));
-    const void* sc = scalars;
-    if (on_device && d > 0) {
-      c->ensure(c->scal, n * 32);
-      HIPCHK(hipMemcpyPeerAsync(c->scal.p, c->device, scalars, ctx->device, n * 32, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-      sc = c->scal.p;
+    const void* sc;
+    int dev_side = on_device;
+    if (placed) {
+      sc = placed[d];
+      dev_side = 1;
+    } else {
+      sc = (const uint8_t*)scalars + p0[d] * 32;
+      if (on_device && d > 0) {
+        c->ensure(c->scal, pn[d] * 32);
+        HIPCHK(hipMemcpyPeerAsync(c->scal.p, c->device, sc, ctx->device, pn[d] * 32, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        sc = c->scal.p;
+      }
     }
-    window_sums_impl(c, sc, n, on_device, opts, lo[d], hi[d], pl, part[d], &st[d]);
+    window_sums_impl(c, sc, pn[d], dev_side, opts, lo[d], hi[d], pl, part[d], &st[d], p_off + p0[d]);
   };
   std::exception_ptr err;
   for (int d = 1; d < ndev; d++) ctx->fan[d - 1]->run([&, d] { shard(d); });
@@ -1076,8 +1111,25 @@ int multi_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devi
   }
   HIPCHK(hipSetDevice(ctx->device));
   if (err) std::rethrow_exception(err);
-  for (int d = 0; d < ndev; d++)
-    if (hi[d] > lo[d]) memcpy(&words[(size_t)(lo[d] - k_lo) * pw], part[d].data(), part[d].size() * 4);
+  if (by_window) {
+    for (int d = 0; d < ndev; d++)
+      if (hi[d] > lo[d]) memcpy(&words[(size_t)(lo[d] - k_lo) * pw], part[d].data(), part[d].size() * 4);
+  } else {
+    // P_k = sum over the devices; an all-zero partial (Z = 0) is the identity, a device without points has none at all
+    for (int k = 0; k < nwin; k++) {
+      if (ctx->is_te()) {
+        msm_host::Ext6 acc = ctx->hte.zero();
+        for (int d = 0; d < ndev; d++)
+          if (!part[d].empty()) acc = ctx->hte.add(acc, te_partial_to_host(ctx, &part[d][(size_t)k * pw]));
+        te_host_to_partial(ctx, acc, &words[(size_t)k * pw]);
+      } else {
+        msm_host::Proj6 acc = ctx->hc.zero();
+        for (int d = 0; d < ndev; d++)
+          if (!part[d].empty()) acc = ctx->hc.add(acc, partial_to_host(ctx, &part[d][(size_t)k * pw]));
+        host_to_partial(ctx, acc, &words[(size_t)k * pw]);
+      }
+    }
+  }
   if (stats) {
     for (int d = 0; d < ndev; d++) {
       stats->n_pairs += st[d].n_pairs;
@@ -1093,9 +1145,11 @@ int multi_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devi
 
 // the one entry the ABI functions use: single- or multi-device
 int any_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, int k_lo, int k_hi,
-                    const Plan& pl, std::vector<uint32_t>& words, msm_result* stats) {
-  if (ctx->children.empty()) return window_sums_impl(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
-  return multi_window_sums(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
+                    const Plan& pl, std::vector<uint32_t>& words, msm_result* stats, const void* const* placed = nullptr) {
+  const uint64_t p_off = opts ? opts->point_lo : 0;
+  if (ctx->children.empty())
+    return window_sums_impl(ctx, placed ? placed[0] : scalars, n, placed ? 1 : on_device, opts, k_lo, k_hi, pl, words, stats, p_off);
+  return multi_window_sums(ctx, scalars, placed, n, on_device, opts, k_lo, k_hi, pl, words, stats, p_off);
 }
 
 // runs f(child) for every child of a multi-device context on the fan-out threads, and f(ctx) on the calling thread;
@@ -1104,9 +1158,15 @@ template <class F>
 int on_all_devices(msm_ctx* ctx, F f) {
   const int nch = (int)ctx->children.size();
   std::vector<int> rc(nch + 1, MSM_OK);
+  // The fan-out jobs write into this frame: whatever the caller's own leg or a wait() throws, every job is waited for
+  // before the frame unwinds (the first exception is re-raised afterwards).
+  std::exception_ptr err;
   for (int i = 0; i < nch; i++) ctx->fan[i]->run([&, i] { rc[i + 1] = f(ctx->children[i]); });
-  rc[0] = f(ctx);
-  for (int i = 0; i < nch; i++) ctx->fan[i]->wait();
+  try { rc[0] = f(ctx); } catch (...) { err = std::current_exception(); }
+  for (int i = 0; i < nch; i++) {
+    try { ctx->fan[i]->wait(); } catch (...) { if (!err) err = std::current_exception(); }
+  }
+  if (err) std::rethrow_exception(err);
   for (int i = 0; i <= nch; i++)
     if (rc[i] != MSM_OK) {
       if (i > 0) ctx->err = ctx->children[i - 1]->err;
@@ -1272,8 +1332,9 @@ int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_ou
 int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, uint8_t* partials_out,
                     msm_result* stats) {
   if (!ctx || !partials_out || (!scalars && n)) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: null argument");
-  if (n > ctx->n_points) return fail(ctx, MSM_ERR_NO_POINTS, "msm_window_sums: %llu scalars but %llu resident points",
-                                     (unsigned long long)n, (unsigned long long)ctx->n_points);
+  if ((opts ? opts->point_lo : 0) + n > ctx->n_points)
+    return fail(ctx, MSM_ERR_NO_POINTS, "msm_window_sums: points [%llu, +%llu) but %llu resident points",
+                (unsigned long long)(opts ? opts->point_lo : 0), (unsigned long long)n, (unsigned long long)ctx->n_points);
   Plan pl;
   if (make_plan(ctx, n, opts, pl)) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: bad window size");
   int k_lo = opts ? opts->k_lo : 0, k_hi = opts ? opts->k_hi : 0;
@@ -1334,12 +1395,12 @@ const msm_host::Curve6* static_host_curve(int curve) {
   }
   return &hc[curve];
 }
-int combine_impl(msm_ctx* ctx, const msm_host::Curve6& C, const uint8_t* partials, int32_t K, int32_t c, msm_result* out);
+int combine_impl(msm_ctx* ctx, const msm_host::Curve6& C, const uint8_t* partials, int32_t K, int32_t c, msm_result* out, int32_t G);
 }  // namespace
 
 namespace {
 // twisted Edwards: (X : Y : Z) in, T rebuilt as (X Z : Y Z : Z^2 : X Y), then the unified-addition Horner
-int te_combine_impl(const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
+int te_combine_impl(const uint8_t* partials, int32_t K, int32_t c, msm_result* out, int32_t G = 1) {
   static msm_host::TeCurve6 C;
   static std::once_flag once;
   std::call_once(once, [] {
@@ -1349,21 +1410,26 @@ int te_combine_impl(const uint8_t* partials, int32_t K, int32_t c, msm_result* o
   });
   std::vector<msm_host::Ext6> P(K);
   for (int k = 0; k < K; k++) {
-    msm_host::Fe6 t[3];
-    for (int j = 0; j < 3; j++) {
-      const uint8_t* b = partials + (size_t)k * 144 + 48 * j;
-      for (int i = 0; i < 6; i++) {
-        uint64_t v = 0;
-        for (int q = 0; q < 8; q++) v |= (uint64_t)b[8 * i + q] << (8 * q);
-        t[j].v[i] = v;
+    P[k] = C.zero();
+    for (int g = 0; g < G; g++) {   // group g's sum of window k
+      msm_host::Fe6 t[3];
+      for (int j = 0; j < 3; j++) {
+        const uint8_t* b = partials + ((size_t)g * K + k) * 144 + 48 * j;
+        for (int i = 0; i < 6; i++) {
+          uint64_t v = 0;
+          for (int q = 0; q < 8; q++) v |= (uint64_t)b[8 * i + q] << (8 * q);
+          t[j].v[i] = v;
+        }
+        if (msm_host::Field6::ge(t[j], C.F.p)) return MSM_ERR_ARG;
+        C.F.mul(t[j], t[j], C.F.r2);
       }
-      if (msm_host::Field6::ge(t[j], C.F.p)) return MSM_ERR_ARG;
-      C.F.mul(t[j], t[j], C.F.r2);
+      msm_host::Ext6 Q;
+      C.F.mul(Q.X, t[0], t[2]);
+      C.F.mul(Q.Y, t[1], t[2]);
+      C.F.mul(Q.Z, t[2], t[2]);
+      C.F.mul(Q.T, t[0], t[1]);
+      P[k] = G == 1 ? Q : C.add(P[k], Q);
     }
-    C.F.mul(P[k].X, t[0], t[2]);
-    C.F.mul(P[k].Y, t[1], t[2]);
-    C.F.mul(P[k].Z, t[2], t[2]);
-    C.F.mul(P[k].T, t[0], t[1]);
   }
   memset(out, 0, sizeof(*out));
   te_horner_points(C, P, c, out);
@@ -1381,37 +1447,46 @@ int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm
       int rc = te_combine_impl(partials, K, c, out);
       return rc ? fail(ctx, rc, "msm_combine: coordinate >= p") : MSM_OK;
     }
-    return combine_impl(ctx, ctx ? ctx->hc : *static_host_curve(MSM_CURVE_BLS12_377_G1), partials, K, c, out);
+    return combine_impl(ctx, ctx ? ctx->hc : *static_host_curve(MSM_CURVE_BLS12_377_G1), partials, K, c, out, 1);
   } MSM_CATCH_ALL(ctx)
 }
 
-int msm_combine_curve(int curve, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
-  if (!partials || !out || K <= 0 || c <= 0) return MSM_ERR_ARG;
+int msm_combine_groups(int curve, const uint8_t* partials, int32_t G, int32_t K, int32_t c, msm_result* out) {
+  if (!partials || !out || K <= 0 || c <= 0 || G <= 0) return MSM_ERR_ARG;
   msm_ctx* const no_ctx = nullptr;
   try {
-    if (curve == MSM_CURVE_ED_ON_BLS12_377) return te_combine_impl(partials, K, c, out);
+    if (curve == MSM_CURVE_ED_ON_BLS12_377) return te_combine_impl(partials, K, c, out, G);
     const msm_host::Curve6* C = static_host_curve(curve);
     if (!C) return MSM_ERR_ARG;
-    return combine_impl(nullptr, *C, partials, K, c, out);
+    return combine_impl(nullptr, *C, partials, K, c, out, G);
   } MSM_CATCH_ALL(no_ctx)
 }
 
+int msm_combine_curve(int curve, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
+  return msm_combine_groups(curve, partials, 1, K, c, out);
+}
+
 namespace {
-int combine_impl(msm_ctx* ctx, const msm_host::Curve6& C, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
+int combine_impl(msm_ctx* ctx, const msm_host::Curve6& C, const uint8_t* partials, int32_t K, int32_t c, msm_result* out, int32_t G) {
   std::vector<msm_host::Proj6> P(K);
   for (int k = 0; k < K; k++) {
-    msm_host::Fe6 t[3];
-    for (int j = 0; j < 3; j++) {
-      const uint8_t* b = partials + (size_t)k * 144 + 48 * j;
-      for (int i = 0; i < 6; i++) {
-        uint64_t v = 0;
-        for (int q = 0; q < 8; q++) v |= (uint64_t)b[8 * i + q] << (8 * q);
-        t[j].v[i] = v;
+    P[k] = C.zero();
+    for (int g = 0; g < G; g++) {   // group g's sum of window k
+      msm_host::Fe6 t[3];
+      for (int j = 0; j < 3; j++) {
+        const uint8_t* b = partials + ((size_t)g * K + k) * 144 + 48 * j;
+        for (int i = 0; i < 6; i++) {
+          uint64_t v = 0;
+          for (int q = 0; q < 8; q++) v |= (uint64_t)b[8 * i + q] << (8 * q);
+          t[j].v[i] = v;
+        }
+        if (msm_host::Field6::ge(t[j], C.F.p)) return fail(ctx, MSM_ERR_ARG, "msm_combine: coordinate >= p");
+        C.F.mul(t[j], t[j], C.F.r2);  // to host Montgomery form
       }
-      if (msm_host::Field6::ge(t[j], C.F.p)) return fail(ctx, MSM_ERR_ARG, "msm_combine: coordinate >= p");
-      C.F.mul(t[j], t[j], C.F.r2);  // to host Montgomery form
+      msm_host::Proj6 Q;
+      Q.X = t[0]; Q.Y = t[1]; Q.Z = t[2];
+      P[k] = G == 1 ? Q : C.add(P[k], Q);
     }
-    P[k].X = t[0]; P[k].Y = t[1]; P[k].Z = t[2];
   }
   memset(out, 0, sizeof(*out));
   horner_to_affine(C, P, c, out);
@@ -1421,12 +1496,13 @@ int combine_impl(msm_ctx* ctx, const msm_host::Curve6& C, const uint8_t* partial
 }
 }  // namespace
 
-int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, msm_result* out) {
-  if (!ctx || !out || (!scalars && n)) return fail(ctx, MSM_ERR_ARG, "msm_run: null argument");
-  if (n > ctx->n_points) return fail(ctx, MSM_ERR_NO_POINTS, "msm_run: %llu scalars but %llu resident points",
-                                     (unsigned long long)n, (unsigned long long)ctx->n_points);
+static int run_impl(msm_ctx* ctx, const void* scalars, const void* const* placed, uint64_t n, int on_device, const msm_opts* opts,
+                    msm_result* out, const char* who) {
+  if ((opts ? opts->point_lo : 0) + n > ctx->n_points)
+    return fail(ctx, MSM_ERR_NO_POINTS, "%s: points [%llu, +%llu) but %llu resident points", who,
+                (unsigned long long)(opts ? opts->point_lo : 0), (unsigned long long)n, (unsigned long long)ctx->n_points);
   Plan pl;
-  if (make_plan(ctx, n, opts, pl)) return fail(ctx, MSM_ERR_ARG, "msm_run: bad window size");
+  if (make_plan(ctx, n, opts, pl)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);
   memset(out, 0, sizeof(*out));
   out->c = pl.c;
   out->K = pl.K;
@@ -1438,7 +1514,7 @@ int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const 
   try {
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<uint32_t> words;
-    any_window_sums(ctx, scalars, n, on_device, opts, 0, pl.K, pl, words, out);
+    any_window_sums(ctx, scalars, n, on_device, opts, 0, pl.K, pl, words, out, placed);
     HIPCHK(hipEventRecord(ctx->ev[10], ctx->stream));
     if (ctx->is_te()) {
       te_horner_to_affine(ctx, words, pl.K, pl.c, out);
@@ -1455,6 +1531,22 @@ int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const 
     out->phase_ms[MSM_T_TOTAL] += ms;
   } MSM_CATCH_ALL(ctx)
   return MSM_OK;
+}
+
+int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, msm_result* out) {
+  if (!ctx || !out || (!scalars && n)) return fail(ctx, MSM_ERR_ARG, "msm_run: null argument");
+  return run_impl(ctx, scalars, nullptr, n, on_device, opts, out, "msm_run");
+}
+
+int msm_run_placed(msm_ctx* ctx, const void* const* dev_scalars, uint64_t n, const msm_opts* opts, msm_result* out) {
+  if (!ctx || !out || !dev_scalars) return fail(ctx, MSM_ERR_ARG, "msm_run_placed: null argument");
+  if (opts && opts->by_window && !ctx->children.empty())
+    return fail(ctx, MSM_ERR_ARG, "msm_run_placed: placed scalars are the shares of a points split (by_window must be 0)");
+  const int ndev = 1 + (int)ctx->children.size();
+  for (int d = 0; d < ndev; d++)
+    if (!dev_scalars[d] && n * (uint64_t)(d + 1) / ndev > n * (uint64_t)d / ndev)
+      return fail(ctx, MSM_ERR_ARG, "msm_run_placed: no scalars for device %d", d);
+  return run_impl(ctx, nullptr, dev_scalars, n, 1, opts, out, "msm_run_placed");
 }
 
 int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy) {
@@ -1826,11 +1918,12 @@ int msm_generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out)
   } MSM_CATCH_ALL(ctx)
 }
 
-int msm_generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void** dev_ptr_out, uint8_t* host_out) {
-  if (!ctx || !dev_ptr_out) return MSM_ERR_ARG;
+int msm_generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void* dev_dst, uint8_t* host_out) {
+  if (!ctx) return MSM_ERR_ARG;
+  if (!dev_dst && !host_out) return fail(ctx, MSM_ERR_ARG, "msm_generate_scalars: neither a device nor a host destination");
   try {
     HIPCHK(hipSetDevice(ctx->device));
-    return msm_gen::generate_scalars(ctx, n, seed, dev_ptr_out, host_out);
+    return msm_gen::generate_scalars(ctx, n, seed, dev_dst, host_out);
   } MSM_CATCH_ALL(ctx)
 }
 

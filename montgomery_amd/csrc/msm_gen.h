@@ -31,9 +31,9 @@ __global__ void __launch_bounds__(256) k_gen_scalars(uint64_t* out, uint64_t n, 
   for (int j = 0; j < 4; j++) out[i * 4 + j] = s[j];
 }
 
-inline int generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void** dev_ptr_out, uint8_t* host_out) {
-  // *dev_ptr_out != NULL on entry: caller-owned device buffer of n * 32 bytes; else the context's buffer
-  void* dst = *dev_ptr_out;
+inline int generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void* dev_dst, uint8_t* host_out) {
+  // dev_dst: caller-owned device buffer of n * 32 bytes; NULL (host copy only): the staging buffer carries them
+  void* dst = dev_dst;
   if (!dst) {
     ctx->ensure(ctx->scal, std::max<uint64_t>(n, 1) * 32);
     dst = ctx->scal.p;
@@ -45,7 +45,6 @@ inline int generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void** dev_
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipGetLastError());
-  *dev_ptr_out = dst;
   return MSM_OK;
 }
 

@@ -239,8 +239,7 @@ static napi_value GenerateScalars(napi_env env, napi_callback_info info) {
   void* data = NULL;
   napi_value buf;
   NAPI_OK(napi_create_buffer(env, (size_t)n * 32, &data, &buf));
-  void* dev = NULL;
-  int rc = msm_generate_scalars(ctx, n, seed, &dev, (uint8_t*)data);
+  int rc = msm_generate_scalars(ctx, n, seed, NULL, (uint8_t*)data);   /* host copy only */
   if (rc != MSM_OK) return throw_msm(env, ctx, rc, "generateScalars");
   return buf;
 }

@@ -44,13 +44,26 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
 
-    from montgomery_amd.distributed import sharded_msm
+    from montgomery_amd.distributed import sharded_msm, sharded_msm_points
     from oracle import msm_oracle as O
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         C = O.BLS12_377
         results = []
+        # points split: every rank sums ALL windows over its share of the points; rank 0 adds the groups per window
+        for name, n, c in (("pa", 23, 9), ("pb", 1, 13)):   # n = 1: rank 0 has no points at all
+            pts, _ = O.random_points_bls377("dist/" + name, n)
+            sc = O.prng_ints("dist/s/" + name, n, C.q)
+            K = -(-127 // c)
+            timing = {}
+            out = sharded_msm_points(lambda first, count: b"".join(_oracle_window_sums(sc[first:first + count], pts[first:first + count], c, K)),
+                                     n, K, c, timing=timing)
+            assert "all_gather_ms" in timing
+            if rank == 0:
+                results.append((out[1], O.msm_batched_affine(sc, pts, c=c)))
+            else:
+                assert out is None
         for name, n, c in (("a", 24, 9), ("b", 5, 16), ("cancel", 2, 7)):
             pts, _ = O.random_points_bls377("dist/" + name, n)
             sc = O.prng_ints("dist/s/" + name, n, C.q)
@@ -155,6 +168,29 @@ def test_sharded_msm_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert len(results) == 3
+    assert len(results) == 5
     for got, exp in results:
         assert got == exp
+
+
+def test_point_shards_partition_and_group_combine():
+    """The share of every rank as msm_ctx_create_multi cuts it, and msm_combine_groups = sum over the groups per window,
+    then the Horner step (checked against the oracle with the points split three ways, one share empty)."""
+    from montgomery_amd.distributed import combine_groups_host, point_shards
+    from oracle import msm_oracle as O
+
+    for n in (0, 1, 7, 64, 1000):
+        for world in (1, 2, 3, 8):
+            sh = point_shards(n, world)
+            assert sh[0][0] == 0 and sum(c for _, c in sh) == n
+            assert all(a[0] + a[1] == b[0] for a, b in zip(sh, sh[1:]))
+            assert max(c for _, c in sh) - min(c for _, c in sh) <= 1
+    C = O.BLS12_377
+    pts, _ = O.random_points_bls377("dist/groups", 11)
+    sc = O.prng_ints("dist/groups/s", 11, C.q)
+    c = 6
+    K = -(-127 // c)
+    parts = b""
+    for first, count in ((0, 5), (5, 0), (5, 6)):
+        parts += b"".join(_oracle_window_sums(sc[first:first + count], pts[first:first + count], c, K))
+    assert combine_groups_host(parts, 3, K, c) == O.msm_batched_affine(sc, pts, c=c)

@@ -92,9 +92,10 @@ def test_strict_scalars_status(gpu_ctx):
 
 @pytest.mark.parametrize("lg", [8, 16])
 def test_device_list_context_on_one_gpu(gpu_ctx, lg):
-    """msm_ctx_create_multi with the device list [0, 0, 0]: three device contexts (here on the same GPU), the windows
-    sharded 3 / 3 / 2 across them by host threads inside the library, partition sums combined on the host.  Host and
-    device scalars, MSM and window sums, against the single-device context on the same inputs."""
+    """msm_ctx_create_multi with the device list [0, 0, 0]: three device contexts (here on the same GPU) driven by host
+    threads inside the library -- by points (default: every device runs all windows on a third of the points and gets only
+    that third of the scalars) and by window (3 / 3 / 2 windows each over all points); the sums are combined on the host.
+    Host, device and pre-placed scalars, MSM and window sums, against the single-device context on the same inputs."""
     from montgomery_amd.api import MsmContext
 
     n = 1 << lg
@@ -107,13 +108,33 @@ def test_device_list_context_on_one_gpu(gpu_ctx, lg):
     exp = O.aff_scale(sum(x * y for x, y in zip(a, O.scalars_from_bytes(sb))) % C.q, G, C.p)
     assert single.as_tuple() == exp
     r_host, info = multi.run(sb)
-    assert r_host.as_tuple() == exp
-    assert info["n_pairs"] == info1["n_pairs"] and info["K"] == info1["K"]
+    assert r_host.as_tuple() == exp and info["K"] == info1["K"]
+    r_win, info_w = multi.run(sb, by_window=True)
+    assert r_win.as_tuple() == exp
+    assert info_w["n_pairs"] == info1["n_pairs"] and info_w["K"] == info1["K"]   # the same windows, only on three contexts
     r_dev, _ = multi.run_device(dev, n)
     assert r_dev.as_tuple() == exp
+    assert multi.run_device(dev, n, by_window=True)[0].as_tuple() == exp
+    # scalars placed by the caller: one device buffer per device with that device's share of the scalars
+    shares = [(n * d // 3, n * (d + 1) // 3) for d in range(3)]
+    placed = []
+    for lo, hi in shares:
+        p = multi.device_alloc(max(32 * (hi - lo), 32))
+        multi.device_upload(p, sb[32 * lo:32 * hi] or b"\0" * 32)
+        placed.append(p)
+    assert multi.run_placed(placed, n)[0].as_tuple() == exp
+    for p in placed:
+        multi.device_free(p)
     K, c = info["K"], info["c"]
     parts, _ = multi.window_sums(sb, n, 0, K)
     assert multi.combine(parts, K, c).as_tuple() == exp
+    parts, _ = multi.window_sums(sb, n, 0, K, by_window=True)
+    assert multi.combine(parts, K, c).as_tuple() == exp
+    # a points shard through the single-device context: windows over [first, first + count) only, groups added by msm_combine_groups
+    from montgomery_amd.distributed import combine_groups_host
+
+    groups = b"".join(gpu_ctx.window_sums(sb[32 * lo:32 * hi], hi - lo, 0, K, c=c, point_lo=lo)[0] for lo, hi in shares)
+    assert combine_groups_host(groups, 3, K, c) == exp
     # a second point set on the multi context, then back
     sid = multi.pointset_create()
     pts, _ = O.random_points_bls377("bnd/multi", 9)
@@ -126,7 +147,34 @@ def test_device_list_context_on_one_gpu(gpu_ctx, lg):
     multi.close()
 
 
-def _sharded_bench(world, log2n):
+def test_curve_facade_takes_a_device_list():
+    """`Weierstrass.create(params, devices=[...])` / `TwistedEdwards.create(params, devices=[...])` (INTEGRATION.md): the
+    reference-shaped curve object over a device-list context, here [0, 0]."""
+    from montgomery_amd import api
+
+    cv = api.Weierstrass.create(api.BLS12_377_PARAMS, devices=[0, 0])
+    assert cv.context.n_devices == 2
+    pts, _ = O.random_points_bls377("bnd/facade", 33)
+    sc = O.prng_ints("bnd/facade/s", 33, C.q)
+    with cv.Parallel.getPointer(33 * 96) as pp, cv.Parallel.getScalarPointer(33 * 32) as sp:
+        cv.Parallel.pointsFromBytes(pp, O.points_to_bytes(pts, 48), 33)
+        cv.Parallel.scalarsFromBytes(sp, O.scalars_to_bytes(sc), 33)
+        res = cv.Parallel.msm(sp, pp, 33)["result"]
+    assert (res.x, res.y) == O.msm_naive_affine(sc, pts, C)
+    cv.context.close()
+    E = O.ED_ON_BLS12_377
+    te = api.TwistedEdwards.create(api.ED_ON_BLS12_377_PARAMS, devices=[0, 0])
+    tp, _ = O.random_points_ed377("bnd/facade/ed", 21)
+    ts = O.prng_ints("bnd/facade/ed/s", 21, E.q)
+    with te.Parallel.getPointer(21 * 64) as pp, te.Parallel.getScalarPointer(21 * 32) as sp:
+        te.Parallel.pointsFromBytes(pp, O.points_to_bytes(tp, 32), 21)
+        te.Parallel.scalarsFromBytes(sp, O.scalars_to_bytes(ts), 21)
+        res = te.Parallel.msm(sp, pp, 21)["result"]
+    assert (res.x, res.y) == O.msm_basic_te(ts, tp)
+    te.context.close()
+
+
+def _sharded_bench(world, log2n, split="auto"):
     import json
     import os
     import socket
@@ -141,11 +189,23 @@ def _sharded_bench(world, log2n):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
-           "--log2n", str(log2n), "--dist-backend", "gloo", "--no-cpu-baseline"]
+           "--log2n", str(log2n), "--dist-backend", "gloo", "--no-cpu-baseline", "--split", split]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     return json.loads(line)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_points_shards_on_one_gpu(world):
+    """bench.py --split points: every rank runs all windows on its share of the points (its scalars only), one all-gather,
+    rank 0 adds the groups per window (msm_combine_groups) and verifies the result against the discrete logs; the line
+    carries what every rank spent where."""
+    d = _sharded_bench(world, 18, "points")
+    assert d["n_gpus"] == world and d["verified"] is True, d
+    assert f"points-shard x{world}" in d["config"]["parallelism"]
+    assert len(d["ranks"]) == world and all(r["shard"][1] == (1 << 18) // world for r in d["ranks"])
+    assert all("phase_ms" in r and r["all_gather_ms"] is not None for r in d["ranks"])
 
 
 @pytest.mark.parametrize("world", [4, 8])

@@ -1,14 +1,36 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+"""Per-rank work of a G-GPU run of the 2^26 MSM, timed on ONE GPU: the window shard (K / G windows over all points) against the
+points shard (all K windows over n / G points), for G = 1, 2, 4, 8.  The proxy behind montgomery_amd.distributed.choose_split.
+usage: python tools/shard_time.py [LOG2N]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from montgomery_amd.api import MsmContext
-n = 1 << 26
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 26
+n = 1 << lg
 ctx = MsmContext()
 ctx.generate_points(n, seed=7)
 dev, _ = ctx.generate_scalars(n, seed=9)
 c, K = ctx.plan(n)
-for (lo, hi) in ((0, 1), (7, 8), (0, 2), (0, 4), (0, 8)):
-    ctx.window_sums(dev, n, lo, hi, c=c, on_device=True)
-    best = 1e9
-    for _ in range(3):
-        t = time.perf_counter(); parts, info = ctx.window_sums(dev, n, lo, hi, c=c, on_device=True); best = min(best, time.perf_counter() - t)
-    print(f"windows [{lo},{hi}) of {K}: {best*1e3:.1f} ms", {k: round(v, 1) for k, v in info["phase_ms"].items()})
+
+def best_of(f, reps=3):
+    f()
+    best, info = 1e9, None
+    for _ in range(reps):
+        t = time.perf_counter(); _, info = f(); best = min(best, time.perf_counter() - t)
+    return best * 1e3, info
+
+full, _ = best_of(lambda: ctx.window_sums(dev, n, 0, K, c=c, on_device=True))
+print(f"2^{lg}, c = {c}, K = {K}: all windows, all points {full:.1f} ms")
+for G in (2, 4, 8):
+    if K % G == 0:
+        w = K // G
+        # the slowest window shard: the lowest windows are full, the top one is lighter
+        tw, iw = best_of(lambda: ctx.window_sums(dev, n, 0, w, c=c, on_device=True))
+        tt, _ = best_of(lambda: ctx.window_sums(dev, n, K - w, K, c=c, on_device=True))
+    else:
+        tw = tt = float("nan"); iw = None
+    m = n // G
+    first = (G - 1) * m
+    tp, ip = best_of(lambda: ctx.window_sums(dev + 32 * first, m, 0, K, c=c, on_device=True, point_lo=first))
+    print(f"G = {G}: window shard {tw:.1f} ms (top windows {tt:.1f})  -> x{full / tw:.2f}   points shard {tp:.1f} ms -> x{full / tp:.2f}")
+    print("   window phases", {k: round(v, 1) for k, v in (iw or {"phase_ms": {}})["phase_ms"].items()})
+    print("   points phases", {k: round(v, 1) for k, v in ip["phase_ms"].items()})
