@@ -201,6 +201,16 @@ int msm_test_curve_op(msm_ctx* ctx, int op, const uint8_t* p, const uint8_t* q, 
  * shared inversion): mode 1 = regular rounds, 2 = tail rounds (operand descriptors; an all-zero H_e is passed as
  * "no second operand").  steps >= 1. */
 int msm_test_batch_add_mode(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t* out, uint64_t n, int mode, uint32_t steps);
+/* Bucket reduction alone (Weierstrass curves): buckets = K x L affine points (x || y, 48-byte LE; (0, 0) = empty bucket),
+ * bucket l of window k at index k L + l - 1; L a power of two.  Writes P_k = sum_l l B_(k,l) as K x 144 bytes (X || Y || Z)
+ * and the device time of the reduction in *ms_out.
+ *   mode 0: as the MSM does it -- projective row / triangle sums per chunk of buckets and bit-sliced weights
+ *           (reduceBucketsColumnProjective, src/msm-batched-affine.ts:556-583);
+ *   mode 1: the all-affine reduction of the reference's single-thread MSM (reduceBucketsAffine,
+ *           src/msm-batched-affine-single-thread.ts:522-667, doc/zprize22.md:317-358) out of in-place batched-affine
+ *           additions and doublings; 2^c0 = buckets per chunk of its linear part.  SURVEY section 8(f)-3. */
+int msm_test_bucket_reduce(msm_ctx* ctx, const uint8_t* buckets, int32_t K, uint32_t L, int mode, int c0, uint8_t* partials_out,
+                           float* ms_out);
 
 #ifdef __cplusplus
 }

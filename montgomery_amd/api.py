@@ -411,6 +411,18 @@ class MsmContext:
         self._check(self._lib.msm_test_batch_add_mode(self._h, bg, bh, out, n, mode, steps))
         return bytes(out)
 
+    def test_bucket_reduce(self, buckets: BytesLike, K: int, L: int, mode: int = 0, c0: int = 2) -> Tuple[bytes, float]:
+        """P_k = sum_l l B_(k,l) for K windows of L buckets (x || y, 48-byte LE each, (0, 0) = empty): K x 144 bytes (X, Y, Z)
+        and the device time in ms.  mode 0: the projective reduction of the MSM; mode 1: the reference's all-affine
+        reduction (reduceBucketsAffine) out of in-place batched additions, chunks of 2^c0 buckets."""
+        if len(buckets) != 96 * K * L:
+            raise MsmError(_lib.MSM_ERR_ARG, f"expected {96 * K * L} bytes of buckets, got {len(buckets)}")
+        buf = (C.c_uint8 * len(buckets)).from_buffer_copy(bytes(buckets))
+        out = (C.c_uint8 * (144 * K))()
+        ms = C.c_float(0)
+        self._check(self._lib.msm_test_bucket_reduce(self._h, buf, K, L, mode, c0, out, C.byref(ms)))
+        return bytes(out), float(ms.value)
+
     def test_batch_add(self, g: BytesLike, h: BytesLike) -> bytes:
         n = len(g) // (2 * self.coord_bytes)
         bg = (C.c_uint8 * len(g)).from_buffer_copy(bytes(g))

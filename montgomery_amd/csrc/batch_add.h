@@ -46,6 +46,9 @@ struct BatchArgs {
   const uint16_t* oidx;     // MODE_GATHER, chunk-ordered pairs (k_chunk_order): pair e writes element (e & ~(CO_PAIRS - 1)) + oidx[e]
   uint32_t* out_rows;       // MODE_GATHER: if set, results leave as 128-byte element rows [x | y | 0] (element k at byte 128 k) instead
                             // of planes; a round with slots == nullptr reads such rows back (pair e = rows 2e, 2e + 1)
+  const uint32_t* desc_b;   // MODE_SEARCH, optional: element index of the second operand of pair e (default: first operand + 1)
+  uint32_t inplace;         // MODE_SEARCH: the sum replaces the FIRST operand (out == in): the in-place batched additions of the
+                            // all-affine bucket reduction, src/msm-batched-affine-single-thread.ts:522-667
 };
 constexpr uint32_t CO_PAIRS = 4096;   // pairs per block of k_chunk_order (sort_kernels.h)
 
@@ -133,8 +136,8 @@ struct PairLoc<MODE_REGULAR> {   // elements 2e, 2e + 1: uniform base of the ste
   __device__ __forceinline__ bool absentB() const { return false; }
 };
 template <>
-struct PairLoc<MODE_SEARCH> {    // elements idx, idx + 1 from the descriptor
-  uint64_t a;                    // byte offset of element idx inside a plane
+struct PairLoc<MODE_SEARCH> {    // elements idx, idx + 1 (or desc_b's) from the descriptors
+  uint64_t a, b;                 // byte offsets of the two operands inside a plane (b = a when the second is absent)
   bool b_absent, skip;
   __device__ __forceinline__ bool absentA() const { return skip; }
   __device__ __forceinline__ bool absentB() const { return b_absent; }
@@ -162,6 +165,7 @@ __device__ __forceinline__ void ba_locate<MODE_SEARCH>(PairLoc<MODE_SEARCH>& L, 
   const uint32_t d = active ? a.desc[(uint64_t)i * T + t] : 0u;
   L.a = (uint64_t)(d >> 1) * 16;
   L.b_absent = (d & 1u) == 0;
+  L.b = L.b_absent ? L.a : (a.desc_b && active) ? (uint64_t)a.desc_b[(uint64_t)i * T + t] * 16 : L.a + 16;
   L.skip = !active;
 }
 template <>
@@ -197,10 +201,11 @@ __device__ __forceinline__ void ba_load_x(Pk& x1, Pk& x2, const PairLoc<MODE>& L
     ba_load3(x2, L.base + 16, 32u * t, a.in_cap * 16);
   } else {
     const char* p = reinterpret_cast<const char*>(a.in) + L.a;
+    const char* q = reinterpret_cast<const char*>(a.in) + L.b;
     const uint64_t s = a.in_cap * 16;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      const uint4 v = *reinterpret_cast<const uint4*>(p + j * s), u = *reinterpret_cast<const uint4*>(p + j * s + (L.b_absent ? 0 : 16));
+      const uint4 v = *reinterpret_cast<const uint4*>(p + j * s), u = *reinterpret_cast<const uint4*>(q + j * s);
       x1.w[4 * j] = v.x; x1.w[4 * j + 1] = v.y; x1.w[4 * j + 2] = v.z; x1.w[4 * j + 3] = v.w;
       x2.w[4 * j] = u.x; x2.w[4 * j + 1] = u.y; x2.w[4 * j + 2] = u.z; x2.w[4 * j + 3] = u.w;
     }
@@ -223,9 +228,10 @@ __device__ __forceinline__ void ba_load_y(Pk& y1, Pk& y2, const PairLoc<MODE>& L
   } else {
     const uint64_t s = a.in_cap * 16;
     const char* p = reinterpret_cast<const char*>(a.in) + L.a + 3 * s;
+    const char* q = reinterpret_cast<const char*>(a.in) + L.b + 3 * s;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      const uint4 v = *reinterpret_cast<const uint4*>(p + j * s), u = *reinterpret_cast<const uint4*>(p + j * s + (L.b_absent ? 0 : 16));
+      const uint4 v = *reinterpret_cast<const uint4*>(p + j * s), u = *reinterpret_cast<const uint4*>(q + j * s);
       y1.w[4 * j] = v.x; y1.w[4 * j + 1] = v.y; y1.w[4 * j + 2] = v.z; y1.w[4 * j + 3] = v.w;
       y2.w[4 * j] = u.x; y2.w[4 * j + 1] = u.y; y2.w[4 * j + 2] = u.z; y2.w[4 * j + 3] = u.w;
     }
@@ -246,7 +252,7 @@ __device__ __forceinline__ void ba_load_b(Pk& x2, Pk& y2, const PairLoc<MODE>& L
     ba_load3(y2, L.base + 3 * a.in_cap * 16 + 16, 32u * t, a.in_cap * 16);
   } else {
     const uint64_t s = a.in_cap * 16;
-    const char* p = reinterpret_cast<const char*>(a.in) + L.a + (L.b_absent ? 0 : 16);
+    const char* p = reinterpret_cast<const char*>(a.in) + L.b;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const uint4 v = *reinterpret_cast<const uint4*>(p + j * s), u = *reinterpret_cast<const uint4*>(p + (j + 3) * s);
@@ -514,6 +520,12 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
           }
           row[6] = make_uint4(0, 0, 0, 0);
           row[7] = make_uint4(0, 0, 0, 0);
+        } else if (MODE == MODE_SEARCH && a.inplace) {   // uniform: the sum replaces the first operand
+          if constexpr (MODE == MODE_SEARCH) {
+            char* ob = reinterpret_cast<char*>(a.out) + L.a;
+            ba_store3(ob, 0u, a.out_cap * 16, x3);
+            ba_store3(ob + 3 * a.out_cap * 16, 0u, a.out_cap * 16, y3);
+          }
         } else
         {
         char* ob = reinterpret_cast<char*>(a.out + (uint64_t)BA_STEP(i) * T);

@@ -377,6 +377,97 @@ void host_to_partial(const msm_ctx* ctx, const msm_host::Proj6& P, uint32_t* out
   }
 }
 
+// Bucket reduction of kc windows of L buckets each: P_k = sum_l l * B_(k,l) (reduceBucketsColumnProjective + the partition
+// sums, src/msm-batched-affine.ts:556-583, :312-319) -> h_partials_out, kc x 36 (32 on the Edwards path) words.  The bucket
+// sums come as projective points from k_bucket_finish (`bucket_proj`) or as the first element of every bucket in the tree
+// buffer (`fin`, `off_fin`).  Runs on w.stream, records w.ev[4] behind its last kernel and returns when the sums are on the host.
+void reduce_buckets(msm_ctx* ctx, msm_ctx::Workspace& w, const uint4* fin, uint64_t fin_cap, const uint32_t* off_fin,
+                    const uint32_t* bucket_proj, uint32_t L, int kc, uint32_t* h_partials_out) {
+  hipStream_t s = w.stream;
+  const bool te = ctx->is_te();
+  const uint64_t nb = (uint64_t)kc * L;
+  const int part_words = te ? 32 : 36;
+  // buckets per lane: enough lanes to fill the chip, but never more than 16 buckets deep (2 additions each)
+  uint32_t TC = 2;
+  while (TC < 16 && nb / TC > 65536) TC *= 2;
+  MSM_KNOB(TC, "MSM_TC", 1);
+  TC = std::min<uint32_t>(TC, L);
+  uint32_t nchunks = (L + TC - 1) / TC;
+  // bit-sliced weighting (Weierstrass path, enough chunks to matter, TC a power of two)
+  uint32_t nbits = 0;
+  while ((1u << nbits) < nchunks) nbits++;
+  const bool bit_sliced = !te && nchunks >= 64 && (TC & (TC - 1)) == 0;
+  ctx->ensure(w.columns, (size_t)kc * nchunks * 4 * NL * 4);
+  ctx->ensure(w.partials, (size_t)kc * 36 * 4);
+  {
+    uint32_t threads = nchunks * (uint32_t)kc;
+    if (te) {
+      hipLaunchKernelGGL(te::k_te_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, fin, fin_cap,
+                         off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
+      hipLaunchKernelGGL(te::k_te_window_sum, dim3(kc), dim3(te::TE_WS_THREADS), 0, s, (uint32_t*)w.partials.p,
+                         (const uint32_t*)w.columns.p, nchunks);
+    } else if (bit_sliced) {
+      ctx->ensure(w.rows_sum, (size_t)kc * nchunks * 3 * NL * 4);
+      W_LAUNCH(ctx, k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p,
+                         (uint32_t*)w.rows_sum.p, fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
+      // first stage: one wave per 512 elements (8 per lane; at 2^20 that is about one wave per SIMD) -- the masked sums
+      // have half as many elements as the triangle sum and get half as many blocks; second stage: one wave per
+      // (window, bit) over the block sums (unused block slots stay zero = the identity)
+      const uint32_t nblk = std::max<uint32_t>(2, nchunks / (8 * BT_THREADS));
+      const size_t c2_bytes = (size_t)kc * (nbits + 1) * nblk * 3 * NL * 4;
+      ctx->ensure(w.columns2, c2_bytes);
+      ctx->ensure(w.partials, (size_t)kc * (nbits + 1) * 36 * 4);
+      HIPCHK(hipMemsetAsync(w.columns2.p, 0, c2_bytes, s));
+      W_LAUNCH(ctx, k_bit_tree, dim3(nbits * (nblk / 2) + nblk, 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.columns2.p,
+                         (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, nbits, 1, 0, nblk);
+      W_LAUNCH(ctx, k_bit_tree, dim3(1, nbits + 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.partials.p,
+                         (const uint32_t*)w.columns2.p, (const uint32_t*)nullptr, nblk, nbits, 0, 1, 1u);
+    } else {
+      W_LAUNCH(ctx, k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, (uint32_t*)nullptr,
+                         fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
+      if (nchunks > 2 * WS_THREADS) {
+        // two-stage: blocks of 2 columns per lane, then one block per window over the block sums
+        const uint32_t per_block = 2 * WS_THREADS;
+        const uint32_t nblk = (nchunks + per_block - 1) / per_block;
+        ctx->ensure(w.columns2, (size_t)kc * nblk * 3 * NL * 4);
+        W_LAUNCH(ctx, k_column_tree, dim3(nblk, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.columns2.p,
+                           (const uint32_t*)w.columns.p, nchunks, per_block);
+        W_LAUNCH(ctx, k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
+                           (const uint32_t*)w.columns2.p, nblk);
+      } else {
+        W_LAUNCH(ctx, k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
+                           (const uint32_t*)w.columns.p, nchunks);
+      }
+    }
+  }
+  if (bit_sliced) {
+    // read the (nbits + 1) sums per window back and finish P_k = tri + TC * sum_b 2^b S_b on the host
+    HIPCHK(hipMemcpyAsync(w.h_part, w.partials.p, (size_t)kc * (nbits + 1) * 36 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(w.ev[4], s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    const auto& C = ctx->hc;
+    for (int kk = 0; kk < kc; kk++) {
+      const uint32_t* base = w.h_part + (size_t)kk * (nbits + 1) * 36;
+      msm_host::Proj6 acc = C.zero();
+      for (int b = (int)nbits - 1; b >= 0; b--) {
+        acc = C.dbl(acc);
+        acc = C.add(acc, partial_to_host(ctx, base + (size_t)b * 36));
+      }
+      for (uint32_t t = TC; t > 1; t >>= 1) acc = C.dbl(acc);   // TC is a power of two on this path
+      acc = C.add(acc, partial_to_host(ctx, base + (size_t)nbits * 36));
+      host_to_partial(ctx, acc, h_partials_out + (size_t)kk * 36);
+    }
+    return;
+  }
+  HIPCHK(hipMemcpyAsync(w.h_part, w.partials.p, (size_t)kc * part_words * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(w.ev[4], s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  memcpy(h_partials_out, w.h_part, (size_t)kc * part_words * 4);
+}
+
+
 // Partition sums P_k for windows [k_lo, k_hi) over the points [p_lo, p_lo + n) -> w.h_part[(k - k_lo) * 36 ...]
 // scalars: device pointer, n x 8 words.
 void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars_all, uint64_t p_lo, uint64_t n, const Plan& pl,
@@ -736,91 +827,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   if (total_slots == 0) HIPCHK(hipEventRecord(w.ev[6], s));
   HIPCHK(hipEventRecord(w.ev[3], s));
 
-  // bucket reduction
-  // buckets per lane: enough lanes to fill the chip, but never more than 16 buckets deep (2 additions each)
-  uint32_t TC = 2;
-  while (TC < 16 && nb / TC > 65536) TC *= 2;
-  MSM_KNOB(TC, "MSM_TC", 1);
-  TC = std::min<uint32_t>(TC, L);
-  uint32_t nchunks = (L + TC - 1) / TC;
-  // bit-sliced weighting (Weierstrass path, enough chunks to matter, TC a power of two)
-  uint32_t nbits = 0;
-  while ((1u << nbits) < nchunks) nbits++;
-  const bool bit_sliced = !te && nchunks >= 64 && (TC & (TC - 1)) == 0;
-  ctx->ensure(w.columns, (size_t)kc * nchunks * 4 * NL * 4);
-  ctx->ensure(w.partials, (size_t)kc * 36 * 4);
-  {
-    uint32_t threads = nchunks * (uint32_t)kc;
-    if (te) {
-      hipLaunchKernelGGL(te::k_te_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, fin, fin_cap,
-                         off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
-      hipLaunchKernelGGL(te::k_te_window_sum, dim3(kc), dim3(te::TE_WS_THREADS), 0, s, (uint32_t*)w.partials.p,
-                         (const uint32_t*)w.columns.p, nchunks);
-    } else if (bit_sliced) {
-      ctx->ensure(w.rows_sum, (size_t)kc * nchunks * 3 * NL * 4);
-      W_LAUNCH(ctx, k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p,
-                         (uint32_t*)w.rows_sum.p, fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
-      // first stage: one wave per 512 elements (8 per lane; at 2^20 that is about one wave per SIMD) -- the masked sums
-      // have half as many elements as the triangle sum and get half as many blocks; second stage: one wave per
-      // (window, bit) over the block sums (unused block slots stay zero = the identity)
-      const uint32_t nblk = std::max<uint32_t>(2, nchunks / (8 * BT_THREADS));
-      const size_t c2_bytes = (size_t)kc * (nbits + 1) * nblk * 3 * NL * 4;
-      ctx->ensure(w.columns2, c2_bytes);
-      ctx->ensure(w.partials, (size_t)kc * (nbits + 1) * 36 * 4);
-      HIPCHK(hipMemsetAsync(w.columns2.p, 0, c2_bytes, s));
-      W_LAUNCH(ctx, k_bit_tree, dim3(nbits * (nblk / 2) + nblk, 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.columns2.p,
-                         (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, nbits, 1, 0, nblk);
-      W_LAUNCH(ctx, k_bit_tree, dim3(1, nbits + 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.partials.p,
-                         (const uint32_t*)w.columns2.p, (const uint32_t*)nullptr, nblk, nbits, 0, 1, 1u);
-    } else {
-      W_LAUNCH(ctx, k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, (uint32_t*)nullptr,
-                         fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
-      if (nchunks > 2 * WS_THREADS) {
-        // two-stage: blocks of 2 columns per lane, then one block per window over the block sums
-        const uint32_t per_block = 2 * WS_THREADS;
-        const uint32_t nblk = (nchunks + per_block - 1) / per_block;
-        ctx->ensure(w.columns2, (size_t)kc * nblk * 3 * NL * 4);
-        W_LAUNCH(ctx, k_column_tree, dim3(nblk, kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.columns2.p,
-                           (const uint32_t*)w.columns.p, nchunks, per_block);
-        W_LAUNCH(ctx, k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
-                           (const uint32_t*)w.columns2.p, nblk);
-      } else {
-        W_LAUNCH(ctx, k_window_sum, dim3(kc), dim3(WS_THREADS), 0, s, (uint32_t*)w.partials.p,
-                           (const uint32_t*)w.columns.p, nchunks);
-      }
-    }
-  }
-  if (bit_sliced) {
-    // read the (nbits + 1) sums per window back and finish P_k = tri + TC * sum_b 2^b S_b on the host
-    HIPCHK(hipMemcpyAsync(w.h_part, w.partials.p, (size_t)kc * (nbits + 1) * 36 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipEventRecord(w.ev[4], s));
-    HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipGetLastError());
-    const auto& C = ctx->hc;
-    for (int kk = 0; kk < kc; kk++) {
-      const uint32_t* base = w.h_part + (size_t)kk * (nbits + 1) * 36;
-      msm_host::Proj6 acc = C.zero();
-      for (int b = (int)nbits - 1; b >= 0; b--) {
-        acc = C.dbl(acc);
-        acc = C.add(acc, partial_to_host(ctx, base + (size_t)b * 36));
-      }
-      for (uint32_t t = TC; t > 1; t >>= 1) acc = C.dbl(acc);   // TC is a power of two on this path
-      acc = C.add(acc, partial_to_host(ctx, base + (size_t)nbits * 36));
-      host_to_partial(ctx, acc, h_partials_out + (size_t)kk * 36);
-    }
-    float ms;
-    HIPCHK(hipEventElapsedTime(&ms, w.ev[0], w.ev[1])); st.ms_digits += ms;
-    HIPCHK(hipEventElapsedTime(&ms, w.ev[1], w.ev[2])); st.ms_sort += ms;
-    HIPCHK(hipEventElapsedTime(&ms, w.ev[2], w.ev[3])); st.ms_acc += ms;
-    HIPCHK(hipEventElapsedTime(&ms, w.ev[2], w.ev[6])); st.ms_r1 += ms;
-    HIPCHK(hipEventElapsedTime(&ms, w.ev[3], w.ev[4])); st.ms_red += ms;
-    return;
-  }
-  HIPCHK(hipMemcpyAsync(w.h_part, w.partials.p, (size_t)kc * part_words * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipEventRecord(w.ev[4], s));
-  HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipGetLastError());
-  memcpy(h_partials_out, w.h_part, (size_t)kc * part_words * 4);
+  reduce_buckets(ctx, w, fin, fin_cap, off_fin, bucket_proj, L, kc, h_partials_out);
   float ms;
   HIPCHK(hipEventElapsedTime(&ms, w.ev[0], w.ev[1])); st.ms_digits += ms;
   HIPCHK(hipEventElapsedTime(&ms, w.ev[1], w.ev[2])); st.ms_sort += ms;
@@ -1834,6 +1841,151 @@ int msm_test_curve_op(msm_ctx* ctx, int op, const uint8_t* p, const uint8_t* q, 
     HIPCHK(hipMemcpyAsync(out, d + 2 * n * nb, n * nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
+    return MSM_OK;
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_test_bucket_reduce(msm_ctx* ctx, const uint8_t* buckets, int32_t K, uint32_t L, int mode, int c0, uint8_t* partials_out,
+                           float* ms_out) {
+  if (!ctx || !buckets || !partials_out || K <= 0 || L == 0 || (L & (L - 1)) || (mode != 0 && mode != 1))
+    return fail(ctx, MSM_ERR_ARG, "msm_test_bucket_reduce: bad argument");
+  if (ctx->is_te()) return fail(ctx, MSM_ERR_ARG, "msm_test_bucket_reduce: Weierstrass curves only");
+  int cl = 0;
+  while ((1u << cl) < L) cl++;
+  if (c0 < 0 || c0 > cl) return fail(ctx, MSM_ERR_ARG, "msm_test_bucket_reduce: c0 must be in [0, log2 L]");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    msm_ctx::Workspace& w = ctx->ws[0];
+    hipStream_t s = w.stream;
+    const uint64_t nb = (uint64_t)K * L;
+    const uint64_t cap = nb + 2 * 257 * 512 + 256;   // plane capacity: idle lanes read (and ignore) past the end
+    DevBuf wire, rows, planes, desc, scr;
+    ctx->ensure(wire, nb * 96);
+    ctx->ensure(rows, nb * ROW_WORDS * 4);
+    ctx->ensure(planes, cap * 96);
+    HIPCHK(hipMemcpyAsync(wire.p, buckets, nb * 96, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, s));
+    HIPCHK(hipMemsetAsync(planes.p, 0, cap * 96, s));
+    W_LAUNCH(ctx, k_points_from_wire, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)rows.p, (const uint32_t*)wire.p,
+             nb, 0, (uint32_t*)ctx->errflag.p);
+    hipLaunchKernelGGL(k_test_rows_to_planes, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint4*)planes.p, cap,
+                       (const uint32_t*)rows.p, (uint32_t)nb);
+    std::vector<uint32_t> parts((size_t)K * 36, 0);
+    float ms = 0;
+    if (mode == 0) {
+      // every bucket holds exactly one element of the tree buffer: offsets 0, 1, 2, ...
+      std::vector<uint32_t> off(nb + 1);
+      for (uint64_t b = 0; b <= nb; b++) off[b] = (uint32_t)b;
+      ctx->ensure(desc, (nb + 1) * 4);
+      HIPCHK(hipMemcpyAsync(desc.p, off.data(), (nb + 1) * 4, hipMemcpyHostToDevice, s));
+      HIPCHK(hipEventRecord(w.ev[3], s));
+      reduce_buckets(ctx, w, (const uint4*)planes.p, cap, (const uint32_t*)desc.p, nullptr, L, K, parts.data());
+      HIPCHK(hipEventElapsedTime(&ms, w.ev[3], w.ev[4]));
+    } else {
+      // The rounds of reduceBucketsAffine as (first operand, second operand) element lists; the sum replaces the first.
+      // e(k, l) = k L + l - 1 for the 1-based bucket index l of the reference.
+      const uint32_t L0 = 1u << c0, D = L / L0;
+      std::vector<std::vector<uint32_t>> ga, gb;
+      auto e = [&](int k, uint64_t l) { return (uint32_t)((uint64_t)k * L + l - 1); };
+      auto round = [&](const std::function<void(int, std::vector<uint32_t>&, std::vector<uint32_t>&)>& fill) {
+        std::vector<uint32_t> A, B;
+        for (int k = 0; k < K; k++) fill(k, A, B);
+        if (!A.empty()) { ga.push_back(std::move(A)); gb.push_back(std::move(B)); }
+      };
+      // linear part: suffix sums inside every chunk of L0 buckets (:563-588)
+      for (uint32_t l = L0 - 1; l >= 1; l--)
+        round([&](int k, std::vector<uint32_t>& A, std::vector<uint32_t>& B) {
+          for (uint32_t d = 0; d < D; d++) { A.push_back(e(k, (uint64_t)d * L0 + l)); B.push_back(e(k, (uint64_t)d * L0 + l + 1)); }
+        });
+      // logarithmic part: chunk heads collect the chunks to their right, power-of-two spans (:590-615)
+      for (uint64_t L1 = L0, D1 = D >> 1; D1 > 0; L1 <<= 1, D1 >>= 1)
+        round([&](int k, std::vector<uint32_t>& A, std::vector<uint32_t>& B) {
+          for (uint64_t d = 0; d < D1; d++) { A.push_back(e(k, d * 2 * L1 + 1)); B.push_back(e(k, (d * 2 + 1) * L1 + 1)); }
+        });
+      // doublings: every head is weighted with the number of buckets it stands for (:616-641)
+      if (D > 1)
+        for (int j = 0; j < c0; j++)
+          round([&](int k, std::vector<uint32_t>& A, std::vector<uint32_t>& B) {
+            for (uint32_t d = 1; d < D; d++) { A.push_back(e(k, (uint64_t)d * L0 + 1)); B.push_back(e(k, (uint64_t)d * L0 + 1)); }
+          });
+      for (uint64_t L1 = 2ull * L0, D1 = D >> 1; D1 > 1; L1 <<= 1, D1 >>= 1)
+        round([&](int k, std::vector<uint32_t>& A, std::vector<uint32_t>& B) {
+          for (uint64_t d = 1; d < D1; d++) { A.push_back(e(k, d * L1 + 1)); B.push_back(e(k, d * L1 + 1)); }
+        });
+      // the buckets now fill the triangle: one addition tree over all of them (:643-662)
+      for (uint64_t m = 1; m < L; m *= 2)
+        round([&](int k, std::vector<uint32_t>& A, std::vector<uint32_t>& B) {
+          for (uint64_t l = 1; l < L; l += 2 * m) { A.push_back(e(k, l)); B.push_back(e(k, l + m)); }
+        });
+      size_t total = 0, biggest = 0;
+      for (auto& v : ga) { total += v.size(); biggest = std::max(biggest, v.size()); }
+      ctx->ensure(desc, std::max<size_t>(total, 1) * 8);
+      std::vector<uint32_t> flat(2 * total);
+      {
+        size_t o = 0;
+        for (size_t r = 0; r < ga.size(); r++) {
+          for (size_t i = 0; i < ga[r].size(); i++) { flat[o + i] = (ga[r][i] << 1) | 1u; flat[total + o + i] = gb[r][i]; }
+          o += ga[r].size();
+        }
+      }
+      HIPCHK(hipMemcpyAsync(desc.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, s));
+      {
+        const RoundGeom g = round_geom(ctx, std::max<uint64_t>(biggest, 1));
+        ctx->ensure(scr, (size_t)g.steps * NL * g.T * 4);
+      }
+      HIPCHK(hipEventRecord(w.ev[3], s));
+      size_t o = 0;
+      for (size_t r = 0; r < ga.size(); r++) {
+        const uint64_t np = ga[r].size();
+        const RoundGeom g = round_geom(ctx, np);
+        BatchArgs a{};
+        a.in = (const uint4*)planes.p;
+        a.in_cap = cap;
+        a.out = (uint4*)planes.p;
+        a.out_cap = cap;
+        a.scratch = (uint32_t*)scr.p;
+        a.sstride = g.T;
+        a.n_out = np;
+        a.steps = g.steps;
+        a.desc = (const uint32_t*)desc.p + o;
+        a.desc_b = (const uint32_t*)desc.p + total + o;
+        a.inplace = 1;
+        W_LAUNCH_MODE(ctx, k_batch_add, MODE_SEARCH, dim3(g.grid), dim3(256), 0, s, a);
+        o += np;
+      }
+      HIPCHK(hipEventRecord(w.ev[4], s));
+      // element e(k, 1) -> partial (X, Y, Z = 1 in device Montgomery form; all-zero = the identity)
+      std::vector<uint32_t> el((size_t)K * 24);
+      for (int k = 0; k < K; k++)
+        for (int cpl = 0; cpl < 6; cpl++)
+          HIPCHK(hipMemcpyAsync(&el[(size_t)k * 24 + 4 * cpl], (const uint4*)planes.p + (uint64_t)cpl * cap + (uint64_t)k * L, 16,
+                                hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventElapsedTime(&ms, w.ev[3], w.ev[4]));
+      for (int k = 0; k < K; k++) {
+        const uint32_t* q = &el[(size_t)k * 24];
+        if (q[11] == INF_WORD) continue;   // identity: the partial stays all-zero
+        memcpy(&parts[(size_t)k * 36], q, 24 * 4);
+        const msm_host::Fe6 one_dev = ctx->hc.F.pow2(390);   // Z = 1 in the form x and y are in: device Montgomery, 1 * 2^390
+        for (int q2 = 0; q2 < 6; q2++) {
+          parts[(size_t)k * 36 + 24 + 2 * q2] = (uint32_t)one_dev.v[q2];
+          parts[(size_t)k * 36 + 24 + 2 * q2 + 1] = (uint32_t)(one_dev.v[q2] >> 32);
+        }
+      }
+    }
+    for (int k = 0; k < K; k++) {
+      const uint32_t* q = &parts[(size_t)k * 36];
+      bool zero_z = true;
+      for (int j = 0; j < 12; j++) zero_z &= q[24 + j] == 0;
+      const msm_host::Proj6 P = zero_z ? ctx->hc.zero() : partial_to_host(ctx, q);
+      msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}}, t;
+      ctx->hc.F.mul(t, P.X, one); fe6_to_bytes(partials_out + (size_t)k * 144, t);
+      ctx->hc.F.mul(t, P.Y, one); fe6_to_bytes(partials_out + (size_t)k * 144 + 48, t);
+      ctx->hc.F.mul(t, P.Z, one); fe6_to_bytes(partials_out + (size_t)k * 144 + 96, t);
+    }
+    if (ms_out) *ms_out = ms;
+    for (DevBuf* b : {&wire, &rows, &planes, &desc, &scr}) ctx->release(*b);
     return MSM_OK;
   } MSM_CATCH_ALL(ctx)
 }

@@ -376,15 +376,34 @@ int oracle_msm_bls377(const uint8_t* points, const uint8_t* scalars, uint64_t n,
 
   proj* part = (proj*)malloc(sizeof(proj) * K);
   int oom = 0;
-  /* Windows one after the other, every phase of a window on ALL threads -- the reference's SPMD layout: entries split
-   * across threads for slicing / counting / sorting (:175-203, :456-502), buckets split across threads for the
-   * accumulation rounds and the reduction (`computeBucketsSplit`, :626-667, src/msm-common.ts:72-172). */
-  uint32_t* dig = (uint32_t*)malloc(4 * n2);
-  uint64_t* start = (uint64_t*)malloc((L + 2) * 8);
-  uint64_t* cursor = (uint64_t*)malloc((L + 2) * 8);
-  aff* sorted = (aff*)malloc(sizeof(aff) * (n2 ? n2 : 1));
-  if (!dig || !start || !cursor || !sorted) oom = 1;
-  for (int k = 0; k < K && !oom; k++) {
+  /* Every phase of a window runs on a TEAM of threads -- the reference's SPMD layout: entries split across the team for
+   * slicing / counting / sorting (:175-203, :456-502), buckets split across it for the accumulation rounds and the
+   * reduction (`computeBucketsSplit`, :626-667, src/msm-common.ts:72-172).  With many cores the windows themselves run side
+   * by side, one team each (they are independent until the final sum, :312-333): 128 threads meeting in four barriers per
+   * window scaled badly (round 2: 7.6e3 points/s per thread at 2^24 against 5.8e4 on 17 threads). */
+  int wpar = 1, team = nthreads, team_seen = 0;
+#ifdef _OPENMP
+  if (nthreads >= 16) {
+    wpar = nthreads / 8 < K ? nthreads / 8 : K;
+    team = nthreads / wpar;
+    omp_set_max_active_levels(2);
+  }
+#endif
+#pragma omp parallel for schedule(dynamic, 1) num_threads(wpar)
+  for (int k = 0; k < K; k++) {
+    const int nthreads = team;   /* inside the window: the team */
+    uint32_t* dig = (uint32_t*)malloc(4 * n2);
+    uint64_t* start = (uint64_t*)malloc((L + 2) * 8);
+    uint64_t* cursor = (uint64_t*)malloc((L + 2) * 8);
+    aff* sorted = (aff*)malloc(sizeof(aff) * (n2 ? n2 : 1));
+    proj* tsum = (proj*)malloc(sizeof(proj) * nthreads);
+    if (!dig || !start || !cursor || !sorted || !tsum) {
+#pragma omp atomic write
+      oom = 1;
+      free(dig); free(start); free(cursor); free(sorted); free(tsum);
+      continue;
+    }
+    for (int i = 0; i < nthreads; i++) proj_zero(&tsum[i]);   /* the runtime may grant an inner team fewer threads than asked for */
     /* slice + count (:175-203) and scatter (:456-502).  NOTE: digits need the carry of all lower windows.
      * Each thread counts its own contiguous share of the entries in a PRIVATE histogram and later scatters the same
      * share from private cursors (a shared histogram bounces its cache lines between 256 threads on two sockets);
@@ -447,13 +466,15 @@ int oracle_msm_bls377(const uint8_t* points, const uint8_t* scalars, uint64_t n,
     const uint64_t total = start[L + 1];
     /* accumulation rounds (:243-282) and bucket reduction (:556-583): buckets [lo, hi] per thread, equal shares of the
      * sorted entries; every thread builds its own pair lists and shares one inversion per round among them */
-    proj* tsum = (proj*)malloc(sizeof(proj) * nthreads);
-    if (!tsum) { oom = 1; break; }
 #pragma omp parallel num_threads(nthreads)
     {
       int tid = 0, nt = 1;
 #ifdef _OPENMP
       tid = omp_get_thread_num(); nt = omp_get_num_threads();
+      if (tid == 0) {
+#pragma omp atomic write
+        team_seen = nt;
+      }
 #endif
       /* bucket range of this thread: boundaries where the cumulative entry count crosses tid / nt of the total */
       uint64_t lo = 1, hi = 0;
@@ -517,9 +538,10 @@ int oracle_msm_bls377(const uint8_t* points, const uint8_t* scalars, uint64_t n,
     for (int i = 0; i < nthreads; i++) proj_add(&acc, &acc, &tsum[i]);
     part[k] = acc;
     free(tsum);
+    free(dig); free(start); free(cursor); free(sorted);
   }
-  free(dig); free(start); free(cursor); free(sorted);
   free(pts); free(mags);
+  if (threads_used && team_seen) *threads_used = wpar * team_seen;   /* what the runtime really granted */
   if (oom) { free(part); return -2; }
   /* final sum (:322-333) */
   proj acc = part[K - 1];

@@ -217,3 +217,44 @@ def test_batch_add_gather_mode_every_kind_of_pair(gpu_ctx):
             memo[key] = O.aff_add(g[i], h[i], p)
         exp = memo[key]
         assert out[96 * i : 96 * i + 96] == (b"\0" * 96 if exp is None else exp[0].to_bytes(48, "little") + exp[1].to_bytes(48, "little")), i
+
+
+def test_bucket_reduction_projective_and_all_affine(gpu_ctx):
+    """P_k = sum_l l B_(k,l) by the projective reduction the MSM uses (mode 0) and by the reference's
+    all-affine reduction (reduceBucketsAffine, src/msm-batched-affine-single-thread.ts:522-667: in-place batched-affine
+    additions and doublings, every chunk size 2^c0) against the oracle's direct sum.  Buckets include empty ones, a repeated
+    point (P + P inside the in-place rounds) and P next to -P (a sum that cancels)."""
+    from oracle import msm_oracle as O
+
+    C = O.BLS12_377
+    K, L = 3, 64
+    pts, _ = O.random_points_bls377("op/reduce", K * L)
+    for i in (5, 17, 40, 64 + 9, 128 + 63):
+        pts[i] = None                                       # empty buckets
+    pts[10] = pts[11] = pts[12]                             # equal neighbours
+    pts[64 + 20] = O.aff_neg(pts[64 + 21], C.p)             # P and -P side by side
+    pts[128 + 0] = None
+    pts[128 + 1] = None
+    buckets = b"".join(bytes(96) if P is None else P[0].to_bytes(48, "little") + P[1].to_bytes(48, "little") for P in pts)
+    exp = []
+    for k in range(K):
+        acc = None
+        for l in range(1, L + 1):
+            B = pts[k * L + l - 1]
+            if B is not None:
+                acc = O.aff_add(acc, O.aff_scale(l, B, C.p), C.p)
+        exp.append(acc)
+
+    def affine(parts):
+        out = []
+        for k in range(K):
+            X, Y, Z = (int.from_bytes(parts[144 * k + 48 * j: 144 * k + 48 * j + 48], "little") for j in range(3))
+            out.append(None if Z == 0 else (X * pow(Z, -1, C.p) % C.p, Y * pow(Z, -1, C.p) % C.p))
+        return out
+
+    got0, ms0 = gpu_ctx.test_bucket_reduce(buckets, K, L, mode=0)
+    assert affine(got0) == exp
+    for c0 in (0, 1, 2, 3, 6):                              # c0 = 6: one chunk (the plain running sum), c0 = 0: tree only
+        got1, ms1 = gpu_ctx.test_bucket_reduce(buckets, K, L, mode=1, c0=c0)
+        assert affine(got1) == exp, c0
+    assert ms0 > 0 and ms1 > 0
