@@ -336,17 +336,25 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, uint32_
       proj_load(Q, bucket_proj + b * (3 * NL));
       proj_add<F>(row, row, Q);
     } else {
-      uint32_t o0 = off_fin[b], o1 = off_fin[b + 1];
-      bool qinf = true;
-      if (o1 > o0) {
-        uint32_t w[NW];
-        load_planes3(w, fin, fin_cap, 0, o0);
-        qinf = w[NW - 1] == INF_WORD;
-        fe_unpack<F>(Q.X, w);
-        load_planes3(w, fin, fin_cap, 3, o0);
-        fe_unpack<F>(Q.Y, w);
+      // every element the tree left in this bucket goes straight into the running row sum (mixed additions): no separate
+      // pass that first sums each bucket on its own, and one full addition per bucket less
+      const uint32_t o0 = off_fin[b], o1 = off_fin[b + 1];
+      uint32_t nx[NW], ny[NW];
+      if (o0 < o1) {
+        load_planes3(nx, fin, fin_cap, 0, o0);
+        load_planes3(ny, fin, fin_cap, 3, o0);
       }
-      proj_add_mixed<F>(row, row, Q, qinf);
+#pragma unroll 1
+      for (uint32_t o = o0; o < o1; o++) {
+        const bool qinf = nx[NW - 1] == INF_WORD;
+        fe_unpack<F>(Q.X, nx);
+        fe_unpack<F>(Q.Y, ny);
+        if (o + 1 < o1) {   // the next element's words are in flight during the addition
+          load_planes3(nx, fin, fin_cap, 0, o + 1);
+          load_planes3(ny, fin, fin_cap, 3, o + 1);
+        }
+        proj_add_mixed<F>(row, row, Q, qinf);
+      }
     }
     proj_add<F>(tri, tri, row);
   }
