@@ -294,9 +294,12 @@ MSM_DEV void fe_carry_out(uint32_t (&r)[N], uint64_t (&t)[N]) {
 
 // Interleaved (CIOS-style) Montgomery multiplication on 30-bit limbs with 64-bit column accumulators.  Row i adds
 // a_i * b and m_i * p, then shifts one limb.  Operands: normalised limbs (< 2^30), a * b < 2^12 p^2; result < p + a b / R.
+// A field that rides a wider limb layout than it needs (Pallas: 255 bits in the 13-limb layout of the 381-bit curves) has
+// C::NLA < C::NL active limbs: every value the kernels form is below 2^(30 NLA), so the partial products of the limbs above
+// are zeros and are not computed (81 instead of 169 multiply-adds; the NL reduction rows stay, R is 2^(30 NL)).
 template <class C>
 MSM_DEV void fe_mul(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) {
-  constexpr int N = C::NL;
+  constexpr int N = C::NL, NA = C::NLA;
   constexpr int GUARD = fe_guard_row<C, false>();
   static_assert(GUARD != -2, "no single guard sweep keeps the accumulators below 2^64");
   uint64_t t[N];
@@ -304,8 +307,10 @@ MSM_DEV void fe_mul(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) {
   for (int j = 0; j < N; j++) t[j] = 0;
 #pragma unroll
   for (int i = 0; i < N; i++) {
+    if (i < NA) {
 #pragma unroll
-    for (int j = 0; j < N; j++) t[j] += (uint64_t)a.l[i] * b.l[j];
+      for (int j = 0; j < NA; j++) t[j] += (uint64_t)a.l[i] * b.l[j];
+    }
     fe_reduce_row<C>(t);
     if (i == GUARD) fe_guard_sweep<N>(t);
   }
@@ -317,7 +322,7 @@ MSM_DEV void fe_mul(Fe<C>& r, const Fe<C>& a, const Fe<C>& b) {
 // when reduction row i retires it: every term a_k a_(i-k) comes from a row k <= i / 2.
 template <class C>
 MSM_DEV void fe_sqr(Fe<C>& r, const Fe<C>& a) {
-  constexpr int N = C::NL;
+  constexpr int N = C::NL, NA = C::NLA;
   constexpr int GUARD = fe_guard_row<C, true>();
   static_assert(GUARD != -2, "no single guard sweep keeps the accumulators below 2^64");
   uint32_t a2[N];
@@ -328,9 +333,11 @@ MSM_DEV void fe_sqr(Fe<C>& r, const Fe<C>& a) {
   for (int j = 0; j < N; j++) t[j] = 0;
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    t[i] += (uint64_t)a.l[i] * a.l[i];
+    if (i < NA) {
+      t[i] += (uint64_t)a.l[i] * a.l[i];
 #pragma unroll
-    for (int j = i + 1; j < N; j++) t[j] += (uint64_t)a.l[i] * a2[j];
+      for (int j = i + 1; j < NA; j++) t[j] += (uint64_t)a.l[i] * a2[j];
+    }
     fe_reduce_row<C>(t);
     if (i == GUARD) fe_guard_sweep<N>(t);
   }

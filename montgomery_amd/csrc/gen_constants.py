@@ -45,13 +45,16 @@ def arr(name, vals, ty="uint32_t"):
     return f"  static constexpr {ty} {name}[{len(vals)}] = {{{body}}};\n"
 
 
-def field_block(struct, p, nl, nw, extra=None):
+def field_block(struct, p, nl, nw, extra=None, nla=None):
     R = 1 << (LB * nl)
     assert R > 4 * p
     mu = (-pow(p, -1, 1 << LB)) % (1 << LB)
     s = f"struct {struct} {{\n"
     s += f"  static constexpr int NL = {nl};   // 30-bit limbs in registers\n"
     s += f"  static constexpr int NW = {nw};   // packed 32-bit words in memory\n"
+    nla = nla or nl
+    assert (1 << (LB * nla)) > 64 * p   # every value the kernels form (sums of a few elements, < 64 p) fits its active limbs
+    s += f"  static constexpr int NLA = {nla};  // limbs a value of this field can occupy: operands of fe_mul / fe_sqr are zero above\n"
     s += f"  static constexpr int BITS = {p.bit_length()};\n"
     s += f"  static constexpr uint32_t MU = 0x{mu:x}u;  // -p^-1 mod 2^30\n"
     s += f"  static constexpr uint32_t PINV30 = 0x{pow(p, -1, 1 << LB):x}u;  // p^-1 mod 2^30\n"
@@ -120,7 +123,7 @@ def main():
     out += field_block("Fp381", FP381, 13, 12, {"BETAW": BETA381, "BW": 4, "GXW": G381X, "GYW": G381Y})
     # Pallas runs through the same 13-limb / 12-word code path with zero upper limbs (R = 2^390 is a valid
     # Montgomery radix for any odd p < R): a curve "by constants only", at the 381-bit path's cost
-    out += field_block("FpPallas", FP_PALLAS, 13, 12, {"BETAW": BETA_PALLAS, "BW": 5, "GXW": GX_PALLAS, "GYW": GY_PALLAS})
+    out += field_block("FpPallas", FP_PALLAS, 13, 12, {"BETAW": BETA_PALLAS, "BW": 5, "GXW": GX_PALLAS, "GYW": GY_PALLAS}, nla=9)
     out += glv_block()
     out += glv_block("GlvPallas", LAMBDA_PALLAS, FQ_PALLAS, 127)
     out += glv_block("GlvBls381", LAMBDA381, FR381, 127)

@@ -122,6 +122,7 @@ def test_mul_sqr_on_unreduced_and_all_ones_operands(lib, field):
         assert r % p == a * b * rinv % p and r < p + a * b // R + 1
         r = raw(1, a, a)
         assert r % p == a * a * rinv % p and r < p + a * a // R + 1
-    ones = R - 1
+    # Pallas rides the 13-limb layout with 9 active limbs (C::NLA): the multiplier's contract is operands below 2^270 there
+    ones = (1 << (30 * 9)) - 1 if field == 3 else R - 1
     assert raw(0, ones, ones) % p == ones * ones * rinv % p
     assert raw(1, ones, ones) % p == ones * ones * rinv % p
