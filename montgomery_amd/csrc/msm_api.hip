@@ -251,12 +251,14 @@ int fail_hip(msm_ctx* ctx, const HipFail& f) {
 // GPU-tuned window size (the reference's table, src/msm-common.ts:25-41, was tuned for 16 CPU threads and copies
 // points).  Weierstrass + GLV (b + 1 = 127 or 128 bits): measured over N = 2^4 .. 2^26 (tools/small_sizes.py), c = 16
 // (K = 8, no degenerate top window, one window's counters fit the LDS) wins from N = 2^12 up -- by 20 % over c = 13
-// at 2^14 .. 2^18, where a smaller window mostly buys more rounds of fixed latency -- and c = 8 below.
+// at 2^14 .. 2^18, where a smaller window mostly buys more rounds of fixed latency -- and c = 8 below.  From 2^28 points
+// c = 22 (K = 6: a quarter fewer pair additions) wins with the three-pass sort and the chunk-ordered round 1 (601 against
+// 643 ms); at 2^26 and 2^27 the two tie (154.7 / 153.4 and 311 / 313 ms, profiles/r03_experiments.txt) and c = 16 stays.
 // Twisted Edwards (b + 1 = 252, no inversion per round): a cost model over the window sizes whose top window is not
 // degenerate, ~9 multiplications per pair addition against ~64 per bucket; its picks are within 3 % of the best
 // measured ones.
 int pick_window(bool te, uint64_t n, int glv_max_bits) {
-  if (!te) return n >= 4096 ? 16 : 8;
+  if (!te) return n >= (1ull << 28) ? 22 : n >= 4096 ? 16 : 8;
   static const int cand_te[] = {4, 6, 7, 9, 12, 14, 16};
   const int b1 = 252;
   (void)glv_max_bits;

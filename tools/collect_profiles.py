@@ -1,7 +1,7 @@
 """Copies the judged summaries of one profiling run (gpurun_out/prof_<tag>/) into profiles/ (tracked)."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 for name, dst in (("trace26", f"{tag}_kernel_stats_2p26.csv"), ("trace20", f"{tag}_kernel_stats_2p20.csv"), ("trace_ed20", f"{tag}_kernel_stats_ed377_2p20.csv")):

@@ -2,25 +2,25 @@
 # Profiling recipe for one round (run on the GPU box through gpurun):  tools/profile_round.sh r02
 # Writes rocprofv3 summaries under gpurun_out/prof_<tag>/; tools/collect_profiles.py copies the ones to keep into profiles/.
 set -x
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd "$(dirname "$0")/.."
 REPO=$PWD
 export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 10 --warmup 5 > $OUT/bench_2p26.json 2> $OUT/bench_2p26.err
-python bench.py --steps 10 --warmup 5 --log2n 20 --no-cpu-baseline > $OUT/bench_2p20.json 2> $OUT/bench_2p20.err
+python bench.py --steps 10 --warmup 5 --log2n 20 --no-cpu-baseline --no-other-configs > $OUT/bench_2p20.json 2> $OUT/bench_2p20.err
 python bench.py --curve ed377 --steps 10 --warmup 5 --log2n 20 > $OUT/bench_ed377_2p20.json 2> $OUT/bench_ed.err
 python bench.py --curve bls12-381 --steps 10 --warmup 5 > $OUT/bench_bls381_2p26.json 2> $OUT/bench_381.err
 python bench.py --curve bls12-381 --steps 10 --warmup 5 --log2n 20 > $OUT/bench_bls381_2p20.json 2>> $OUT/bench_381.err
 python tools/cpu_series.py $OUT/cpu_baseline.json > $OUT/cpu_series.log 2>&1
-for u in ubench_int2 ubench_inv ubench_mul2 ubench_mad3 ubench_carry; do [ -x tools/$u ] && ./tools/$u > $OUT/$u.txt 2>&1; done
+for u in ubench_int2; do [ -x tools/$u ] && ./tools/$u > $OUT/$u.txt 2>&1; done
 [ -x tools/ubench_gather ] && { ./tools/ubench_gather 16 512; for b in 256 1024 2048; do echo "workgroups $b"; ./tools/ubench_gather 16 $b | grep -E "range    16384 MB  wave window (       0|     256) MB"; done; } > $OUT/ubench_gather.txt 2>/dev/null
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace26 -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $OUT/trace26.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace20 -- python3 $REPO/bench.py --steps 5 --warmup 1 --log2n 20 --no-cpu-baseline --no-verify > $OUT/trace20.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace26 -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-other-configs > $OUT/trace26.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace20 -- python3 $REPO/bench.py --steps 5 --warmup 1 --log2n 20 --no-cpu-baseline --no-verify --no-other-configs > $OUT/trace20.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ed20 -- python3 $REPO/bench.py --curve ed377 --steps 5 --warmup 1 --log2n 20 > $OUT/trace_ed20.log 2>&1
-PM="python3 $REPO/bench.py --steps 1 --warmup 0 --log2n 24 --no-cpu-baseline --no-verify"
+PM="python3 $REPO/bench.py --steps 1 --warmup 0 --log2n 24 --no-cpu-baseline --no-verify --no-other-configs"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PM > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PM > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pmc_sq -- $PM > $OUT/pmc_sq.log 2>&1
