@@ -41,9 +41,10 @@ enum {
   MSM_CURVE_BLS12_377_G1 = 0,     /* Weierstrass + GLV, batched-affine path: src/msm-batched-affine.ts */
   MSM_CURVE_ED_ON_BLS12_377 = 1,  /* twisted Edwards, generic path: src/msm-basic.ts */
   MSM_CURVE_BLS12_381_G1 = 2,     /* Weierstrass + GLV, batched-affine path; src/concrete/bls12-381.params.ts */
-  MSM_CURVE_PALLAS = 3            /* same path, src/concrete/pasta.params.ts.  Runs in the 381-bit-wide code path:
-                                   * every coordinate at this ABI is a 48-byte little-endian integer (upper 16
-                                   * bytes zero); the facades translate the reference's 32-byte Pallas wire form */
+  MSM_CURVE_PALLAS = 3            /* same path on 9 limbs / 8 packed words, src/concrete/pasta.params.ts (the reference sizes
+                                   * limbs per field, src/parallel.ts:53-57): coordinates at this ABI -- wire points, test
+                                   * operands, the used part of msm_result.x / .y -- are 32-byte little-endian integers, as for
+                                   * the Edwards curve; window sums stay 144-byte (X, Y, Z) records for every curve */
 };
 
 typedef struct msm_ctx msm_ctx;
@@ -163,7 +164,9 @@ int msm_generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void* dev_dst,
 /* Read resident points [first, first + count) back in wire format (tests, CPU-baseline sampling). */
 int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy);
 
-/* ---- fine-grained GPU operators for parity tests (debug surface) ---- */
+/* ---- fine-grained GPU operators for parity tests (debug surface) ----
+ * Coordinates are the curve's ABI width: 48-byte little-endian integers for BLS12-377 / BLS12-381, 32-byte ones for Pallas and
+ * Ed-on-BLS12-377 ("48-byte" / "96-byte" below stand for one / two coordinates of that width). */
 enum { MSM_OP_MUL = 0, MSM_OP_SQR = 1, MSM_OP_ADD = 2, MSM_OP_SUB = 3, MSM_OP_INV = 4,
        MSM_OP_TO_MONT = 5, MSM_OP_FROM_MONT = 6,
        MSM_OP_INV_FERMAT = 7,   /* a^(p-2): the cross-check of MSM_OP_INV (division steps) */

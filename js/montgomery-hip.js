@@ -43,7 +43,7 @@ function bigintToLeBytes(x, n) {
 }
 
 function createCurve(params, curveId, coordBytes, device, wireBytes) {
-  wireBytes = wireBytes || coordBytes;   // the reference's packed coordinate size; Pallas: 32 on the wire, 48 at the C ABI
+  wireBytes = wireBytes || coordBytes;   // the reference's packed coordinate size = the C ABI's: 48, or 32 for the 255-bit fields
   const ctx = hip.createContext(curveId, device || 0);   // device: an index, or a list of indices (one context over several GPUs)
   const pointBytes = 2 * coordBytes;
   const Parallel = {
@@ -97,7 +97,7 @@ const weierstrassIds = { "bls12-377": hip.CURVE_BLS12_377_G1, "bls12-381": hip.C
 const Weierstrass = {
   create(params, device) {
     if (!(params.label in weierstrassIds)) throw new Error(`curve ${params.label} has no device constants`);
-    return createCurve(params, weierstrassIds[params.label], 48, device, params.label === "pallas" ? 32 : 48);
+    return createCurve(params, weierstrassIds[params.label], params.label === "pallas" ? 32 : 48, device);
   },
 };
 const TwistedEdwards = { create(params, device) { return createCurve(params, hip.CURVE_ED_ON_BLS12_377, 32, device); } };

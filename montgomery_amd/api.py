@@ -169,7 +169,7 @@ class MsmContext:
         self.n_points = 0
         self._cur_set = 0
         self._set_sizes: Dict[int, int] = {0: 0}
-        self.coord_bytes = 32 if curve == _lib.CURVE_ED_ON_BLS12_377 else 48
+        self.coord_bytes = 32 if curve in (_lib.CURVE_ED_ON_BLS12_377, _lib.CURVE_PALLAS) else 48   # per field, as the reference sizes them
         self._gen_buf, self._gen_cap = 0, 0   # device buffer of generate_scalars(into=0)
 
     def close(self) -> None:
@@ -386,7 +386,7 @@ class MsmContext:
 
     def test_fp_raw(self, op: int, a_limbs: Sequence[Sequence[int]], b_limbs: Sequence[Sequence[int]]) -> List[List[int]]:
         """fe_mul / fe_sqr on raw 30-bit-limb operands (lists of NL ints per element); returns the raw result limbs."""
-        nl = 9 if self.curve == _lib.CURVE_ED_ON_BLS12_377 else 13
+        nl = 9 if self.curve in (_lib.CURVE_ED_ON_BLS12_377, _lib.CURVE_PALLAS) else 13   # limbs are sized per field
         n = len(a_limbs)
         A = (C.c_uint32 * (nl * n))(*[w for e in a_limbs for w in e])
         B = (C.c_uint32 * (nl * n))(*[w for e in b_limbs for w in e])
@@ -395,16 +395,17 @@ class MsmContext:
         return [[int(out[i * nl + j]) for j in range(nl)] for i in range(n)]
 
     def test_curve_op(self, op: int, p: BytesLike, q: BytesLike) -> bytes:
-        """Projective (X || Y || Z, 48 B each) or extended Edwards (X || Y || Z || T, 32 B each) operator; see msm_hip.h."""
+        """Projective (X || Y || Z, one coordinate width each) or extended Edwards (X || Y || Z || T, 32 B each) operator; see
+        msm_hip.h."""
         bp = (C.c_uint8 * len(p)).from_buffer_copy(bytes(p))
         bq = (C.c_uint8 * len(q)).from_buffer_copy(bytes(q))
         out = (C.c_uint8 * len(p))()
-        nb = 128 if self.curve == _lib.CURVE_ED_ON_BLS12_377 else 144
+        nb = 128 if self.curve == _lib.CURVE_ED_ON_BLS12_377 else 3 * self.coord_bytes
         self._check(self._lib.msm_test_curve_op(self._h, op, bp, bq, out, len(p) // nb))
         return bytes(out)
 
     def test_batch_add_mode(self, g: BytesLike, h: BytesLike, mode: int, steps: int) -> bytes:
-        n = len(g) // 96
+        n = len(g) // (2 * self.coord_bytes)
         bg = (C.c_uint8 * len(g)).from_buffer_copy(bytes(g))
         bh = (C.c_uint8 * len(h)).from_buffer_copy(bytes(h))
         out = (C.c_uint8 * len(g))()
@@ -415,8 +416,8 @@ class MsmContext:
         """P_k = sum_l l B_(k,l) for K windows of L buckets (x || y, 48-byte LE each, (0, 0) = empty): K x 144 bytes (X, Y, Z)
         and the device time in ms.  mode 0: the projective reduction of the MSM; mode 1: the reference's all-affine
         reduction (reduceBucketsAffine) out of in-place batched additions, chunks of 2^c0 buckets."""
-        if len(buckets) != 96 * K * L:
-            raise MsmError(_lib.MSM_ERR_ARG, f"expected {96 * K * L} bytes of buckets, got {len(buckets)}")
+        if len(buckets) != 2 * self.coord_bytes * K * L:
+            raise MsmError(_lib.MSM_ERR_ARG, f"expected {2 * self.coord_bytes * K * L} bytes of buckets, got {len(buckets)}")
         buf = (C.c_uint8 * len(buckets)).from_buffer_copy(bytes(buckets))
         out = (C.c_uint8 * (144 * K))()
         ms = C.c_float(0)
@@ -494,8 +495,7 @@ class _Parallel:
     def __init__(self, ctx: MsmContext, params):
         self._ctx = ctx
         self._params = params
-        # wire bytes per coordinate = the reference's packed field size (src/wasm/field-helpers.ts:211-301);
-        # Pallas (32) differs from the 48-byte coordinates its context takes at the C ABI
+        # wire bytes per coordinate = the reference's packed field size (src/wasm/field-helpers.ts:211-301) = the C ABI's
         self._wire_bytes = (params.modulus.bit_length() + 7) // 8 if hasattr(params, "modulus") else ctx.coord_bytes
 
     def getPointer(self, size: int) -> PointPtr:

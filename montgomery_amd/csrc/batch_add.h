@@ -38,7 +38,7 @@ struct BatchArgs {
   uint64_t in_cap;
   uint4* out;               // output planes
   uint64_t out_cap;
-  uint32_t* scratch;        // prefix products: per step 3 uint4 planes + 1 dword plane of T lanes each (52 B per pair)
+  uint32_t* scratch;        // prefix products: per step NL / 4 uint4 planes + 1 dword plane of T lanes each (52 B per pair at 13 limbs)
   uint64_t n_out;           // number of output elements
   uint32_t steps;
   const uint32_t* desc;     // MODE_SEARCH: operand descriptors from k_tail_desc
@@ -83,11 +83,11 @@ constexpr int BA_THREADS = 256;
 // y -> p - y where `flip` (gather mode: the sign bit of the payload), else unchanged:  (y ^ m) + ((p + 1) & m).
 // A zero y becomes p (congruent); such a value is reduced before it is stored or compared.
 template <class F>
-__device__ __forceinline__ void pk_cond_neg(Pk& y, bool flip) {
+__device__ __forceinline__ void pk_cond_neg(PkW<F::NW>& y, bool flip) {
   const uint32_t m = flip ? 0xFFFFFFFFu : 0u;
-  Pk t;
+  PkW<F::NW> t;
 #pragma unroll
-  for (int j = 0; j < NW; j++) {
+  for (int j = 0; j < F::NW; j++) {
     y.w[j] ^= m;
     t.w[j] = (j == 0 ? F::PW[0] + 1u : F::PW[j]) & m;   // p is odd: p + 1 changes word 0 only
   }
@@ -97,32 +97,36 @@ __device__ __forceinline__ void pk_cond_neg(Pk& y, bool flip) {
 // the (rare) excess of a Montgomery product over p: r < p (1 + 2^-11) -> [0, p).  One compare on the top word decides
 // for the whole wave; the subtraction itself runs for a wave in ~30 (2^-11 x 64 lanes).
 template <class F>
-__device__ __forceinline__ void pk_reduce_product(Pk& r) {
-  if (__any(r.w[11] >= F::PW[11])) pk_cond_sub_p<F>(r);
+__device__ __forceinline__ void pk_reduce_product(PkW<F::NW>& r) {
+  if (__any(r.w[F::NW - 1] >= F::PW[F::NW - 1])) pk_cond_sub_p<F>(r);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // memory access: planes ("piece" c of element e at uint4 index c * cap + e) and point rows
 // ---------------------------------------------------------------------------------------------------------------
 
-// 48-byte coordinate = 3 pieces, `stride` bytes apart, starting at byte `off` (32-bit, per lane) from the uniform `base`
-__device__ __forceinline__ void ba_load3(Pk& w, const char* base, uint32_t off, uint64_t stride) {
+// one coordinate = W / 4 pieces of 16 bytes (3 for the 12-word fields, 2 for the 8-word ones), `stride` bytes apart, starting
+// at byte `off` (32-bit, per lane) from the uniform `base`
+template <int W>
+__device__ __forceinline__ void ba_load3(PkW<W>& w, const char* base, uint32_t off, uint64_t stride) {
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
+  for (int j = 0; j < W / 4; j++) {
     const uint4 v = *reinterpret_cast<const uint4*>(base + (uint64_t)j * stride + off);
     w.w[4 * j] = v.x; w.w[4 * j + 1] = v.y; w.w[4 * j + 2] = v.z; w.w[4 * j + 3] = v.w;
   }
 }
-__device__ __forceinline__ void ba_load3_wide(Pk& w, const char* p) {   // per-lane 64-bit address, consecutive pieces
+template <int W>
+__device__ __forceinline__ void ba_load3_wide(PkW<W>& w, const char* p) {   // per-lane 64-bit address, consecutive pieces
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
+  for (int j = 0; j < W / 4; j++) {
     const uint4 v = reinterpret_cast<const uint4*>(p)[j];
     w.w[4 * j] = v.x; w.w[4 * j + 1] = v.y; w.w[4 * j + 2] = v.z; w.w[4 * j + 3] = v.w;
   }
 }
-__device__ __forceinline__ void ba_store3(char* base, uint32_t off, uint64_t stride, const Pk& w) {
+template <int W>
+__device__ __forceinline__ void ba_store3(char* base, uint32_t off, uint64_t stride, const PkW<W>& w) {
 #pragma unroll
-  for (int j = 0; j < 3; j++)
+  for (int j = 0; j < W / 4; j++)
     *reinterpret_cast<uint4*>(base + (uint64_t)j * stride + off) = make_uint4(w.w[4 * j], w.w[4 * j + 1], w.w[4 * j + 2], w.w[4 * j + 3]);
 }
 
@@ -191,8 +195,9 @@ __device__ __forceinline__ void ba_locate<MODE_GATHER>(PairLoc<MODE_GATHER>& L, 
   L.flags = (aa ? 1u : 0u) | (bb ? 2u : 0u) | ((pp.x & 1u) ? 4u : 0u) | ((pp.y & 1u) ? 8u : 0u);
 }
 
-template <int MODE>
-__device__ __forceinline__ void ba_load_x(Pk& x1, Pk& x2, const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t) {
+template <class F, int MODE>
+__device__ __forceinline__ void ba_load_x(PkW<F::NW>& x1, PkW<F::NW>& x2, const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t) {
+  constexpr int NP = F::NW / 4;   // 16-byte pieces per coordinate
   if constexpr (MODE == MODE_GATHER) {
     ba_load3_wide(x1, L.pa);
     ba_load3_wide(x2, L.pb);
@@ -204,7 +209,7 @@ __device__ __forceinline__ void ba_load_x(Pk& x1, Pk& x2, const PairLoc<MODE>& L
     const char* q = reinterpret_cast<const char*>(a.in) + L.b;
     const uint64_t s = a.in_cap * 16;
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
+    for (int j = 0; j < NP; j++) {
       const uint4 v = *reinterpret_cast<const uint4*>(p + j * s), u = *reinterpret_cast<const uint4*>(q + j * s);
       x1.w[4 * j] = v.x; x1.w[4 * j + 1] = v.y; x1.w[4 * j + 2] = v.z; x1.w[4 * j + 3] = v.w;
       x2.w[4 * j] = u.x; x2.w[4 * j + 1] = u.y; x2.w[4 * j + 2] = u.z; x2.w[4 * j + 3] = u.w;
@@ -215,22 +220,23 @@ __device__ __forceinline__ void ba_load_x(Pk& x1, Pk& x2, const PairLoc<MODE>& L
 // y coordinates; gather mode applies the sign bit of the payload: y -> p - y (a zero y becomes p: congruent, and
 // only ever stored after ba_canonical_y)
 template <class F, int MODE>
-__device__ __forceinline__ void ba_load_y(Pk& y1, Pk& y2, const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t) {
+__device__ __forceinline__ void ba_load_y(PkW<F::NW>& y1, PkW<F::NW>& y2, const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t) {
+  constexpr int NP = F::NW / 4;
   if constexpr (MODE == MODE_GATHER) {
-    ba_load3_wide(y1, L.pa + 48);
-    ba_load3_wide(y2, L.pb + 48);
+    ba_load3_wide(y1, L.pa + 4 * F::NW);
+    ba_load3_wide(y2, L.pb + 4 * F::NW);
     pk_cond_neg<F>(y1, L.flags & 4u);
     pk_cond_neg<F>(y2, L.flags & 8u);
   } else if constexpr (MODE == MODE_REGULAR) {
-    const char* b = L.base + 3 * a.in_cap * 16;
+    const char* b = L.base + NP * a.in_cap * 16;
     ba_load3(y1, b, 32u * t, a.in_cap * 16);
     ba_load3(y2, b + 16, 32u * t, a.in_cap * 16);
   } else {
     const uint64_t s = a.in_cap * 16;
-    const char* p = reinterpret_cast<const char*>(a.in) + L.a + 3 * s;
-    const char* q = reinterpret_cast<const char*>(a.in) + L.b + 3 * s;
+    const char* p = reinterpret_cast<const char*>(a.in) + L.a + NP * s;
+    const char* q = reinterpret_cast<const char*>(a.in) + L.b + NP * s;
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
+    for (int j = 0; j < NP; j++) {
       const uint4 v = *reinterpret_cast<const uint4*>(p + j * s), u = *reinterpret_cast<const uint4*>(q + j * s);
       y1.w[4 * j] = v.x; y1.w[4 * j + 1] = v.y; y1.w[4 * j + 2] = v.z; y1.w[4 * j + 3] = v.w;
       y2.w[4 * j] = u.x; y2.w[4 * j + 1] = u.y; y2.w[4 * j + 2] = u.z; y2.w[4 * j + 3] = u.w;
@@ -241,45 +247,49 @@ __device__ __forceinline__ void ba_load_y(Pk& y1, Pk& y2, const PairLoc<MODE>& L
 // The second operand of a pair once more (x and y, sign applied): only for the patch of "first operand is the identity",
 // which trailing padding never produces -- it needs a cancellation P - P earlier in the tree.
 template <class F, int MODE>
-__device__ __forceinline__ void ba_load_b(Pk& x2, Pk& y2, const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t) {
+__device__ __forceinline__ void ba_load_b(PkW<F::NW>& x2, PkW<F::NW>& y2, const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t) {
+  constexpr int NP = F::NW / 4;
   if constexpr (MODE == MODE_GATHER) {
     ba_load3_wide(x2, L.pb);
-    ba_load3_wide(y2, L.pb + 48);
+    ba_load3_wide(y2, L.pb + 4 * F::NW);
     pk_cond_neg<F>(y2, L.flags & 8u);
     pk_cond_sub_p<F>(y2);
   } else if constexpr (MODE == MODE_REGULAR) {
     ba_load3(x2, L.base + 16, 32u * t, a.in_cap * 16);
-    ba_load3(y2, L.base + 3 * a.in_cap * 16 + 16, 32u * t, a.in_cap * 16);
+    ba_load3(y2, L.base + NP * a.in_cap * 16 + 16, 32u * t, a.in_cap * 16);
   } else {
     const uint64_t s = a.in_cap * 16;
     const char* p = reinterpret_cast<const char*>(a.in) + L.b;
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const uint4 v = *reinterpret_cast<const uint4*>(p + j * s), u = *reinterpret_cast<const uint4*>(p + (j + 3) * s);
+    for (int j = 0; j < NP; j++) {
+      const uint4 v = *reinterpret_cast<const uint4*>(p + j * s), u = *reinterpret_cast<const uint4*>(p + (j + NP) * s);
       x2.w[4 * j] = v.x; x2.w[4 * j + 1] = v.y; x2.w[4 * j + 2] = v.z; x2.w[4 * j + 3] = v.w;
       y2.w[4 * j] = u.x; y2.w[4 * j + 1] = u.y; y2.w[4 * j + 2] = u.z; y2.w[4 * j + 3] = u.w;
     }
   }
 }
 
-// prefix product of one (step, lane): 13 limbs as 3 uint4 + 1 dword, each in its own plane of T lanes
-__device__ __forceinline__ void ba_store_pre(const BatchArgs& a, uint32_t i, uint64_t, uint32_t t, const uint32_t (&l)[NL]) {
+// prefix product of one (step, lane): N limbs (13 or 9) as N / 4 uint4 + 1 dword, each in its own plane of T lanes
+template <int N>
+__device__ __forceinline__ void ba_store_pre(const BatchArgs& a, uint32_t i, uint64_t, uint32_t t, const uint32_t (&l)[N]) {
+  static_assert(N % 4 == 1, "limb count = whole 16-byte pieces + one dword");
   const uint64_t T = a.sstride;
-  char* sb = reinterpret_cast<char*>(a.scratch) + (uint64_t)i * T * 52;
+  char* sb = reinterpret_cast<char*>(a.scratch) + (uint64_t)i * T * (4 * N);
 #pragma unroll
-  for (int j = 0; j < 3; j++)
+  for (int j = 0; j < N / 4; j++)
     *reinterpret_cast<uint4*>(sb + (uint64_t)j * T * 16 + 16u * t) = make_uint4(l[4 * j], l[4 * j + 1], l[4 * j + 2], l[4 * j + 3]);
-  *reinterpret_cast<uint32_t*>(sb + 48ull * T + 4u * t) = l[12];
+  *reinterpret_cast<uint32_t*>(sb + (uint64_t)(N / 4) * 16 * T + 4u * t) = l[N - 1];
 }
-__device__ __forceinline__ void ba_load_pre(uint32_t (&l)[NL], const BatchArgs& a, uint32_t i, uint64_t, uint32_t t) {
+template <int N>
+__device__ __forceinline__ void ba_load_pre(uint32_t (&l)[N], const BatchArgs& a, uint32_t i, uint64_t, uint32_t t) {
   const uint64_t T = a.sstride;
-  const char* sb = reinterpret_cast<const char*>(a.scratch) + (uint64_t)i * T * 52;
+  const char* sb = reinterpret_cast<const char*>(a.scratch) + (uint64_t)i * T * (4 * N);
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
+  for (int j = 0; j < N / 4; j++) {
     const uint4 v = *reinterpret_cast<const uint4*>(sb + (uint64_t)j * T * 16 + 16u * t);
     l[4 * j] = v.x; l[4 * j + 1] = v.y; l[4 * j + 2] = v.z; l[4 * j + 3] = v.w;
   }
-  l[12] = *reinterpret_cast<const uint32_t*>(sb + 48ull * T + 4u * t);
+  l[N - 1] = *reinterpret_cast<const uint32_t*>(sb + (uint64_t)(N / 4) * 16 * T + 4u * t);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -294,8 +304,11 @@ enum : uint32_t { BA_ZERO = 1, BA_COPY_A = 2, BA_COPY_B = 4, BA_DOUBLE = 8, BA_S
 // Forward and backward sweep call this with the same inputs, so both see the same den.  HAVE_Y: the caller already
 // holds the pair's y coordinates (backward sweep); otherwise they are loaded in the rare equal-x case only.
 template <class F, int MODE, bool HAVE_Y>
-__device__ __forceinline__ uint32_t ba_denominator(Fe<F>& den, const Pk& x1, const Pk& x2, const Pk* y1p, const Pk* y2p,
-                                                    const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t, bool active) {
+__device__ __forceinline__ uint32_t ba_denominator(Fe<F>& den, const PkW<F::NW>& x1, const PkW<F::NW>& x2, const PkW<F::NW>* y1p,
+                                                    const PkW<F::NW>* y2p, const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t,
+                                                    bool active) {
+  using Pk = PkW<F::NW>;
+  constexpr int NW = F::NW;
   bool same_x_out;
   Pk dx;
   {
@@ -340,6 +353,8 @@ __device__ __forceinline__ uint32_t ba_denominator(Fe<F>& den, const Pk& x1, con
 template <class CV, int MODE>
 __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArgs a) {
   using F = typename CV::F;
+  using Pk = PkW<F::NW>;
+  constexpr int NW = F::NW, NP = F::NW / 4;   // packed words and 16-byte pieces per coordinate
   const uint64_t T = (uint64_t)gridDim.x * BA_THREADS;
   const uint32_t t = blockIdx.x * BA_THREADS + threadIdx.x;
   const uint32_t steps = a.steps;
@@ -360,14 +375,14 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
     PairLoc<MODE> L;
     Pk x1, x2;
     ba_locate<MODE>(L, a, 0, T, t, is_active(0));
-    ba_load_x<MODE>(x1, x2, L, a, t);
+    ba_load_x<F, MODE>(x1, x2, L, a, t);
 #pragma unroll 1
     for (uint32_t i = 0; i < steps; i++) {
       Fe<F> den;
       ba_denominator<F, MODE, false>(den, x1, x2, nullptr, nullptr, L, a, t, is_active(i));
       if (i + 1 < steps) {   // the next pair's x: its registers are free now, the multiplication covers the latency
         ba_locate<MODE>(L, a, BA_STEP(i + 1), T, t, is_active(i + 1));
-        ba_load_x<MODE>(x1, x2, L, a, t);
+        ba_load_x<F, MODE>(x1, x2, L, a, t);
       }
       ba_store_pre(a, BA_STEP(i), T, t, acc.l);
       BA_FENCE();
@@ -389,15 +404,15 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
   // launch bound.
   {
 #if MSM_BA_WAVES >= 3
-    __shared__ uint4 park[9 * BA_THREADS];
+    __shared__ uint4 park[3 * NP * BA_THREADS];
     auto park_put = [&](int slot, const Pk& v) {
 #pragma unroll
-      for (int j = 0; j < 3; j++) park[(slot * 3 + j) * BA_THREADS + threadIdx.x] = make_uint4(v.w[4 * j], v.w[4 * j + 1], v.w[4 * j + 2], v.w[4 * j + 3]);
+      for (int j = 0; j < NP; j++) park[(slot * NP + j) * BA_THREADS + threadIdx.x] = make_uint4(v.w[4 * j], v.w[4 * j + 1], v.w[4 * j + 2], v.w[4 * j + 3]);
     };
     auto park_get = [&](Pk& v, int slot) {
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const uint4 q = park[(slot * 3 + j) * BA_THREADS + threadIdx.x];
+      for (int j = 0; j < NP; j++) {
+        const uint4 q = park[(slot * NP + j) * BA_THREADS + threadIdx.x];
         v.w[4 * j] = q.x; v.w[4 * j + 1] = q.y; v.w[4 * j + 2] = q.z; v.w[4 * j + 3] = q.w;
       }
     };
@@ -409,7 +424,7 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
     Pk x1, x2, y1, y2, nx1, nx2;
     Fe<F> pre, npre;
     ba_locate<MODE>(L, a, BA_STEP(steps - 1), T, t, is_active(steps - 1));
-    ba_load_x<MODE>(x1, x2, L, a, t);
+    ba_load_x<F, MODE>(x1, x2, L, a, t);
     ba_load_pre(pre.l, a, BA_STEP(steps - 1), T, t);
     ba_load_y<F, MODE>(y1, y2, L, a, t);
     Ln = L;
@@ -448,7 +463,7 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
       // 37 registers that are free from now on (the widest point of the step, inv * den with d and num waiting, is behind)
       if (i > 0) {
         ba_locate<MODE>(Ln, a, BA_STEP((uint32_t)i - 1), T, t, is_active((uint32_t)i - 1));
-        ba_load_x<MODE>(nx1, nx2, Ln, a, t);
+        ba_load_x<F, MODE>(nx1, nx2, Ln, a, t);
         ba_load_pre(npre.l, a, BA_STEP((uint32_t)i - 1), T, t);
       }
       BA_FENCE();
@@ -514,23 +529,23 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
           const uint64_t o = a.oidx ? (e_cur & ~(uint64_t)(CO_PAIRS - 1)) + o_local : e_cur;
           uint4* row = reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.out_rows) + o * 128);
 #pragma unroll
-          for (int j = 0; j < 3; j++) {
+          for (int j = 0; j < NP; j++) {
             row[j] = make_uint4(x3.w[4 * j], x3.w[4 * j + 1], x3.w[4 * j + 2], x3.w[4 * j + 3]);
-            row[3 + j] = make_uint4(y3.w[4 * j], y3.w[4 * j + 1], y3.w[4 * j + 2], y3.w[4 * j + 3]);
+            row[NP + j] = make_uint4(y3.w[4 * j], y3.w[4 * j + 1], y3.w[4 * j + 2], y3.w[4 * j + 3]);
           }
-          row[6] = make_uint4(0, 0, 0, 0);
-          row[7] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+          for (int j = 2 * NP; j < 8; j++) row[j] = make_uint4(0, 0, 0, 0);
         } else if (MODE == MODE_SEARCH && a.inplace) {   // uniform: the sum replaces the first operand
           if constexpr (MODE == MODE_SEARCH) {
             char* ob = reinterpret_cast<char*>(a.out) + L.a;
             ba_store3(ob, 0u, a.out_cap * 16, x3);
-            ba_store3(ob + 3 * a.out_cap * 16, 0u, a.out_cap * 16, y3);
+            ba_store3(ob + NP * a.out_cap * 16, 0u, a.out_cap * 16, y3);
           }
         } else
         {
         char* ob = reinterpret_cast<char*>(a.out + (uint64_t)BA_STEP(i) * T);
         ba_store3(ob, 16u * t, a.out_cap * 16, x3);
-        ba_store3(ob + 3 * a.out_cap * 16, 16u * t, a.out_cap * 16, y3);
+        ba_store3(ob + NP * a.out_cap * 16, 16u * t, a.out_cap * 16, y3);
         }
       }
       x1 = nx1; x2 = nx2; pre = npre; L = Ln;

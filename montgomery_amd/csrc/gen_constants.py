@@ -123,7 +123,7 @@ def main():
     out += field_block("Fp381", FP381, 13, 12, {"BETAW": BETA381, "BW": 4, "GXW": G381X, "GYW": G381Y})
     # Pallas runs through the same 13-limb / 12-word code path with zero upper limbs (R = 2^390 is a valid
     # Montgomery radix for any odd p < R): a curve "by constants only", at the 381-bit path's cost
-    out += field_block("FpPallas", FP_PALLAS, 13, 12, {"BETAW": BETA_PALLAS, "BW": 5, "GXW": GX_PALLAS, "GYW": GY_PALLAS}, nla=9)
+    out += field_block("FpPallas", FP_PALLAS, 9, 8, {"BETAW": BETA_PALLAS, "BW": 5, "GXW": GX_PALLAS, "GYW": GY_PALLAS})
     out += glv_block()
     out += glv_block("GlvPallas", LAMBDA_PALLAS, FQ_PALLAS, 127)
     out += glv_block("GlvBls381", LAMBDA381, FR381, 127)

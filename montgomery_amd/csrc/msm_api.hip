@@ -70,9 +70,9 @@ inline uint32_t ceil_log2_u64(uint64_t n) {
 
 // host-side view of the per-curve constants (constants_gen.h)
 struct CurveInfo {
-  const uint32_t* pw;   // base field modulus, 12 words
+  const uint32_t* pw;   // base field modulus, 12 words (zero-extended for the 8-word fields)
   const uint32_t* q;    // scalar field order, 8 words
-  const uint32_t* gx;   // generator (Weierstrass curves), 12 words each
+  const uint32_t* gx;   // generator (Weierstrass curves), 12 words each, device Montgomery form
   const uint32_t* gy;
   int glv_max_bits;     // Scalar.maxBits after decomposition, src/wasm/glv.ts:216-226
   int q_bits;           // bit length of q
@@ -81,7 +81,14 @@ struct CurveInfo {
 inline const CurveInfo& curve_info(int curve) {
   static const CurveInfo bls377 = {msm::Fp377::PW, msm::GlvBls377::Q, msm::Fp377::GXW, msm::Fp377::GYW, msm::GlvBls377::MAX_BITS, 253};
   static const CurveInfo bls381 = {msm::Fp381::PW, msm::GlvBls381::Q, msm::Fp381::GXW, msm::Fp381::GYW, msm::GlvBls381::MAX_BITS, 255};
-  static const CurveInfo pallas = {msm::FpPallas::PW, msm::GlvPallas::Q, msm::FpPallas::GXW, msm::FpPallas::GYW, msm::GlvPallas::MAX_BITS, 255};
+  // Pallas lives on 8 packed words; the host side reads 12 (zero-extended copies)
+  static uint32_t pal_p[12], pal_gx[12], pal_gy[12];
+  static const bool pal_init = [] {
+    for (int i = 0; i < 8; i++) { pal_p[i] = msm::FpPallas::PW[i]; pal_gx[i] = msm::FpPallas::GXW[i]; pal_gy[i] = msm::FpPallas::GYW[i]; }
+    return true;
+  }();
+  (void)pal_init;
+  static const CurveInfo pallas = {pal_p, msm::GlvPallas::Q, pal_gx, pal_gy, msm::GlvPallas::MAX_BITS, 255};
   static const CurveInfo ed377 = {msm::Fp253::PW, msm::FRED_Q, nullptr, nullptr, 251, 251};
   return curve == MSM_CURVE_BLS12_381_G1 ? bls381 : curve == MSM_CURVE_PALLAS ? pallas : curve == MSM_CURVE_ED_ON_BLS12_377 ? ed377 : bls377;
 }
@@ -187,10 +194,15 @@ struct msm_ctx {
   Workspace ws[N_WS];
 
   msm_host::Curve6 hc;
-  msm_host::Fe6 k_dev_to_host;  // 2^378: device Montgomery (2^390) -> host Montgomery (2^384)
+  msm_host::Fe6 k_dev_to_host;  // 2^(768 - 30 NL): device Montgomery (radix 2^(30 NL)) -> host Montgomery (2^384)
   msm_host::TeCurve6 hte;       // Ed-on-BLS12-377 over the 253-bit field (same 6-limb host field code)
   msm_host::Fe6 k_te_to_host;   // 2^498: device Montgomery (2^270) -> host Montgomery (2^384)
   bool is_te() const { return curve == MSM_CURVE_ED_ON_BLS12_377; }
+  // per-field sizes (the reference sizes limbs per field, src/parallel.ts:53-57): 30-bit limbs in registers, packed words
+  // per coordinate in memory, and the coordinate bytes at the ABI (wire points, results, test operands)
+  int nl() const { return (curve == MSM_CURVE_PALLAS || is_te()) ? 9 : 13; }
+  int nw() const { return (curve == MSM_CURVE_PALLAS || is_te()) ? 8 : 12; }
+  size_t coord_bytes() const { return (size_t)nw() * 4; }
 
   void ensure(DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return;
@@ -220,6 +232,13 @@ struct msm_ctx {
     if ((ctx)->curve == MSM_CURVE_BLS12_381_G1) hipLaunchKernelGGL((KERNEL<msm::CvBls381, MODE>), __VA_ARGS__); \
     else if ((ctx)->curve == MSM_CURVE_PALLAS) hipLaunchKernelGGL((KERNEL<msm::CvPallas, MODE>), __VA_ARGS__);  \
     else hipLaunchKernelGGL((KERNEL<msm::CvBls377, MODE>), __VA_ARGS__);                    \
+  } while (0)
+
+// point rows -> tree planes (test ops), by the packed words of the curve's coordinates
+#define ROWS_TO_PLANES(ctx, ...)                                                                       \
+  do {                                                                                                 \
+    if ((ctx)->nw() == 8) hipLaunchKernelGGL((k_test_rows_to_planes<8>), __VA_ARGS__);                 \
+    else hipLaunchKernelGGL((k_test_rows_to_planes<12>), __VA_ARGS__);                                 \
   } while (0)
 
 #include "msm_gen.h"
@@ -344,9 +363,15 @@ RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather = false, bo
   return RoundGeom{(uint32_t)steps, (uint32_t)grid, grid * 256};
 }
 
-void words_to_fe6(msm_host::Fe6& r, const uint32_t* w) {
-  for (int i = 0; i < 6; i++) r.v[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+void words_to_fe6(msm_host::Fe6& r, const uint32_t* w, int nw = 12) {   // nw packed words, zero-extended
+  for (int i = 0; i < 6; i++)
+    r.v[i] = (2 * i < nw ? (uint64_t)w[2 * i] : 0) | ((2 * i + 1 < nw ? (uint64_t)w[2 * i + 1] : 0) << 32);
 }
+
+void fe6_to_bytes(uint8_t* out, const msm_host::Fe6& a);
+// element e of a plane buffer read back to the host (uint4 piece c of element e at word (c * cap + e) * 4) -> x || y in wire
+// form (coordinate bytes of the curve; the identity as zeros)
+void plane_element_to_wire(const msm_ctx* ctx, const uint32_t* planes, uint64_t cap, uint64_t e, uint8_t* out_xy);
 
 void fe6_to_bytes(uint8_t* out, const msm_host::Fe6& a) {
   for (int i = 0; i < 6; i++)
@@ -838,6 +863,26 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   HIPCHK(hipEventElapsedTime(&ms, w.ev[3], w.ev[4])); st.ms_red += ms;
 }
 
+void plane_element_to_wire(const msm_ctx* ctx, const uint32_t* planes, uint64_t cap, uint64_t e, uint8_t* out_xy) {
+  const int nw = ctx->nw(), np = nw / 4;
+  const size_t cb = ctx->coord_bytes();
+  uint32_t w[24];
+  for (int cpl = 0; cpl < 2 * np; cpl++)
+    for (int q = 0; q < 4; q++) w[4 * cpl + q] = planes[((uint64_t)cpl * cap + e) * 4 + q];
+  memset(out_xy, 0, 2 * cb);
+  if (w[nw - 1] == INF_WORD) return;
+  msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
+  for (int j = 0; j < 2; j++) {
+    msm_host::Fe6 t;
+    words_to_fe6(t, w + nw * j, nw);
+    ctx->hc.F.mul(t, t, ctx->k_dev_to_host);
+    ctx->hc.F.mul(t, t, one);
+    uint8_t b48[48];
+    fe6_to_bytes(b48, t);
+    memcpy(out_xy + cb * j, b48, cb);
+  }
+}
+
 // how many windows fit one group under the workspace budget
 int windows_per_group(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
   // bytes per window and point (Weierstrass: 2 entries per point): digits 8, record arrays of the radix passes 16 (+ 8 for the
@@ -1235,7 +1280,7 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     return MSM_ERR_INTERNAL;
   }
   ctx->hc.F.init(curve == MSM_CURVE_ED_ON_BLS12_377 ? Fp377::PW : curve_info(curve).pw);   // (the Edwards context uses hte)
-  ctx->k_dev_to_host = ctx->hc.F.pow2(378);
+  ctx->k_dev_to_host = ctx->hc.F.pow2(768 - 30 * ctx->nl());   // device radix 2^(30 NL): 2^378 for 13 limbs, 2^498 for 9
   {
     uint32_t pw[12] = {0};
     for (int i = 0; i < 8; i++) pw[i] = Fp253::PW[i];
@@ -1278,7 +1323,7 @@ static int set_points_one(msm_ctx* ctx, const void* points, uint64_t n, int on_d
   if (!ctx || (!points && n)) return fail(ctx, MSM_ERR_ARG, "msm_set_points: null argument");
   if (n >= (1ull << 30)) return fail(ctx, MSM_ERR_ARG, "msm_set_points: n must be < 2^30");
   const bool te = ctx->is_te();
-  const size_t wire_bytes = te ? 64 : 96;
+  const size_t wire_bytes = 2 * ctx->coord_bytes();   // x || y, little-endian
   const size_t row_words = te ? te::TE_ROW_WORDS : ROW_WORDS;
   try {
     HIPCHK(hipSetDevice(ctx->device));
@@ -1318,7 +1363,7 @@ int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, 
     std::vector<uint8_t> host;
     const void* src = points;
     if (on_device && n) {   // the buffer lives on devices[0]: the other devices take it through the host
-      host.resize((size_t)n * (ctx->is_te() ? 64 : 96));
+      host.resize((size_t)n * 2 * ctx->coord_bytes());
       HIPCHK(hipSetDevice(ctx->device));
       HIPCHK(hipMemcpy(host.data(), points, host.size(), hipMemcpyDeviceToHost));
       src = host.data();
@@ -1585,17 +1630,21 @@ int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy
     std::vector<uint32_t> rows((size_t)count * ROW_WORDS);
     if (count)
       HIPCHK(hipMemcpy(rows.data(), (const uint32_t*)ctx->rows.p + first * ROW_WORDS, rows.size() * 4, hipMemcpyDeviceToHost));
-    memset(out_xy, 0, (size_t)count * 96);
+    const int nw = ctx->nw();
+    const size_t cb = ctx->coord_bytes();
+    memset(out_xy, 0, (size_t)count * 2 * cb);
     msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
     for (uint64_t i = 0; i < count; i++) {
       const uint32_t* row = &rows[(size_t)i * ROW_WORDS];
-      if (row[11] == INF_WORD) continue;
+      if (row[nw - 1] == INF_WORD) continue;
       for (int j = 0; j < 2; j++) {
         msm_host::Fe6 t;
-        words_to_fe6(t, row + ROW_Y * j);
+        words_to_fe6(t, row + nw * j, nw);
         ctx->hc.F.mul(t, t, ctx->k_dev_to_host);  // host Montgomery
         ctx->hc.F.mul(t, t, one);                 // plain
-        fe6_to_bytes(out_xy + i * 96 + 48 * j, t);
+        uint8_t b48[48];
+        fe6_to_bytes(b48, t);
+        memcpy(out_xy + i * 2 * cb + cb * j, b48, cb);
       }
     }
   } MSM_CATCH_ALL(ctx)
@@ -1604,7 +1653,7 @@ int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy
 
 int msm_test_fp(msm_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, uint64_t n) {
   if (!ctx || !a || !b || !out) return fail(ctx, MSM_ERR_ARG, "msm_test_fp: null argument");
-  const size_t nb = ctx->is_te() ? 32 : 48;
+  const size_t nb = ctx->coord_bytes();
   try {
     HIPCHK(hipSetDevice(ctx->device));
     ctx->ensure(ctx->misc, n * nb * 3 + 64);
@@ -1628,7 +1677,7 @@ int msm_test_batch_inverse(msm_ctx* ctx, const uint8_t* xs, uint8_t* out, uint64
   if (!ctx || !xs || !out || per_lane == 0) return fail(ctx, MSM_ERR_ARG, "msm_test_batch_inverse: bad argument");
   try {
     HIPCHK(hipSetDevice(ctx->device));
-    const size_t nb = ctx->is_te() ? 32 : 48;
+    const size_t nb = ctx->coord_bytes();
     ctx->ensure(ctx->misc, n * 2 * nb + 64);
     uint8_t* d = (uint8_t*)ctx->misc.p;
     HIPCHK(hipMemcpyAsync(d, xs, n * nb, hipMemcpyHostToDevice, ctx->stream));
@@ -1734,19 +1783,20 @@ int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t
     HIPCHK(hipSetDevice(ctx->device));
     // rows for 2n points: pair e = (row 2e, row 2e + 1), gathered through identity payload slots
     DevBuf rows, wire, slots, outb, scr;
-    ctx->ensure(wire, 2 * n * 96);
+    const size_t pb = 2 * ctx->coord_bytes();   // wire point; a tree node has the same size
+    ctx->ensure(wire, 2 * n * pb);
     ctx->ensure(rows, 2 * n * ROW_WORDS * 4);
     ctx->ensure(slots, 2 * n * 4);
-    ctx->ensure(outb, n * 96);
-    std::vector<uint8_t> inter(2 * n * 96);
+    ctx->ensure(outb, n * pb);
+    std::vector<uint8_t> inter(2 * n * pb);
     std::vector<uint32_t> sl(2 * n);
     for (uint64_t i = 0; i < n; i++) {
-      memcpy(&inter[(2 * i) * 96], g + i * 96, 96);
-      memcpy(&inter[(2 * i + 1) * 96], h + i * 96, 96);
+      memcpy(&inter[(2 * i) * pb], g + i * pb, pb);
+      memcpy(&inter[(2 * i + 1) * pb], h + i * pb, pb);
       sl[2 * i] = (uint32_t)((2 * i) << 2);
       sl[2 * i + 1] = (uint32_t)((2 * i + 1) << 2);
     }
-    HIPCHK(hipMemcpyAsync(wire.p, inter.data(), 2 * n * 96, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(wire.p, inter.data(), 2 * n * pb, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(slots.p, sl.data(), 2 * n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
     W_LAUNCH(ctx, k_points_from_wire, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)rows.p,
@@ -1767,25 +1817,11 @@ int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t
     a.n_out = n;
     a.steps = gm.steps;
     W_LAUNCH_MODE(ctx, k_batch_add, MODE_GATHER, dim3(gm.grid), dim3(256), 0, ctx->stream, a);
-    std::vector<uint32_t> planes(n * 24);
-    HIPCHK(hipMemcpyAsync(planes.data(), outb.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint32_t> planes(n * pb / 4);
+    HIPCHK(hipMemcpyAsync(planes.data(), outb.p, n * pb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
-    msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
-    for (uint64_t e = 0; e < n; e++) {
-      uint32_t w[24];
-      for (int cpl = 0; cpl < 6; cpl++)
-        for (int q = 0; q < 4; q++) w[4 * cpl + q] = planes[((uint64_t)cpl * n + e) * 4 + q];
-      memset(out + e * 96, 0, 96);
-      if (w[11] == INF_WORD) continue;
-      for (int j = 0; j < 2; j++) {
-        msm_host::Fe6 t;
-        words_to_fe6(t, w + 12 * j);
-        ctx->hc.F.mul(t, t, ctx->k_dev_to_host);
-        ctx->hc.F.mul(t, t, one);
-        fe6_to_bytes(out + e * 96 + 48 * j, t);
-      }
-    }
+    for (uint64_t e = 0; e < n; e++) plane_element_to_wire(ctx, planes.data(), n, e, out + e * pb);
     for (DevBuf* b : {&rows, &wire, &slots, &outb, &scr}) ctx->release(*b);
   } MSM_CATCH_ALL(ctx)
   return MSM_OK;
@@ -1802,7 +1838,7 @@ static int generate_points_one(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t*
 int msm_test_fp_raw(msm_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, uint64_t n) {
   if (!ctx || !a || !b || !out) return fail(ctx, MSM_ERR_ARG, "msm_test_fp_raw: null argument");
   if (op != MSM_OP_MUL && op != MSM_OP_SQR) return fail(ctx, MSM_ERR_ARG, "msm_test_fp_raw: op must be MSM_OP_MUL or MSM_OP_SQR");
-  const size_t nb = (ctx->is_te() ? te::TL : NL) * 4;
+  const size_t nb = (size_t)ctx->nl() * 4;
   try {
     HIPCHK(hipSetDevice(ctx->device));
     ctx->ensure(ctx->misc, n * nb * 3 + 64);
@@ -1826,7 +1862,7 @@ int msm_test_fp_raw(msm_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, 
 int msm_test_curve_op(msm_ctx* ctx, int op, const uint8_t* p, const uint8_t* q, uint8_t* out, uint64_t n) {
   if (!ctx || !p || !q || !out) return fail(ctx, MSM_ERR_ARG, "msm_test_curve_op: null argument");
   if (op < 0 || op > 2) return fail(ctx, MSM_ERR_ARG, "msm_test_curve_op: unknown operator");
-  const size_t nb = ctx->is_te() ? 128 : 144;
+  const size_t nb = ctx->is_te() ? 128 : 3 * ctx->coord_bytes();   // extended (X, Y, Z, T) or projective (X, Y, Z)
   try {
     HIPCHK(hipSetDevice(ctx->device));
     ctx->ensure(ctx->misc, n * nb * 3 + 64);
@@ -1862,16 +1898,18 @@ int msm_test_bucket_reduce(msm_ctx* ctx, const uint8_t* buckets, int32_t K, uint
     const uint64_t nb = (uint64_t)K * L;
     const uint64_t cap = nb + 2 * 257 * 512 + 256;   // plane capacity: idle lanes read (and ignore) past the end
     DevBuf wire, rows, planes, desc, scr;
-    ctx->ensure(wire, nb * 96);
+    const size_t pb = 2 * ctx->coord_bytes();
+    const int nw = ctx->nw(), np = nw / 4;
+    ctx->ensure(wire, nb * pb);
     ctx->ensure(rows, nb * ROW_WORDS * 4);
-    ctx->ensure(planes, cap * 96);
-    HIPCHK(hipMemcpyAsync(wire.p, buckets, nb * 96, hipMemcpyHostToDevice, s));
+    ctx->ensure(planes, cap * pb);
+    HIPCHK(hipMemcpyAsync(wire.p, buckets, nb * pb, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, s));
-    HIPCHK(hipMemsetAsync(planes.p, 0, cap * 96, s));
+    HIPCHK(hipMemsetAsync(planes.p, 0, cap * pb, s));
     W_LAUNCH(ctx, k_points_from_wire, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)rows.p, (const uint32_t*)wire.p,
              nb, 0, (uint32_t*)ctx->errflag.p);
-    hipLaunchKernelGGL(k_test_rows_to_planes, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint4*)planes.p, cap,
-                       (const uint32_t*)rows.p, (uint32_t)nb);
+    ROWS_TO_PLANES(ctx, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint4*)planes.p, cap, (const uint32_t*)rows.p,
+                   (uint32_t)nb);
     std::vector<uint32_t> parts((size_t)K * 36, 0);
     float ms = 0;
     if (mode == 0) {
@@ -1959,7 +1997,7 @@ int msm_test_bucket_reduce(msm_ctx* ctx, const uint8_t* buckets, int32_t K, uint
       // element e(k, 1) -> partial (X, Y, Z = 1 in device Montgomery form; all-zero = the identity)
       std::vector<uint32_t> el((size_t)K * 24);
       for (int k = 0; k < K; k++)
-        for (int cpl = 0; cpl < 6; cpl++)
+        for (int cpl = 0; cpl < 2 * np; cpl++)
           HIPCHK(hipMemcpyAsync(&el[(size_t)k * 24 + 4 * cpl], (const uint4*)planes.p + (uint64_t)cpl * cap + (uint64_t)k * L, 16,
                                 hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
@@ -1967,9 +2005,10 @@ int msm_test_bucket_reduce(msm_ctx* ctx, const uint8_t* buckets, int32_t K, uint
       HIPCHK(hipEventElapsedTime(&ms, w.ev[3], w.ev[4]));
       for (int k = 0; k < K; k++) {
         const uint32_t* q = &el[(size_t)k * 24];
-        if (q[11] == INF_WORD) continue;   // identity: the partial stays all-zero
-        memcpy(&parts[(size_t)k * 36], q, 24 * 4);
-        const msm_host::Fe6 one_dev = ctx->hc.F.pow2(390);   // Z = 1 in the form x and y are in: device Montgomery, 1 * 2^390
+        if (q[nw - 1] == INF_WORD) continue;   // identity: the partial stays all-zero
+        memcpy(&parts[(size_t)k * 36], q, nw * 4);            // X, Y at words 0 and 12 of the partial (upper words zero)
+        memcpy(&parts[(size_t)k * 36 + 12], q + nw, nw * 4);
+        const msm_host::Fe6 one_dev = ctx->hc.F.pow2(30 * ctx->nl());   // Z = 1 in the form x and y are in: device Montgomery
         for (int q2 = 0; q2 < 6; q2++) {
           parts[(size_t)k * 36 + 24 + 2 * q2] = (uint32_t)one_dev.v[q2];
           parts[(size_t)k * 36 + 24 + 2 * q2 + 1] = (uint32_t)(one_dev.v[q2] >> 32);
@@ -2001,28 +2040,29 @@ int msm_test_batch_add_mode(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, ui
     // element 2e = G_e, 2e + 1 = H_e in plane layout; search mode: an all-zero H_e is passed as "no second operand"
     const uint64_t T = ((n + steps - 1) / steps + 255) / 256 * 256;
     const uint64_t in_cap = 2 * (uint64_t)steps * T;     // idle lanes of the last step read (and ignore) up to here
+    const size_t pb = 2 * ctx->coord_bytes();            // wire point = tree node
     DevBuf rows, wire, planes, outb, scr, desc;
-    ctx->ensure(wire, 2 * n * 96);
+    ctx->ensure(wire, 2 * n * pb);
     ctx->ensure(rows, 2 * n * ROW_WORDS * 4);
-    ctx->ensure(planes, in_cap * 96);
-    ctx->ensure(outb, (uint64_t)steps * T * 96);
+    ctx->ensure(planes, in_cap * pb);
+    ctx->ensure(outb, (uint64_t)steps * T * pb);
     ctx->ensure(scr, (size_t)steps * NL * T * 4);
-    std::vector<uint8_t> inter(2 * n * 96);
+    std::vector<uint8_t> inter(2 * n * pb);
     std::vector<uint32_t> hd(n);
     for (uint64_t i = 0; i < n; i++) {
-      memcpy(&inter[(2 * i) * 96], g + i * 96, 96);
-      memcpy(&inter[(2 * i + 1) * 96], h + i * 96, 96);
+      memcpy(&inter[(2 * i) * pb], g + i * pb, pb);
+      memcpy(&inter[(2 * i + 1) * pb], h + i * pb, pb);
       bool hz = true;
-      for (int j = 0; j < 96; j++) hz = hz && h[i * 96 + j] == 0;
+      for (size_t j = 0; j < pb; j++) hz = hz && h[i * pb + j] == 0;
       hd[i] = (uint32_t)((2 * i) << 1) | (hz ? 0u : 1u);
     }
     HIPCHK(hipMemcpyAsync(wire.p, inter.data(), inter.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
-    HIPCHK(hipMemsetAsync(planes.p, 0, in_cap * 96, ctx->stream));
+    HIPCHK(hipMemsetAsync(planes.p, 0, in_cap * pb, ctx->stream));
     W_LAUNCH(ctx, k_points_from_wire, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)rows.p,
                        (const uint32_t*)wire.p, 2 * n, 0, (uint32_t*)ctx->errflag.p);
-    hipLaunchKernelGGL(k_test_rows_to_planes, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, (uint4*)planes.p,
-                       in_cap, (const uint32_t*)rows.p, (uint32_t)(2 * n));
+    ROWS_TO_PLANES(ctx, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, (uint4*)planes.p, in_cap,
+                   (const uint32_t*)rows.p, (uint32_t)(2 * n));
     BatchArgs a{};
     a.in = (const uint4*)planes.p;
     a.in_cap = in_cap;
@@ -2040,25 +2080,11 @@ int msm_test_batch_add_mode(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, ui
     } else {
       W_LAUNCH_MODE(ctx, k_batch_add, MODE_REGULAR, dim3((uint32_t)(T / 256)), dim3(256), 0, ctx->stream, a);
     }
-    std::vector<uint32_t> pl(a.out_cap * 24);
+    std::vector<uint32_t> pl(a.out_cap * pb / 4);
     HIPCHK(hipMemcpyAsync(pl.data(), outb.p, pl.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
-    msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
-    for (uint64_t e = 0; e < n; e++) {
-      uint32_t w[24];
-      for (int cpl = 0; cpl < 6; cpl++)
-        for (int q = 0; q < 4; q++) w[4 * cpl + q] = pl[((uint64_t)cpl * a.out_cap + e) * 4 + q];
-      memset(out + e * 96, 0, 96);
-      if (w[11] == INF_WORD) continue;
-      for (int j = 0; j < 2; j++) {
-        msm_host::Fe6 t;
-        words_to_fe6(t, w + 12 * j);
-        ctx->hc.F.mul(t, t, ctx->k_dev_to_host);
-        ctx->hc.F.mul(t, t, one);
-        fe6_to_bytes(out + e * 96 + 48 * j, t);
-      }
-    }
+    for (uint64_t e = 0; e < n; e++) plane_element_to_wire(ctx, pl.data(), a.out_cap, e, out + e * pb);
     for (DevBuf* b : {&rows, &wire, &planes, &outb, &scr, &desc}) ctx->release(*b);
     return MSM_OK;
   } MSM_CATCH_ALL(ctx)

@@ -108,7 +108,8 @@ inline int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_o
     C.F.mul(G.Y, t, ctx->k_dev_to_host);
     G.Z = C.F.one;
   }
-  std::vector<uint8_t> wire((size_t)N_BASIS * TBL * 96);
+  const size_t cb = ctx->coord_bytes(), pb = 2 * cb;   // wire coordinate / point bytes of this curve
+  std::vector<uint8_t> wire((size_t)N_BASIS * TBL * pb);
   std::vector<U256> tbl_scalar((size_t)N_BASIS * TBL);
   Fe6 one_plain = {{1, 0, 0, 0, 0, 0}};
   for (int j = 0; j < N_BASIS; j++) {
@@ -127,9 +128,9 @@ inline int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_o
       addmod_q(sacc, sacc, b, q);
       tbl_scalar[(size_t)j * TBL + t] = sacc;
       Fe6 zi, x, y;
-      uint8_t* w = &wire[((size_t)j * TBL + t) * 96];
+      uint8_t* w = &wire[((size_t)j * TBL + t) * pb];
       if (C.is_zero(acc)) {
-        memset(w, 0, 96);
+        memset(w, 0, pb);
         continue;
       }
       C.F.inv(zi, acc.Z);
@@ -137,10 +138,10 @@ inline int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_o
       C.F.mul(y, acc.Y, zi);
       C.F.mul(x, x, one_plain);
       C.F.mul(y, y, one_plain);
-      for (int i = 0; i < 6; i++)
+      for (size_t i = 0; i < cb / 8; i++)
         for (int k = 0; k < 8; k++) {
           w[8 * i + k] = (uint8_t)(x.v[i] >> (8 * k));
-          w[48 + 8 * i + k] = (uint8_t)(y.v[i] >> (8 * k));
+          w[cb + 8 * i + k] = (uint8_t)(y.v[i] >> (8 * k));
         }
     }
   }

@@ -51,6 +51,7 @@ template <class CV>
 __global__ void __launch_bounds__(256) k_gen_points(uint32_t* rows_out, const uint32_t* tables, uint64_t n, uint64_t seed) {
   using namespace msm;
   using F = typename CV::F;
+  constexpr int NL = F::NL;
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Proj<F> acc;
@@ -61,12 +62,12 @@ __global__ void __launch_bounds__(256) k_gen_points(uint32_t* rows_out, const ui
     const uint32_t* row = tables + ((uint64_t)j * TBL + t) * ROW_WORDS;
     Proj<F> Q;
     fe_load<F>(Q.X, row);
-    fe_load<F>(Q.Y, row + ROW_Y);
+    fe_load<F>(Q.Y, row + F::NW);
     proj_add_mixed<F>(acc, acc, Q, false);
   }
   uint32_t* out = rows_out + i * ROW_WORDS;
   if (proj_is_zero<F>(acc)) {
-    store_row_identity(out);
+    store_row_identity<F::NW / 4>(out);
     return;
   }
   Fe<F> zi, x, y, bx, beta;

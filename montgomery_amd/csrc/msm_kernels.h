@@ -30,18 +30,20 @@
 
 namespace msm {
 
-// curve configurations: every curve-dependent kernel is a template over one of these.  Both base
-// fields use 13 x 30-bit limbs in registers and 12 x 32-bit words in memory, so all buffer layouts
-// and the curve-independent sort / scan kernels are shared.
+// curve configurations: every curve-dependent kernel is a template over one of these and takes its limb and word counts from
+// the field (the reference sizes limbs per field too, src/parallel.ts:53-57, src/field-msm.ts:20-56): 13 x 30-bit limbs in
+// registers and 12 x 32-bit words (3 pieces of 16 bytes) in memory for the 377- / 381-bit primes, 9 limbs and 8 words (2 pieces)
+// for Pallas.  Point rows are 256 bytes for all of them (two 128-byte lines), the curve-independent sort / scan kernels are shared.
 struct CvBls377 { using F = Fp377; using G = GlvBls377; };   // src/concrete/bls12-377.params.ts
 struct CvBls381 { using F = Fp381; using G = GlvBls381; };   // src/concrete/bls12-381.params.ts
-struct CvPallas { using F = FpPallas; using G = GlvPallas; }; // src/concrete/pasta.params.ts (255-bit p, zero upper limbs)
-constexpr int NL = 13;
+struct CvPallas { using F = FpPallas; using G = GlvPallas; }; // src/concrete/pasta.params.ts (255-bit p)
+constexpr int NL = 13;   // the wide layout; kernels use F::NL / F::NW
 constexpr int NW = 12;
-static_assert(Fp377::NL == NL && Fp377::NW == NW && Fp381::NL == NL && Fp381::NW == NW, "shared layouts");
+static_assert(Fp377::NL == NL && Fp377::NW == NW && Fp381::NL == NL && Fp381::NW == NW, "the 12-word layout");
+constexpr int PART_WORDS = 36;   // a window sum on its way to the host: X, Y, Z at word 0, 12, 24 (8-word fields: upper words zero)
 constexpr int ROW_WORDS = 64;   // 256 B per point
 constexpr int ROW_HALF = 32;    // word offset of the endomorphism image (second 128-byte line)
-constexpr int ROW_Y = 12;       // word offset of y inside a line
+constexpr int ROW_Y = 12;       // word offset of y inside a line of the 12-word fields (in general: F::NW)
 constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t INF_WORD = 0xFFFFFFFFu;
 
@@ -53,31 +55,36 @@ namespace msm {
 // small helpers
 // ---------------------------------------------------------------------------------------------
 
-MSM_DEV void load_words12(uint32_t (&w)[NW], const uint32_t* p) {
+template <int W>
+MSM_DEV void load_words12(uint32_t (&w)[W], const uint32_t* p) {
   const uint4* p4 = reinterpret_cast<const uint4*>(p);
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
+  for (int j = 0; j < W / 4; j++) {
     uint4 v = p4[j];
     w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
   }
 }
 
-MSM_DEV void load_planes3(uint32_t (&w)[NW], const uint4* base, uint64_t cap, int first_plane, uint64_t e) {
+// one coordinate (W / 4 pieces) of element e; x starts at plane 0, y at plane W / 4
+template <int W>
+MSM_DEV void load_planes3(uint32_t (&w)[W], const uint4* base, uint64_t cap, int first_plane, uint64_t e) {
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
+  for (int j = 0; j < W / 4; j++) {
     uint4 v = base[(uint64_t)(first_plane + j) * cap + e];
     w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
   }
 }
 
-MSM_DEV void store_planes3(uint4* base, uint64_t cap, int first_plane, uint64_t e, const uint32_t (&w)[NW]) {
+template <int W>
+MSM_DEV void store_planes3(uint4* base, uint64_t cap, int first_plane, uint64_t e, const uint32_t (&w)[W]) {
 #pragma unroll
-  for (int j = 0; j < 3; j++)
+  for (int j = 0; j < W / 4; j++)
     base[(uint64_t)(first_plane + j) * cap + e] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
 
 template <class F>
-MSM_DEV bool words_ge_p(const uint32_t (&w)[NW]) {  // w >= p ?
+MSM_DEV bool words_ge_p(const uint32_t (&w)[F::NW]) {  // w >= p ?
+  constexpr int NW = F::NW;
   bool gt = false, lt = false;
 #pragma unroll
   for (int j = NW - 1; j >= 0; j--) {
@@ -91,6 +98,7 @@ MSM_DEV bool words_ge_p(const uint32_t (&w)[NW]) {  // w >= p ?
 
 template <class F>
 MSM_DEV bool fe_equal(const Fe<F>& a, const Fe<F>& b) {
+  constexpr int NL = F::NL;
   uint32_t o = 0;
 #pragma unroll
   for (int i = 0; i < NL; i++) o |= a.l[i] ^ b.l[i];
@@ -98,22 +106,23 @@ MSM_DEV bool fe_equal(const Fe<F>& a, const Fe<F>& b) {
 }
 
 template <class F>
-MSM_DEV void store_row(uint32_t* row, const Fe<F>& x, const Fe<F>& y, const Fe<F>& bx) {
+MSM_DEV void store_row(uint32_t* row, const Fe<F>& x, const Fe<F>& y, const Fe<F>& bx) {   // y follows x: word F::NW of a line
   fe_store<F>(row, x);
-  fe_store<F>(row + ROW_Y, y);
+  fe_store<F>(row + F::NW, y);
   fe_store<F>(row + ROW_HALF, bx);
-  fe_store<F>(row + ROW_HALF + ROW_Y, y);
+  fe_store<F>(row + ROW_HALF + F::NW, y);
 }
 
+template <int NP>   // NP = pieces per coordinate
 MSM_DEV void store_row_identity(uint32_t* row) {
   uint4* r4 = reinterpret_cast<uint4*>(row);
   const uint4 ones = make_uint4(INF_WORD, INF_WORD, INF_WORD, INF_WORD), zeros = make_uint4(0, 0, 0, 0);
 #pragma unroll
   for (int h = 0; h < 2; h++)
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
+    for (int j = 0; j < NP; j++) {
       r4[h * (ROW_HALF / 4) + j] = ones;
-      r4[h * (ROW_HALF / 4) + 3 + j] = zeros;
+      r4[h * (ROW_HALF / 4) + NP + j] = zeros;
     }
 }
 
@@ -125,17 +134,18 @@ template <class CV>
 __global__ void __launch_bounds__(256) k_points_from_wire(uint32_t* rows, const uint32_t* wire, uint64_t n,
                                                           int check_curve, uint32_t* err) {
   using F = typename CV::F;
+  constexpr int NL = F::NL, NW = F::NW;
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t xw[NW], yw[NW];
-  load_words12(xw, wire + i * 24);
-  load_words12(yw, wire + i * 24 + 12);
+  load_words12(xw, wire + i * (2 * NW));
+  load_words12(yw, wire + i * (2 * NW) + NW);
   uint32_t* row = rows + i * ROW_WORDS;
   uint32_t any = 0;
 #pragma unroll
   for (int j = 0; j < NW; j++) any |= xw[j] | yw[j];
   if (any == 0) {  // (0, 0) is not on y^2 = x^3 + 1: used as the wire encoding of the identity
-    store_row_identity(row);
+    store_row_identity<NW / 4>(row);
     return;
   }
   if (words_ge_p<F>(xw) || words_ge_p<F>(yw)) atomicOr(err, 1u);
@@ -243,11 +253,13 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, const uint32_t* s
 
 template <class F>
 MSM_DEV void proj_store(uint32_t* dst, const Proj<F>& P) {
+  constexpr int NL = F::NL;
 #pragma unroll
   for (int l = 0; l < NL; l++) { dst[l] = P.X.l[l]; dst[NL + l] = P.Y.l[l]; dst[2 * NL + l] = P.Z.l[l]; }
 }
 template <class F>
 MSM_DEV void proj_load(Proj<F>& P, const uint32_t* src) {
+  constexpr int NL = F::NL;
 #pragma unroll
   for (int l = 0; l < NL; l++) { P.X.l[l] = src[l]; P.Y.l[l] = src[NL + l]; P.Z.l[l] = src[2 * NL + l]; }
 }
@@ -255,6 +267,7 @@ MSM_DEV void proj_load(Proj<F>& P, const uint32_t* src) {
 // "planar" form for arrays that consecutive lanes walk together: word w of element j at base[w * stride + j]
 template <class F>
 MSM_DEV void proj_store_planar(uint32_t* base, uint64_t stride, uint64_t j, const Proj<F>& P) {
+  constexpr int NL = F::NL;
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     base[(uint64_t)l * stride + j] = P.X.l[l];
@@ -264,6 +277,7 @@ MSM_DEV void proj_store_planar(uint32_t* base, uint64_t stride, uint64_t j, cons
 }
 template <class F>
 MSM_DEV void proj_load_planar(Proj<F>& P, const uint32_t* base, uint64_t stride, uint64_t j) {
+  constexpr int NL = F::NL;
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     P.X.l[l] = base[(uint64_t)l * stride + j];
@@ -283,6 +297,7 @@ template <class CV>
 __global__ void __launch_bounds__(256) k_bucket_finish(uint32_t* bucket_proj, const uint4* in, uint64_t in_cap,
                                                        const uint32_t* off, uint32_t nb, const uint32_t* perm) {
   using F = typename CV::F;
+  constexpr int NL = F::NL, NW = F::NW, NP = F::NW / 4;
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   if (perm) b = perm[b];   // buckets ordered by remaining count (k_finish_perm): equal trip counts inside a wave
@@ -294,7 +309,7 @@ __global__ void __launch_bounds__(256) k_bucket_finish(uint32_t* bucket_proj, co
   uint32_t nx[NW], ny[NW];
   if (o0 < o1) {
     load_planes3(nx, in, in_cap, 0, o0);
-    load_planes3(ny, in, in_cap, 3, o0);
+    load_planes3(ny, in, in_cap, NP, o0);
   }
 #pragma unroll 1
   for (uint32_t o = o0; o < o1; o++) {
@@ -304,7 +319,7 @@ __global__ void __launch_bounds__(256) k_bucket_finish(uint32_t* bucket_proj, co
     fe_unpack<F>(Q.Y, ny);
     if (o + 1 < o1) {
       load_planes3(nx, in, in_cap, 0, o + 1);
-      load_planes3(ny, in, in_cap, 3, o + 1);
+      load_planes3(ny, in, in_cap, NP, o + 1);
     }
     proj_add_mixed<F>(acc, acc, Q, qinf);
   }
@@ -320,6 +335,7 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, uint32_
                                                        const uint32_t* off_fin, const uint32_t* bucket_proj, uint32_t L,
                                                        uint32_t TC, uint32_t nchunks, uint32_t k_cnt) {
   using F = typename CV::F;
+  constexpr int NL = F::NL, NW = F::NW, NP = F::NW / 4;
   uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= nchunks * k_cnt) return;
   uint32_t kk = id / nchunks, ch = id - kk * nchunks;
@@ -342,7 +358,7 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, uint32_
       uint32_t nx[NW], ny[NW];
       if (o0 < o1) {
         load_planes3(nx, fin, fin_cap, 0, o0);
-        load_planes3(ny, fin, fin_cap, 3, o0);
+        load_planes3(ny, fin, fin_cap, NP, o0);
       }
 #pragma unroll 1
       for (uint32_t o = o0; o < o1; o++) {
@@ -351,7 +367,7 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(uint32_t* columns, uint32_
         fe_unpack<F>(Q.Y, ny);
         if (o + 1 < o1) {   // the next element's words are in flight during the addition
           load_planes3(nx, fin, fin_cap, 0, o + 1);
-          load_planes3(ny, fin, fin_cap, 3, o + 1);
+          load_planes3(ny, fin, fin_cap, NP, o + 1);
         }
         proj_add_mixed<F>(row, row, Q, qinf);
       }
@@ -386,6 +402,7 @@ constexpr int WS_THREADS = 256;
 template <class CV>
 __global__ void __launch_bounds__(WS_THREADS) k_window_sum(uint32_t* partials, const uint32_t* columns, uint32_t nchunks) {
   using F = typename CV::F;
+  constexpr int NL = F::NL, NW = F::NW, NP = F::NW / 4;
   __shared__ uint32_t lds[3 * NL * WS_THREADS];
   const uint32_t kk = blockIdx.x, tid = threadIdx.x;
   Proj<F> acc;
@@ -423,8 +440,10 @@ __global__ void __launch_bounds__(WS_THREADS) k_window_sum(uint32_t* partials, c
     fe_reduce_2p<F>(acc.X);
     fe_reduce_2p<F>(acc.Y);
     fe_reduce_2p<F>(acc.Z);
-    uint32_t* dst = partials + (uint64_t)kk * 36;
+    uint32_t* dst = partials + (uint64_t)kk * PART_WORDS;
     uint32_t w[NW];
+#pragma unroll
+    for (int j = 0; j < PART_WORDS; j++) dst[j] = 0;
     fe_pack<F>(w, acc.X);
 #pragma unroll
     for (int j = 0; j < NW; j++) dst[j] = w[j];
@@ -444,6 +463,7 @@ template <class CV>
 __global__ void __launch_bounds__(WS_THREADS) k_column_tree(uint32_t* out, const uint32_t* columns, uint32_t nchunks,
                                                             uint32_t per_block) {
   using F = typename CV::F;
+  constexpr int NL = F::NL, NW = F::NW, NP = F::NW / 4;
   __shared__ uint32_t lds[3 * NL * WS_THREADS];
   const uint32_t b = blockIdx.x, kk = blockIdx.y, tid = threadIdx.x, nblk = gridDim.x;
   const uint32_t beg = b * per_block, end = min(beg + per_block, nchunks);
@@ -503,6 +523,7 @@ __global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu
                                                          uint32_t n_in, uint32_t nbits, int masked, int pack_out,
                                                          uint32_t nblk_out) {
   using F = typename CV::F;
+  constexpr int NL = F::NL, NW = F::NW, NP = F::NW / 4;
   __shared__ uint32_t lds[3 * NL * BT_THREADS];
   // First stage (masked): grid.x enumerates, per window, nbits masked sums of nblk_out / 2 blocks each and then the
   // triangle sum of nblk_out blocks -- the masked sums have half as many elements, so every wave of the launch has
@@ -570,8 +591,10 @@ __global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu
       fe_reduce_2p<F>(acc.X);
       fe_reduce_2p<F>(acc.Y);
       fe_reduce_2p<F>(acc.Z);
-      uint32_t* dst = out + o * 36;
+      uint32_t* dst = out + o * PART_WORDS;
       uint32_t w[NW];
+#pragma unroll
+      for (int j = 0; j < PART_WORDS; j++) dst[j] = 0;
       fe_pack<F>(w, acc.X);
 #pragma unroll
       for (int j = 0; j < NW; j++) dst[j] = w[j];
@@ -597,6 +620,7 @@ enum : int { OP_MUL = 0, OP_SQR = 1, OP_ADD = 2, OP_SUB = 3, OP_INV = 4, OP_TO_M
 template <class CV>
 __global__ void __launch_bounds__(256) k_test_fp(uint32_t* out, const uint32_t* a, const uint32_t* b, uint32_t n, int op) {
   using F = typename CV::F;
+  constexpr int NL = F::NL, NW = F::NW, NP = F::NW / 4;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fe<F> x, y, r;
@@ -682,6 +706,7 @@ enum : int { CURVE_OP_ADD = 0, CURVE_OP_DOUBLE = 1, CURVE_OP_ADD_MIXED = 2 };
 template <class CV>
 __global__ void __launch_bounds__(64) k_test_curve_op(uint32_t* out, const uint32_t* pp, const uint32_t* qq, uint32_t n, int op) {
   using F = typename CV::F;
+  constexpr int NL = F::NL, NW = F::NW, NP = F::NW / 4;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fe<F> r2, one;
@@ -693,7 +718,7 @@ __global__ void __launch_bounds__(64) k_test_curve_op(uint32_t* out, const uint3
   Fe<F>* co[6] = {&P.X, &P.Y, &P.Z, &Q.X, &Q.Y, &Q.Z};
   bool q_zero_xy = true;
   for (int j = 0; j < 6; j++) {
-    const uint32_t* src = (j < 3 ? pp : qq) + (uint64_t)i * 36 + (j % 3) * 12;
+    const uint32_t* src = (j < 3 ? pp : qq) + (uint64_t)i * (3 * NW) + (j % 3) * NW;
     fe_load<F>(*co[j], src);
     if (j == 3 || j == 4) q_zero_xy = q_zero_xy && fe_is_zero_canonical<F>(*co[j]);
     fe_mul<F>(*co[j], *co[j], r2);      // to Montgomery form, < 1.5 p
@@ -705,7 +730,7 @@ __global__ void __launch_bounds__(64) k_test_curve_op(uint32_t* out, const uint3
   for (int j = 0; j < 3; j++) {
     fe_mul<F>(*ro[j], *ro[j], one);     // leave Montgomery form
     fe_reduce_4p<F>(*ro[j]);
-    fe_store<F>(out + (uint64_t)i * 36 + j * 12, *ro[j]);
+    fe_store<F>(out + (uint64_t)i * (3 * NW) + j * NW, *ro[j]);
   }
 }
 

@@ -682,14 +682,15 @@ __global__ void __launch_bounds__(CO_THREADS) k_chunk_order(uint2* pairs_out, ui
 }
 
 // point rows (k_points_from_wire) -> tree planes, element e of the planes = row e: test input of the plane-reading modes
+template <int W>   // W = packed words per coordinate (12 or 8)
 __global__ void __launch_bounds__(256) k_test_rows_to_planes(uint4* planes, uint64_t cap, const uint32_t* rows, uint32_t n) {
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
-  uint32_t w[NW];
+  uint32_t w[W];
   load_words12(w, rows + (uint64_t)e * ROW_WORDS);
   store_planes3(planes, cap, 0, e, w);
-  load_words12(w, rows + (uint64_t)e * ROW_WORDS + ROW_Y);
-  store_planes3(planes, cap, 3, e, w);
+  load_words12(w, rows + (uint64_t)e * ROW_WORDS + W);
+  store_planes3(planes, cap, W / 4, e, w);
 }
 
 // ---------------------------------------------------------------------------------------------

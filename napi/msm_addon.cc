@@ -100,7 +100,7 @@ static napi_value CreateContext(napi_env env, napi_callback_info info) {
   }
   h->ctx = ctx;
   h->curve = curve;
-  h->coord_bytes = curve == MSM_CURVE_ED_ON_BLS12_377 ? 32 : 48;
+  h->coord_bytes = (curve == MSM_CURVE_ED_ON_BLS12_377 || curve == MSM_CURVE_PALLAS) ? 32 : 48;   /* per field */
   h->point_bytes = 2 * h->coord_bytes;
   napi_value out;
   NAPI_OK(napi_create_external(env, h, finalize_handle, NULL, &out));
@@ -133,7 +133,7 @@ static napi_value SetPoints(napi_env env, napi_callback_info info) {  // pointsF
   if (argc > 2) napi_get_value_int32(env, argv[2], &point_bytes);
   if (argc > 3) napi_get_value_int32(env, argv[3], &check);
   if ((size_t)point_bytes != h->point_bytes || len % h->point_bytes) {   // the C ABI reads n x point_bytes of this curve
-    napi_throw_range_error(env, NULL, "point buffer: expected a multiple of the curve's point size (96 bytes, Ed-on-BLS12-377: 64)");
+    napi_throw_range_error(env, NULL, "point buffer: expected a multiple of the curve's point size (96 bytes; Ed-on-BLS12-377 and Pallas: 64)");
     return NULL;
   }
   int rc = msm_set_points(ctx, data, len / point_bytes, 0, check);

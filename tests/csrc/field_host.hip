@@ -46,7 +46,7 @@ static void op_raw(int which, const uint32_t* a, const uint32_t* b, uint32_t* ou
   for (int i = 0; i < C::NL; i++) out[i] = r.l[i];
 }
 extern "C" {
-// field 0 = Fp377 (12 words), 1 = Fp253 (8 words), 2 = Fp381 (12 words), 3 = FpPallas (12 words, upper 4 zero); operands are canonical Montgomery-form words
+// field 0 = Fp377 (12 words), 1 = Fp253 (8 words), 2 = Fp381 (12 words), 3 = FpPallas (8 words); operands are canonical Montgomery-form words
 void host_fp_op(int field, int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
   if (field == 0) op<Fp377>(which, a, b, out);
   else if (field == 1) op<Fp253>(which, a, b, out);

@@ -16,7 +16,8 @@ from oracle import msm_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-R = 1 << 390
+R = 1 << 390   # Montgomery radix and coordinate bytes of the case under test: set by the `cv` fixture (module-scoped, so the
+CB = 48         # tests of one curve run together): 2^390 / 48 for BLS12-381, 2^270 / 32 for Pallas (limbs sized per field)
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -25,15 +26,23 @@ def H(x):
 
 
 def tb(v):
-    return v.to_bytes(48, "little")
+    return v.to_bytes(CB, "little")
 
 
 def fb(b, i):
-    return int.from_bytes(b[48 * i : 48 * i + 48], "little")
+    return int.from_bytes(b[CB * i : CB * i + CB], "little")
 
 
 def enc_pt(P):
-    return b"\0" * 96 if P is None else tb(P[0]) + tb(P[1])
+    return b"\0" * (2 * CB) if P is None else tb(P[0]) + tb(P[1])
+
+
+def golden_points(hexstr):
+    """The golden files store 48-byte coordinates; a 32-byte curve takes the low 32 bytes of each."""
+    raw = bytes.fromhex(hexstr)
+    if CB == 48:
+        return raw
+    return b"".join(raw[48 * i : 48 * i + CB] for i in range(len(raw) // 48))
 
 
 class Case:
@@ -52,7 +61,11 @@ class Case:
 
 @pytest.fixture(scope="module", params=["bls381", "pallas"])
 def cv(request):
+    global R, CB
     case = Case(request.param)
+    CB = case.ctx.coord_bytes
+    R = 1 << (390 if CB == 48 else 270)
+    assert CB == (48 if request.param == "bls381" else 32)
     yield case
     case.ctx.close()
 
@@ -89,11 +102,11 @@ def test_fp_operators_and_inverse(cv):
     back = ctx.test_fp(_lib.OP_FROM_MONT, ctx.test_fp(_lib.OP_INV, mont))
     assert all(fb(back, i) == pow(v, -1, p) for i, v in enumerate(nz))
     inv = ctx.test_fp(_lib.OP_INV, mont)
-    assert ctx.test_fp(_lib.OP_INV_FERMAT, mont[: 48 * 64]) == inv[: 48 * 64]
-    assert ctx.test_fp(_lib.OP_INV_KALISKI, mont[: 48 * 64]) == inv[: 48 * 64]
-    assert ctx.test_fp(_lib.OP_INV_WORDSLICED, mont[: 48 * 64]) == inv[: 48 * 64]
+    assert ctx.test_fp(_lib.OP_INV_FERMAT, mont[: CB * 64]) == inv[: CB * 64]
+    assert ctx.test_fp(_lib.OP_INV_KALISKI, mont[: CB * 64]) == inv[: CB * 64]
+    assert ctx.test_fp(_lib.OP_INV_WORDSLICED, mont[: CB * 64]) == inv[: CB * 64]
     for per_lane in (1, 7, 100):
-        out = ctx.test_fp(_lib.OP_FROM_MONT, ctx.test_batch_inverse(mont[: 48 * 203], per_lane))
+        out = ctx.test_fp(_lib.OP_FROM_MONT, ctx.test_batch_inverse(mont[: CB * 203], per_lane))
         assert all(fb(out, i) == pow(v, -1, p) for i, v in enumerate(nz[:203])), per_lane
     # golden field vectors
     cases = gold["fp"]
@@ -129,7 +142,7 @@ def test_batch_add(cv):
 def test_msm_golden_vectors(cv):
     ctx, gold, B, P_MOD = cv.ctx, cv.gold, cv.B, cv.B.p
     for c in gold["msm"]:
-        ctx.set_points(bytes.fromhex(c["points"]))
+        ctx.set_points(golden_points(c["points"]))
         exp = None if c["result"] is None else (H(c["result"][0]), H(c["result"][1]))
         for cc in (c["c"], None, 3, 11, 16):
             res, info = ctx.run(bytes.fromhex(c["scalars"]), c=cc)

@@ -15,7 +15,7 @@ FIELDS = {
     0: (O.BLS12_377.p, 12, 13),   # modulus, packed words, 30-bit limbs
     1: (O.ED_ON_BLS12_377.p, 8, 9),
     2: (0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 12, 13),  # BLS12-381: p != 1 mod 2^30
-    3: (O.PALLAS.p, 12, 13),  # Pallas in the 13-limb path (zero upper limbs)
+    3: (O.PALLAS.p, 8, 9),    # Pallas: 255 bits on 9 limbs / 8 words
 }
 
 
@@ -122,7 +122,6 @@ def test_mul_sqr_on_unreduced_and_all_ones_operands(lib, field):
         assert r % p == a * b * rinv % p and r < p + a * b // R + 1
         r = raw(1, a, a)
         assert r % p == a * a * rinv % p and r < p + a * a // R + 1
-    # Pallas rides the 13-limb layout with 9 active limbs (C::NLA): the multiplier's contract is operands below 2^270 there
-    ones = (1 << (30 * 9)) - 1 if field == 3 else R - 1
+    ones = R - 1
     assert raw(0, ones, ones) % p == ones * ones * rinv % p
     assert raw(1, ones, ones) % p == ones * ones * rinv % p
