@@ -44,8 +44,11 @@ struct BatchArgs {
   const uint32_t* desc;     // MODE_SEARCH: operand descriptors from k_tail_desc
   uint64_t sstride;         // lanes per scratch plane (>= T; see ba_store_pre)
   const uint16_t* oidx;     // MODE_GATHER, chunk-ordered pairs (k_chunk_order): pair e writes element (e & ~(CO_PAIRS - 1)) + oidx[e]
-  uint32_t* out_rows;       // MODE_GATHER: if set, results leave as 128-byte element rows [x | y | 0] (element k at byte 128 k) instead
-                            // of planes; a round with slots == nullptr reads such rows back (pair e = rows 2e, 2e + 1)
+  uint32_t* out_rows;       // MODE_GATHER: if set, results leave as 64-byte element records instead of planes (element k: its x record
+                            // at byte 64 k, its y record out_y_off bytes further; 8-word fields: one record [x | y]); a round with
+                            // slots == nullptr reads such records back through `points` (pair e = elements 2e, 2e + 1)
+  uint64_t y_off;           // MODE_GATHER: bytes from the x of an operand to its y (4 NW inside a row of the point table)
+  uint64_t out_y_off;       // out_rows, 12-word fields: bytes from the x record of a result to its y record
   const uint32_t* desc_b;   // MODE_SEARCH, optional: element index of the second operand of pair e (default: first operand + 1)
   uint32_t inplace;         // MODE_SEARCH: the sum replaces the FIRST operand (out == in): the in-place batched additions of the
                             // all-affine bucket reduction, src/msm-batched-affine-single-thread.ts:522-667
@@ -178,18 +181,19 @@ __device__ __forceinline__ void ba_locate<MODE_GATHER>(PairLoc<MODE_GATHER>& L, 
   uint2 pp = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
   if (active) {
     if (a.slots) pp = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.slots) + 8ull * i * T + 8u * t);
-    else {   // element rows written by the round before: element k is "entry" k of a row table, payload = k << 1
+    else {   // element records written by the round before: element k is "entry" k of a table of 64-byte records
       const uint32_t e4 = (uint32_t)(((uint64_t)i * T + t) << 2);
       pp = make_uint2(e4, e4 + 2u);
     }
   }
+  const uint32_t rs = a.slots ? 128u : 64u;   // uniform: bytes per operand (a row of the point table / one record)
   const bool aa = pp.x == 0xFFFFFFFFu, bb = pp.y == 0xFFFFFFFFu;
   // absent operands read row 0 (valid memory) and are then ignored: no divergent loads
 #ifdef BA_X_ROWMASK   // experiment: all gathers inside a 256 MB window of the table (wrong sums, timing of perfect locality)
   pp.x &= (BA_X_ROWMASK << 2) | 3u; pp.y &= (BA_X_ROWMASK << 2) | 3u;
 #endif
-  const uint64_t oa = aa ? 0 : (uint64_t)(pp.x >> 2) * 256 + ((pp.x & 2u) ? 128 : 0);
-  const uint64_t ob = bb ? 0 : (uint64_t)(pp.y >> 2) * 256 + ((pp.y & 2u) ? 128 : 0);
+  const uint64_t oa = aa ? 0 : (uint64_t)(pp.x >> 1) * rs;
+  const uint64_t ob = bb ? 0 : (uint64_t)(pp.y >> 1) * rs;
   L.pa = reinterpret_cast<const char*>(a.points) + oa;
   L.pb = reinterpret_cast<const char*>(a.points) + ob;
   L.flags = (aa ? 1u : 0u) | (bb ? 2u : 0u) | ((pp.x & 1u) ? 4u : 0u) | ((pp.y & 1u) ? 8u : 0u);
@@ -223,8 +227,8 @@ template <class F, int MODE>
 __device__ __forceinline__ void ba_load_y(PkW<F::NW>& y1, PkW<F::NW>& y2, const PairLoc<MODE>& L, const BatchArgs& a, uint32_t t) {
   constexpr int NP = F::NW / 4;
   if constexpr (MODE == MODE_GATHER) {
-    ba_load3_wide(y1, L.pa + 4 * F::NW);
-    ba_load3_wide(y2, L.pb + 4 * F::NW);
+    ba_load3_wide(y1, L.pa + a.y_off);
+    ba_load3_wide(y2, L.pb + a.y_off);
     pk_cond_neg<F>(y1, L.flags & 4u);
     pk_cond_neg<F>(y2, L.flags & 8u);
   } else if constexpr (MODE == MODE_REGULAR) {
@@ -251,7 +255,7 @@ __device__ __forceinline__ void ba_load_b(PkW<F::NW>& x2, PkW<F::NW>& y2, const 
   constexpr int NP = F::NW / 4;
   if constexpr (MODE == MODE_GATHER) {
     ba_load3_wide(x2, L.pb);
-    ba_load3_wide(y2, L.pb + 4 * F::NW);
+    ba_load3_wide(y2, L.pb + a.y_off);
     pk_cond_neg<F>(y2, L.flags & 8u);
     pk_cond_sub_p<F>(y2);
   } else if constexpr (MODE == MODE_REGULAR) {
@@ -523,18 +527,31 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
       if (i > 0) ba_load_y<F, MODE>(y1, y2, Ln, a, t);   // the next pair's y: in flight during the stores and d = inv * pre
       if (!(kind & BA_SKIP)) {
         if (MODE == MODE_GATHER && a.out_rows) {
-          // Uniform: chunk-ordered round 1.  The pair's element index comes from the table, and the element leaves as ONE whole
-          // 128-byte line: a permuted store of 16-byte plane pieces leaves every line partly written by several workgroups (on
-          // different XCDs), and the memory side then reads, merges and rewrites each of them (measured: round 1 68 -> 107 ms).
+          // Uniform: chunk-ordered round 1.  The pair's element index comes from the table, and the element leaves as whole
+          // 64-byte records: a permuted store of 16-byte plane pieces leaves every line partly written by several workgroups (on
+          // different XCDs), and the memory side then reads, merges and rewrites each of them (measured: round 1 68 -> 107 ms);
+          // aligned 64-byte pieces go through.  12-word fields: an x record [x | 16 bytes] and, a.out_y_off bytes further, a y record
+          // -- the two x of the next round's pair (2k, 2k + 1) are then one 128-byte line, and its forward sweep touches nothing
+          // else.  8-word fields: one record [x | y].
           const uint64_t o = a.oidx ? (e_cur & ~(uint64_t)(CO_PAIRS - 1)) + o_local : e_cur;
-          uint4* row = reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.out_rows) + o * 128);
+          uint4* rx = reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.out_rows) + o * 64);
+          if constexpr (NP == 3) {
+            uint4* ry = reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.out_rows) + a.out_y_off + o * 64);
 #pragma unroll
-          for (int j = 0; j < NP; j++) {
-            row[j] = make_uint4(x3.w[4 * j], x3.w[4 * j + 1], x3.w[4 * j + 2], x3.w[4 * j + 3]);
-            row[NP + j] = make_uint4(y3.w[4 * j], y3.w[4 * j + 1], y3.w[4 * j + 2], y3.w[4 * j + 3]);
+            for (int j = 0; j < 3; j++) {
+              rx[j] = make_uint4(x3.w[4 * j], x3.w[4 * j + 1], x3.w[4 * j + 2], x3.w[4 * j + 3]);
+              ry[j] = make_uint4(y3.w[4 * j], y3.w[4 * j + 1], y3.w[4 * j + 2], y3.w[4 * j + 3]);
+            }
+            rx[3] = make_uint4(0, 0, 0, 0);
+            ry[3] = make_uint4(0, 0, 0, 0);
+          } else {
+            static_assert(NP == 2 || NP == 3, "records are laid out for 8- and 12-word coordinates");
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+              rx[j] = make_uint4(x3.w[4 * j], x3.w[4 * j + 1], x3.w[4 * j + 2], x3.w[4 * j + 3]);
+              rx[2 + j] = make_uint4(y3.w[4 * j], y3.w[4 * j + 1], y3.w[4 * j + 2], y3.w[4 * j + 3]);
+            }
           }
-#pragma unroll
-          for (int j = 2 * NP; j < 8; j++) row[j] = make_uint4(0, 0, 0, 0);
         } else if (MODE == MODE_SEARCH && a.inplace) {   // uniform: the sum replaces the first operand
           if constexpr (MODE == MODE_SEARCH) {
             char* ob = reinterpret_cast<char*>(a.out) + L.a;

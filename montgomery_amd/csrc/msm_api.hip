@@ -684,6 +684,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   // the 128 slots of a wave span more than ~1 GB of rows: 64 L rows of 256 bytes, i.e. from c = 18 with more than 2^22 points.
   const uint32_t* round1_slots = (const uint32_t*)w.slots.p;
   const uint16_t* round1_oidx = nullptr;
+  uint64_t rec_y_off = 0;   // 12-word fields: where the y records of round 1's results start inside w.rows1
   bool chunked = false;   // round 1 walks chunk-ordered pairs and writes element rows, round 2 reads them
   {
     long long chunk_rows_log = 22;   // 2^22 rows of 256 bytes = 1 GB
@@ -696,7 +697,8 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       const uint64_t n_pairs = total_slots / 2;
       ctx->ensure(w.slots2, total_slots * 4);
       ctx->ensure(w.oidx, n_pairs * 2);
-      ctx->ensure(w.rows1, n_pairs * 128 + 256);
+      rec_y_off = (n_pairs * 64 + 255) & ~(uint64_t)255;
+      ctx->ensure(w.rows1, 2 * rec_y_off + 256);
       hipLaunchKernelGGL(k_chunk_order, dim3((uint32_t)((n_pairs + CO_PAIRS - 1) / CO_PAIRS)), dim3(CO_THREADS), 0, s,
                          (uint2*)w.slots2.p, (uint16_t*)w.oidx.p, (const uint2*)w.slots.p, n_pairs, (uint32_t)chunk_rows_log,
                          (uint32_t)nch + 1);
@@ -777,8 +779,11 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
       a.n_out = n_out;
       a.steps = g.steps;
       const bool rows_out = r == 1 && chunked, rows_in = r == 2 && chunked;
+      a.y_off = 4 * ctx->nw();
       if (rows_out) a.out_rows = (uint32_t*)w.rows1.p;
       if (rows_in) { a.points = (const uint32_t*)w.rows1.p; a.slots = nullptr; }
+      if (rows_out) a.out_y_off = rec_y_off;                      // 12-word fields: x records, then y records (batch_add.h)
+      if (rows_in && ctx->nw() == 12) a.y_off = rec_y_off;
       if (r == 1 || rows_in) {
         if (te) hipLaunchKernelGGL(te::k_te_add<MODE_GATHER>, dim3(g.grid), dim3(256), 0, s, a);
         else W_LAUNCH_MODE(ctx, k_batch_add, MODE_GATHER, dim3(g.grid), dim3(256), 0, s, a);
@@ -1810,6 +1815,7 @@ int msm_test_batch_add(msm_ctx* ctx, const uint8_t* g, const uint8_t* h, uint8_t
     BatchArgs a{};
     a.points = (const uint32_t*)rows.p;
     a.slots = (const uint32_t*)slots.p;
+    a.y_off = 4 * ctx->nw();
     a.out = (uint4*)outb.p;
     a.out_cap = n;
     a.scratch = (uint32_t*)scr.p;
