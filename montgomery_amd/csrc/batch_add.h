@@ -53,7 +53,10 @@ struct BatchArgs {
   uint32_t inplace;         // MODE_SEARCH: the sum replaces the FIRST operand (out == in): the in-place batched additions of the
                             // all-affine bucket reduction, src/msm-batched-affine-single-thread.ts:522-667
 };
-constexpr uint32_t CO_PAIRS = 4096;   // pairs per block of k_chunk_order (sort_kernels.h)
+#ifndef MSM_CO_PAIRS
+#define MSM_CO_PAIRS 4096
+#endif
+constexpr uint32_t CO_PAIRS = MSM_CO_PAIRS;   // pairs per block of k_chunk_order (sort_kernels.h)
 
 constexpr int BA_THREADS = 256;
 // Phase fence: hipcc's scheduler otherwise interleaves independent multiplications of one step (inv * den with num * d,

@@ -277,7 +277,8 @@ int fail_hip(msm_ctx* ctx, const HipFail& f) {
 // degenerate, ~9 multiplications per pair addition against ~64 per bucket; its picks are within 3 % of the best
 // measured ones.
 int pick_window(bool te, uint64_t n, int glv_max_bits) {
-  if (!te) return n >= (1ull << 28) ? 22 : n >= 4096 ? 16 : 8;
+  // measured (profiles/r03_experiments.txt item 5): the mean bucket of the big windows wants ~128 entries
+  if (!te) return n >= (1ull << 28) ? 22 : n >= (1ull << 27) ? 21 : n >= 4096 ? 16 : 8;
   static const int cand_te[] = {4, 6, 7, 9, 12, 14, 16};
   const int b1 = 252;
   (void)glv_max_bits;

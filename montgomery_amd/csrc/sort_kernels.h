@@ -623,7 +623,10 @@ __global__ void __launch_bounds__(256) k_fine_hist(uint32_t* counts, const uint3
 // ---------------------------------------------------------------------------------------------
 
 constexpr int CO_THREADS = 256, CO_PPT = CO_PAIRS / CO_THREADS;   // 16 consecutive pairs per thread
-constexpr int CO_MAX_KEYS = 65;                                   // up to 64 chunks + the pads
+#ifndef MSM_CO_MAX_KEYS
+#define MSM_CO_MAX_KEYS 65
+#endif
+constexpr int CO_MAX_KEYS = MSM_CO_MAX_KEYS;                      // up to 64 chunks + the pads
 
 __global__ void __launch_bounds__(CO_THREADS) k_chunk_order(uint2* pairs_out, uint16_t* oidx, const uint2* pairs_in, uint64_t n_pairs,
                                                             uint32_t row_shift, uint32_t nkeys) {
