@@ -11,7 +11,7 @@ from montgomery_amd.api import MsmContext
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 c_oracle.load()
-curves = [(_lib.CURVE_BLS12_377_G1, O.BLS12_377, 48), (_lib.CURVE_BLS12_381_G1, O.BLS12_381, 48), (_lib.CURVE_PALLAS, O.PALLAS, 48)]
+curves = [(_lib.CURVE_BLS12_377_G1, O.BLS12_377, 48), (_lib.CURVE_BLS12_381_G1, O.BLS12_381, 48), (_lib.CURVE_PALLAS, O.PALLAS, 32)]
 ctxs = {cid: MsmContext(cid) for cid, _, _ in curves}
 pools = {cid: O.random_points_bls377(f"fuzz/{B.label}", 300, B)[0] for cid, B, _ in curves}
 E = O.ED_ON_BLS12_377
@@ -58,7 +58,8 @@ while time.time() - t0 < budget:
     no_glv = rnd.random() < 0.15
     if no_glv and c is not None and c < 4: c = 4
     ctx = ctxs[cid]
-    ctx.set_points(b"".join(b"\0" * 96 if P is None else P[0].to_bytes(48, "little") + P[1].to_bytes(48, "little") for P in pts))
+    cb = ctx.coord_bytes
+    ctx.set_points(b"".join(b"\0" * (2 * cb) if P is None else P[0].to_bytes(cb, "little") + P[1].to_bytes(cb, "little") for P in pts))
     got, info = ctx.run(O.scalars_to_bytes(sc), c=c, no_glv=no_glv)
     if cid == _lib.CURVE_BLS12_377_G1:
         exp, _ = c_oracle.msm_bls377(O.points_to_bytes([(0, 0) if P is None else P for P in pts], 48), O.scalars_to_bytes(sc), 0)
