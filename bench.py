@@ -15,7 +15,7 @@ scaling = "strong".
 
 Prints ONE JSON line on rank 0 with the driver's contract plus
   `roofline`      dominant kernel k_batch_add, HIP-event timed inside the library on its own stream,
-  `cpu_baseline`  the C port of the oracle on ALL host cores, bounded sample,
+  `cpu_baseline`  the C port of the oracle on the host cores this box grants (its cgroup CPU quota), bounded sample, in a child process,
   `verified`      the result of the LAST timed step checked outside the timed region against the known
                   discrete logs of the generated points: sum s_i P_i == (sum s_i a_i mod q) G
                   (the reference compares every size it benchmarks, scripts/msm-weierstrass.ts:97-107),
@@ -69,49 +69,57 @@ def expected_from_logs(curve_name, a_host, s_host, n):
 def cpu_baseline(ctx, log2n_sample, seed):
     """Times oracle/msm_oracle.c (kind "port") on the host cores over the first 2^k resident points, k = 20 and
     log2n_sample: one untimed warm-up call (thread pool, page faults), then repeated timed calls per size -- median and
-    sample standard deviation as everywhere else.  The reference's WASM path cannot run here."""
-    from oracle import c_oracle
+    sample standard deviation as everywhere else.  The port runs in a child process (oracle/time_port.py) on the same bytes:
+    under the OpenMP runtime torch brings into THIS process its nested teams get one thread each (round 2 and the first
+    lines of round 3 timed it on 7-8 threads that way).  The reference's WASM path cannot run here."""
+    import subprocess
+    import tempfile
 
-    c_oracle.load()
+    sizes = sorted({min(20, log2n_sample), log2n_sample})
+    n_top = 1 << sizes[-1]
+    pts = ctx.get_points(0, n_top)
+    _, sc = ctx.generate_scalars(n_top, seed=seed, to_host=True)
+    with tempfile.TemporaryDirectory(prefix="msm_cpu_") as d:
+        with open(os.path.join(d, "points.bin"), "wb") as f:
+            f.write(pts)
+        with open(os.path.join(d, "scalars.bin"), "wb") as f:
+            f.write(sc)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_port.py"), d, "30"] + [str(lg) for lg in sizes],
+                             env=env, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError("oracle/time_port.py failed: " + out.stderr[-500:])
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
     series, threads = [], 1
-    budget_s = 30.0
-    t_all = time.perf_counter()
-    warm = ctx.get_points(0, 1 << 16)
-    _, wsc = ctx.generate_scalars(1 << 16, seed=seed, to_host=True)
-    c_oracle.msm_bls377(warm, wsc, 0)
-    ref = None
-    for lg in sorted({min(20, log2n_sample), log2n_sample}):
-        n = 1 << lg
-        pts = ctx.get_points(0, n)
-        _, sc = ctx.generate_scalars(n, seed=seed, to_host=True)
-        times = []
-        for rep in range(3):
-            t0 = time.perf_counter()
-            ref, threads = c_oracle.msm_bls377(pts, sc, 0)
-            times.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_all + times[-1] > budget_s:   # the next repeat would not fit the bounded sample
-                break
-        dev, _ = ctx.generate_scalars(n, seed=seed)
-        got, _ = ctx.run_device(dev, n)
+    for e in rep["series"]:
+        n = 1 << e["log2_n"]
+        got, _ = ctx.run(sc[:32 * n])
+        ref = None if e["result"] is None else (int(e["result"][0], 16), int(e["result"][1], 16))
         assert got.as_tuple() == ref, "GPU result differs from the CPU oracle on the cpu_baseline sample"
-        series.append({"log2_n": lg, "runs": len(times), "median_s": statistics.median(times),
+        times = e["times_s"]
+        threads = e["threads"]
+        series.append({"log2_n": e["log2_n"], "runs": len(times), "median_s": statistics.median(times),
                        "std_s": statistics.stdev(times) if len(times) > 1 else None, "points_per_s": n / statistics.median(times),
-                       "window_bits": c_oracle.load().oracle_window_size(lg)})
+                       "threads": threads, "window_bits": e["window_bits"]})
     top = series[-1]
+    quota = rep.get("quota") or 0
     return {
         "value": top["points_per_s"],
         "unit": "points/s",
-        "cores": os.cpu_count(),
+        "cores": threads,
+        "host_cpus": os.cpu_count(),
+        "cpu_quota": quota or None,
         "threads": threads,
         "kind": "port",
         "per_thread": top["points_per_s"] / threads,
         "series": series,
         "sample": f"BLS12-377 G1 MSMs over the first 2^{top['log2_n']} resident points (reference window table, c = {top['window_bits']}), "
-                  f"{top['runs']} timed calls after a warm-up, median {top['median_s']:.2f} s on {threads} OpenMP threads (windows side by "
-                  f"side, one team of threads each; inside a window entries split across the team for slicing / sorting, buckets for "
-                  f"the accumulation and reduction, as the reference's SPMD threads); GPU result on the same inputs checked equal. "
-                  f"A correctness checker first: the reference publishes 6.8e4 points/s per wasm thread at 2^16 on a laptop "
-                  f"(doc/zprize23.md:119-123); compare per_thread",
+                  f"{top['runs']} timed calls after a warm-up, median {top['median_s']:.2f} s on {threads} OpenMP threads"
+                  + (f" (the box grants {quota} CPUs through its cgroup quota; {os.cpu_count()} logical CPUs are visible)" if quota else "")
+                  + " (windows side by side, a team of threads each; inside a window entries split across the team for slicing / "
+                  "sorting, buckets for the accumulation and reduction, as the reference's SPMD threads); GPU result on the same "
+                  "inputs checked equal. A correctness checker first: the reference publishes 6.8e4 points/s per wasm thread at "
+                  "2^16 on a laptop (doc/zprize23.md:119-123); compare per_thread",
     }
 
 

@@ -29,6 +29,8 @@ def load() -> C.CDLL:
         lib.oracle_fp_op.restype = None
         lib.oracle_window_size.argtypes = [C.c_int]
         lib.oracle_window_size.restype = C.c_int
+        lib.oracle_cpu_quota.argtypes = []
+        lib.oracle_cpu_quota.restype = C.c_int
         lib.oracle_dot_u256.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         lib.oracle_dot_u256.restype = None
         _lib = lib
