@@ -176,6 +176,12 @@ struct msm_ctx {
   // staging / misc buffers shared by all window groups
   DevBuf scal, errflag, misc;
   uint32_t* h_info = nullptr;      // pinned
+  // host -> device staging of big pageable buffers (upload_staged): pinned chunks, a copy stream and an event per chunk slot
+  static constexpr int STAGE_THREADS = 4, STAGE_SLOTS = 2;
+  static constexpr size_t STAGE_CHUNK = (size_t)16 << 20;
+  char* stage_pin = nullptr;
+  hipStream_t stage_stream[STAGE_THREADS] = {};
+  hipEvent_t stage_ev[STAGE_THREADS][STAGE_SLOTS + 1] = {};
   uint64_t ws_budget = 0;          // bytes the per-group workspaces may take in total
 
   // per-group workspace: two of them, each with its own stream, so that the memory-bound sort of one
@@ -986,13 +992,59 @@ void te_horner_to_affine(const msm_ctx* ctx, const std::vector<uint32_t>& words,
   te_horner_points(ctx->hte, P, c, out);
 }
 
+// A big buffer in pageable host memory (what a caller of msm_run normally holds: 2 GB of scalars at 2^26) crosses PCIe at
+// ~20 GB/s through one hipMemcpy, which stages it through pinned memory on one thread.  Here a few host threads copy 16 MB
+// chunks into pinned slots of their own and queue each chunk's transfer behind it, so the host copies and the DMA overlap.
+// Ordered into ctx->stream: work queued there afterwards sees the whole buffer.
+void upload_staged(msm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  constexpr int T = msm_ctx::STAGE_THREADS, S = msm_ctx::STAGE_SLOTS;
+  constexpr size_t CH = msm_ctx::STAGE_CHUNK;
+  if (bytes < 4 * CH) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return;
+  }
+  if (!ctx->stage_pin) {
+    HIPCHK(hipHostMalloc((void**)&ctx->stage_pin, (size_t)T * S * CH, hipHostMallocDefault));
+    for (int t = 0; t < T; t++) {
+      HIPCHK(hipStreamCreateWithFlags(&ctx->stage_stream[t], hipStreamNonBlocking));
+      for (int q = 0; q <= S; q++) HIPCHK(hipEventCreateWithFlags(&ctx->stage_ev[t][q], hipEventDisableTiming));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // dst may still be in use by what the stream holds
+  const size_t n_chunks = (bytes + CH - 1) / CH;
+  hipError_t rc[T];
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++) {
+    rc[t] = hipSuccess;
+    th.emplace_back([&, t] {
+      hipError_t e = hipSetDevice(ctx->device);
+      size_t turn = 0;
+      for (size_t i = t; i < n_chunks && e == hipSuccess; i += T, turn++) {
+        const int q = (int)(turn % S);
+        char* pin = ctx->stage_pin + ((size_t)t * S + q) * CH;
+        if (turn >= (size_t)S) e = hipEventSynchronize(ctx->stage_ev[t][q]);   // the slot's previous transfer has left it
+        if (e != hipSuccess) break;
+        const size_t off = i * CH, len = std::min(CH, bytes - off);
+        memcpy(pin, (const char*)src + off, len);
+        e = hipMemcpyAsync((char*)dst + off, pin, len, hipMemcpyHostToDevice, ctx->stage_stream[t]);
+        if (e == hipSuccess) e = hipEventRecord(ctx->stage_ev[t][q], ctx->stage_stream[t]);
+      }
+      if (e == hipSuccess) e = hipEventRecord(ctx->stage_ev[t][S], ctx->stage_stream[t]);
+      rc[t] = e;
+    });
+  }
+  for (auto& x : th) x.join();
+  for (int t = 0; t < T; t++) HIPCHK(rc[t]);
+  for (int t = 0; t < T; t++) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[t][S], 0));
+}
+
 int stage_scalars(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const uint32_t** d_out) {
   if (on_device) {
     *d_out = (const uint32_t*)scalars;
     return MSM_OK;
   }
   ctx->ensure(ctx->scal, n * 32);
-  HIPCHK(hipMemcpyAsync(ctx->scal.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  upload_staged(ctx, ctx->scal.p, scalars, n * 32);
   *d_out = (const uint32_t*)ctx->scal.p;
   return MSM_OK;
 }
@@ -1318,6 +1370,9 @@ void msm_ctx_destroy(msm_ctx* ctx) {
     if (w.stream) (void)hipStreamDestroy(w.stream);
   }
   if (ctx->h_info) (void)hipHostFree(ctx->h_info);
+  if (ctx->stage_pin) (void)hipHostFree(ctx->stage_pin);
+  for (auto& st : ctx->stage_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  for (auto& row : ctx->stage_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1338,7 +1393,7 @@ static int set_points_one(msm_ctx* ctx, const void* points, uint64_t n, int on_d
     const uint32_t* d_wire = (const uint32_t*)points;
     if (!on_device && n) {
       ctx->ensure(ctx->misc, n * wire_bytes);
-      HIPCHK(hipMemcpyAsync(ctx->misc.p, points, n * wire_bytes, hipMemcpyHostToDevice, ctx->stream));
+      upload_staged(ctx, ctx->misc.p, points, n * wire_bytes);
       d_wire = (const uint32_t*)ctx->misc.p;
     }
     HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
@@ -2196,7 +2251,10 @@ int msm_device_upload(msm_ctx* ctx, void* dev_ptr, const void* host, uint64_t by
   if (!ctx || !dev_ptr || (!host && bytes)) return fail(ctx, MSM_ERR_ARG, "msm_device_upload: null argument");
   try {
     HIPCHK(hipSetDevice(ctx->device));
-    if (bytes) HIPCHK(hipMemcpy(dev_ptr, host, bytes, hipMemcpyHostToDevice));
+    if (bytes) {
+      upload_staged(ctx, dev_ptr, host, bytes);
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     return MSM_OK;
   } MSM_CATCH_ALL(ctx)
 }

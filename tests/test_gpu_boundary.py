@@ -243,3 +243,29 @@ def test_two_rank_sharded_bench_in_child_processes():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["verified"] is True, d
     assert d["config"]["workload"] == "bls12-377-g1-msm-2^20" and "window-shard x2" in d["config"]["parallelism"]
+
+
+def test_big_host_buffers_cross_in_staged_chunks():
+    """Host scalars and wire points above 64 MB go through the library's pinned staging chunks (16 MB each, several host
+    threads, the last chunk ragged): the MSM over host scalars must equal the one over the same scalars resident on the
+    device, and points uploaded from the host must read back byte for byte."""
+    from montgomery_amd.api import MsmContext
+
+    n = (1 << 21) + 12345                       # 67.5 MB of scalars, 202 MB of wire points
+    ctx = MsmContext()
+    logs = ctx.generate_points(n, seed=31, want_scalars=True)    # P_i = a_i G; the a_i as 32-byte integers
+    dev, host = ctx.generate_scalars(n, seed=32, to_host=True)
+    on_dev, _ = ctx.run_device(dev, n)
+    on_host, _ = ctx.run(host)
+    assert on_host.as_tuple() == on_dev.as_tuple()
+    from oracle import c_oracle
+
+    k = c_oracle.dot_mod(logs, host, n, C.q)
+    assert on_dev.as_tuple() == O.aff_scale(k, G, C.p)
+    wire = ctx.get_points(0, n)
+    other = MsmContext()
+    other.set_points(wire)
+    assert other.get_points(0, n) == wire
+    other_host, _ = other.run(host)
+    assert other_host.as_tuple() == on_dev.as_tuple()
+    other.close(); ctx.close()
