@@ -233,6 +233,25 @@ def test_msm_large_known_discrete_logs(cv, lg):
     assert res2.as_tuple() == res.as_tuple()
 
 
+@pytest.mark.parametrize("c", [20, 22])
+def test_big_windows_chunk_ordered_round1(cv, c):
+    """2^23 points with windows of 2^19 / 2^21 buckets: the three-pass split, round 1 walking its pairs chunk by chunk of
+    the row table and leaving element records (one 64-byte record [x | y] per element on the 8-word field of Pallas, an x and
+    a y record on the 12-word field of BLS12-381), round 2 reading them back -- against the known discrete logs."""
+    from oracle import c_oracle
+
+    ctx, B = cv.ctx, cv.B
+    n = 1 << 23
+    a = ctx.generate_points(n, seed=777 + c, want_scalars=True, raw=True)
+    dev, s = ctx.generate_scalars(n, seed=888 + c, to_host=True, raw=True)
+    res, info = ctx.run_device(dev, n, c=c)
+    assert info["c"] == c
+    k = c_oracle.dot_mod(a, s, n, B.q)
+    assert res.as_tuple() == O.aff_scale(k, (B.gx, B.gy), B.p), info
+    res16, _ = ctx.run_device(dev, n)
+    assert res16.as_tuple() == res.as_tuple()
+
+
 def test_reference_shaped_api(cv):
     ctx, gold, B, P_MOD = cv.ctx, cv.gold, cv.B, cv.B.p
     from montgomery_amd.api import BLS12_381_PARAMS, PALLAS_PARAMS, Weierstrass
