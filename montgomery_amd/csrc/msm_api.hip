@@ -899,7 +899,7 @@ void plane_element_to_wire(const msm_ctx* ctx, const uint32_t* planes, uint64_t 
 int windows_per_group(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
   // bytes per window and point (Weierstrass: 2 entries per point): digits 8, record arrays of the radix passes 16 (+ 8 for the
   // third pass of windows above 2^15 buckets), slots ~9, tree buffers 96 + 48, prefix scratch 56; a chunk-ordered round 1
-  // (c >= 18) adds its reordered slots, the index table and the 128-byte element rows, and its plane buffers start one round
+  // (c >= 18) adds its reordered slots, the index table and the element records (128 bytes per pair), and its plane buffers start one round
   // later.  Per window and bucket: counters, cursors, up to 34 offset tables, and the block histograms of the sort.
   const bool te = ctx->is_te();
   const bool big = pl.c > 16;
