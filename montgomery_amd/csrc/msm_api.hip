@@ -1011,6 +1011,7 @@ void upload_staged(msm_ctx* ctx, void* dst, const void* src, size_t bytes) {
     }
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));   // dst may still be in use by what the stream holds
+  for (int t = 0; t < T; t++) HIPCHK(hipStreamSynchronize(ctx->stage_stream[t]));   // and the slots by an earlier upload
   const size_t n_chunks = (bytes + CH - 1) / CH;
   hipError_t rc[T];
   std::vector<std::thread> th;
