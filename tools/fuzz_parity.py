@@ -1,5 +1,5 @@
 """Randomised differential run of the HIP path against the C oracle (BLS12-377) and the Python oracle (other curves):
-random N, window sizes, point multisets with repeats / negations / identities, scalar patterns.  Usage:
+random N, window sizes (FUZZ_CS=21,22,23,24 picks them; 0 = the default policy), point multisets with repeats / negations / identities, scalar patterns.  Usage:
     python tools/fuzz_parity.py [seconds] [seed]"""
 import random, sys, time
 sys.path.insert(0, "/root/repo")
@@ -8,6 +8,8 @@ from oracle import c_oracle
 from montgomery_amd import _lib
 from montgomery_amd.api import MsmContext
 
+import os
+CS = [int(x) or None for x in os.environ["FUZZ_CS"].split(",")] if os.environ.get("FUZZ_CS") else [None, None, 2, 3, 4, 5, 7, 8, 10, 11, 13, 15, 16, 17, 19, 20]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 c_oracle.load()
@@ -54,7 +56,7 @@ while time.time() - t0 < budget:
     elif mode == "same": sc = [rnd.randrange(B.q)] * n
     elif mode == "edge": sc = [rnd.choice([0, 1, 2, B.q - 1, B.q - 2, B.lam, B.lam + 1, B.q // 2, (1 << 127) - 1, 1 << 127, 1 << 126]) for _ in range(n)]
     else: sc = [B.q - 1 - rnd.randrange(1 << 20) for _ in range(n)]
-    c = rnd.choice([None, None, 2, 3, 4, 5, 7, 8, 10, 11, 13, 15, 16, 17, 19, 20])
+    c = rnd.choice(CS)
     no_glv = rnd.random() < 0.15
     if no_glv and c is not None and c < 4: c = 4
     ctx = ctxs[cid]
