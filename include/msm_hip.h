@@ -122,6 +122,13 @@ int msm_device_alloc(msm_ctx* ctx, uint64_t bytes, void** dev_ptr_out);
 int msm_device_free(msm_ctx* ctx, void* dev_ptr);
 int msm_device_upload(msm_ctx* ctx, void* dev_ptr, const void* host, uint64_t bytes);
 
+/* Device memory the working buffers of one call may take (digits, sort records, tree nodes: the reference sizes them per call
+ * in wasm memory, src/msm-batched-affine.ts:96-130).  0 = automatic: 85 % of what the device has free when a big call starts.
+ * Windows run in as many groups as fit, and a window whose buffers would not fit at all runs over ranges of the points, one
+ * range after the other, its sums added on the host -- so a limit (a GPU shared with other work) or an input of 2^29 points
+ * costs time, not an error.  Multi-device contexts apply the limit per device. */
+int msm_set_workspace_limit(msm_ctx* ctx, uint64_t bytes);
+
 /* sum_i scalars[i] * points[i] over the first n resident points
  * (msm / msmUnsafe, src/msm-batched-affine.ts:69-340, 587-598; for the Edwards curve msmBasic,
  * src/msm-basic.ts:45-164).  on_device != 0: `scalars` already sits in HBM. */

@@ -30,7 +30,7 @@ EXPORTS = (
     "msm_ctx_create_multi", "msm_ctx_device_count", "msm_pointset_create", "msm_pointset_select", "msm_pointset_destroy",
     "msm_device_alloc", "msm_device_free", "msm_device_upload",
     "msm_test_fp_raw", "msm_test_curve_op", "msm_test_batch_add_mode",
-    "msm_run_placed", "msm_combine_groups", "msm_test_bucket_reduce",
+    "msm_run_placed", "msm_combine_groups", "msm_test_bucket_reduce", "msm_set_workspace_limit",
 )
 
 
@@ -101,6 +101,7 @@ def load() -> C.CDLL:
     lib.msm_device_alloc.argtypes = [vp, u64, C.POINTER(vp)]
     lib.msm_device_free.argtypes = [vp, vp]
     lib.msm_device_upload.argtypes = [vp, vp, vp, u64]
+    lib.msm_set_workspace_limit.argtypes = [vp, u64]
     lib.msm_test_fp_raw.argtypes = [vp, C.c_int, vp, vp, vp, u64]
     lib.msm_test_curve_op.argtypes = [vp, C.c_int, vp, vp, vp, u64]
     lib.msm_test_batch_add_mode.argtypes = [vp, vp, vp, vp, u64, C.c_int, C.c_uint32]

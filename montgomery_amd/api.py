@@ -221,6 +221,10 @@ class MsmContext:
         buf = data if isinstance(data, C.Array) else (C.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")
         self._check(self._lib.msm_device_upload(self._h, C.c_void_p(dev_ptr), buf, len(data)))
 
+    def set_workspace_limit(self, nbytes: int) -> None:
+        """Device memory the working buffers of one call may take (0 = automatic); see include/msm_hip.h."""
+        self._check(self._lib.msm_set_workspace_limit(self._h, int(nbytes)))
+
     @property
     def n_devices(self) -> int:
         return int(self._lib.msm_ctx_device_count(self._h))

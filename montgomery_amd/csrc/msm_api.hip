@@ -183,6 +183,7 @@ struct msm_ctx {
   hipStream_t stage_stream[STAGE_THREADS] = {};
   hipEvent_t stage_ev[STAGE_THREADS][STAGE_SLOTS + 1] = {};
   uint64_t ws_budget = 0;          // bytes the per-group workspaces may take in total
+  uint64_t ws_limit = 0;           // msm_set_workspace_limit: the caller's cap on ws_budget (0 = automatic)
 
   // per-group workspace: two of them, each with its own stream, so that the memory-bound sort of one
   // window group runs under the ALU-bound accumulation of the other
@@ -216,7 +217,12 @@ struct msm_ctx {
     b.p = nullptr;
     b.cap = 0;
     size_t want = bytes + bytes / 16 + 256;
-    HIPCHK(hipMalloc(&b.p, want));
+    const hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();   // the failure must not stay behind as this thread's "last error": the kernel-launch checks read it
+      b.p = nullptr;
+      throw HipFail{e, "hipMalloc(&b.p, want)", __LINE__};
+    }
     b.cap = want;
   }
   void release(DevBuf& b) {
@@ -276,9 +282,10 @@ int fail_hip(msm_ctx* ctx, const HipFail& f) {
 // GPU-tuned window size (the reference's table, src/msm-common.ts:25-41, was tuned for 16 CPU threads and copies
 // points).  Weierstrass + GLV (b + 1 = 127 or 128 bits): measured over N = 2^4 .. 2^26 (tools/small_sizes.py), c = 16
 // (K = 8, no degenerate top window, one window's counters fit the LDS) wins from N = 2^12 up -- by 20 % over c = 13
-// at 2^14 .. 2^18, where a smaller window mostly buys more rounds of fixed latency -- and c = 8 below.  From 2^28 points
-// c = 22 (K = 6: a quarter fewer pair additions) wins with the three-pass sort and the chunk-ordered round 1 (601 against
-// 643 ms); at 2^26 and 2^27 the two tie (154.7 / 153.4 and 311 / 313 ms, profiles/r03_experiments.txt) and c = 16 stays.
+// at 2^14 .. 2^18, where a smaller window mostly buys more rounds of fixed latency -- and c = 8 below.  From 2^27 points
+// the big windows (K = 7 / 6: a quarter fewer pair additions) win with the three-pass sort and the chunk-ordered round 1:
+// c = 21 at 2^27 (303 against 314 ms), c = 22 from 2^28 (601 against 643 ms); at 2^26 they are level with c = 16
+// (153 / 154 ms, profiles/r03_experiments.txt items 5 and 12) and c = 16 stays.
 // Twisted Edwards (b + 1 = 252, no inversion per round): a cost model over the window sizes whose top window is not
 // degenerate, ~9 multiplications per pair addition against ~64 per bucket; its picks are within 3 % of the best
 // measured ones.
@@ -896,7 +903,7 @@ void plane_element_to_wire(const msm_ctx* ctx, const uint32_t* planes, uint64_t 
 }
 
 // how many windows fit one group under the workspace budget
-int windows_per_group(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
+long double window_bytes(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
   // bytes per window and point (Weierstrass: 2 entries per point): digits 8, record arrays of the radix passes 16 (+ 8 for the
   // third pass of windows above 2^15 buckets), slots ~9, tree buffers 96 + 48, prefix scratch 56; a chunk-ordered round 1
   // (c >= 18) adds its reordered slots, the index table and the element records (128 bytes per pair), and its plane buffers start one round
@@ -906,9 +913,18 @@ int windows_per_group(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
   long double per_point = te ? (4 + 8 + 5 + 64 + 32) : (8 + 16 + 9 + 96 + 48 + 56);
   if (big && !te) per_point += 8 + 9 + 2 + 128 - 72;
   const long double hist_bins = big ? (long double)(pl.L >> 7) : (long double)pl.L;
-  long double per = (long double)n * per_point + (long double)pl.L * 4 * 40 + hist_bins * 4 * (2.0L * ctx->n_cu);
-  int w = (int)std::max<long double>(1, (long double)ctx->ws_budget / msm_ctx::N_WS / per);
+  return (long double)n * per_point + (long double)pl.L * 4 * 40 + hist_bins * 4 * (2.0L * ctx->n_cu);
+}
+int windows_per_group(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
+  int w = (int)std::max<long double>(1, (long double)ctx->ws_budget / msm_ctx::N_WS / window_bytes(ctx, n, pl));
   return std::min(w, pl.K);
+}
+// how many ranges of the points ONE window has to be cut into for its workspace to fit (1: it fits as a whole)
+uint64_t point_pieces(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
+  const long double room = (long double)ctx->ws_budget / msm_ctx::N_WS;
+  uint64_t pieces = 1;
+  while (pieces < 256 && n / pieces > 4096 && window_bytes(ctx, (n + pieces - 1) / pieces, pl) > room) pieces++;
+  return pieces;
 }
 
 // S = sum_k 2^(ck) P_k, then affine (src/msm-batched-affine.ts:322-333, src/curve-projective.ts:335-349)
@@ -1051,8 +1067,8 @@ int stage_scalars(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, 
 }
 
 // windows [k_lo, k_hi) over the resident points [p_off, p_off + n); scalars[i] belongs to point p_off + i
-int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, int k_lo, int k_hi,
-                     const Plan& pl, std::vector<uint32_t>& words, msm_result* stats, uint64_t p_off = 0) {
+int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, int k_lo, int k_hi,
+                     const Plan& pl, std::vector<uint32_t>& words, msm_result* stats, uint64_t p_off) {
   const uint32_t* d_scal = nullptr;
   HIPCHK(hipEventRecord(ctx->ev[8], ctx->stream));
   stage_scalars(ctx, scalars, n, on_device, &d_scal);
@@ -1064,6 +1080,18 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   // run in step (both sort, both gather, ...): what the second one buys is two tree kernels sharing the chip -- forward
   // (memory-heavy) and backward (issue-heavy) sweeps of different waves mix, the small last rounds fill each other's
   // idle CUs -- not a sort hidden under an accumulation
+  if (ctx->ws_limit) {
+    ctx->ws_budget = ctx->ws_limit;
+  } else if (n >= (1ull << 22)) {
+    // big inputs: the budget is what the device has free NOW (point sets, scalar buffers and other contexts have come and
+    // gone since the context was made) plus what the workspaces already hold
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    uint64_t held = 0;
+    for (auto& w : ctx->ws)
+      for (DevBuf* b : w.all) held += b->cap;
+    ctx->ws_budget = (uint64_t)((free_b + held) * 0.85L);
+  }
   int wpg = std::min(windows_per_group(ctx, n, pl), 128);
   const int nwin = k_hi - k_lo;
   // measured on MI355X: two groups win 14 % at 2^23 / 2^24, 3 % at 2^22, nothing at 2^21 -- below that the fixed
@@ -1078,15 +1106,24 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   std::vector<Group> groups;
   // A single window (the 8-GPU shard) has no second window group to hide its sort and tails under: split it by
   // points instead -- two half-size sub-MSMs of the same window on the two streams, their sums added on the host.
-  const bool split_points = nwin == 1 && want_groups == 1 && !ctx->is_te() && n >= (1ull << 24) && !MSM_KNOB_SET("MSM_GROUPS");
+  // The same split serves inputs whose single window no longer fits the workspace budget (2^29 points: 165 GB per window
+  // at c = 22 next to a 137 GB row table): every window runs over as many ranges of the points as it takes, one after the
+  // other on the two streams, and the sums of its ranges are added on the host.
+  uint64_t pieces = 1;
+  if (nwin == 1 && want_groups == 1 && !ctx->is_te() && n >= (1ull << 24) && !MSM_KNOB_SET("MSM_GROUPS")) pieces = 2;
+  pieces = std::max(pieces, point_pieces(ctx, n, pl));
+  MSM_KNOB(pieces, "MSM_PIECES", 1);
+  const bool split_points = pieces > 1;
   if (split_points) {
-    const uint64_t h = n / 2;
-    groups.push_back({k_lo, k_hi, 0, h});
-    groups.push_back({k_lo, k_hi, h, n - h});
+    for (int k = k_lo; k < k_hi; k++)
+      for (uint64_t q = 0; q < pieces; q++) {
+        const uint64_t lo = n * q / pieces, hi = n * (q + 1) / pieces;
+        groups.push_back({k, k + 1, lo, hi - lo});
+      }
   } else {
     for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg), 0, n});
   }
-  std::vector<uint32_t> split_part[2];
+  std::vector<std::vector<uint32_t>> split_part(split_points ? groups.size() : 0);
   HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));   // staged scalars are in place before the group streams start
   std::atomic<int> next{0};
@@ -1133,8 +1170,21 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     if (pl.strict && (ctx->h_info[0] & 4u)) throw MsmFail{MSM_ERR_SCALAR, "a scalar is >= the group order q (msm_opts.strict)"};
   }
   if (split_points) {
-    const msm_host::Proj6 sum = ctx->hc.add(partial_to_host(ctx, split_part[0].data()), partial_to_host(ctx, split_part[1].data()));
-    host_to_partial(ctx, sum, words.data());
+    // P_k = sum over the ranges; an all-zero partial (Z = 0) is the identity
+    for (int k = k_lo; k < k_hi; k++) {
+      uint32_t* out = &words[(size_t)(k - k_lo) * pw];
+      if (ctx->is_te()) {
+        msm_host::Ext6 acc = ctx->hte.zero();
+        for (size_t gi = 0; gi < groups.size(); gi++)
+          if (groups[gi].ka == k && !split_part[gi].empty()) acc = ctx->hte.add(acc, te_partial_to_host(ctx, split_part[gi].data()));
+        te_host_to_partial(ctx, acc, out);
+      } else {
+        msm_host::Proj6 acc = ctx->hc.zero();
+        for (size_t gi = 0; gi < groups.size(); gi++)
+          if (groups[gi].ka == k && !split_part[gi].empty()) acc = ctx->hc.add(acc, partial_to_host(ctx, split_part[gi].data()));
+        host_to_partial(ctx, acc, out);
+      }
+    }
   }
   for (int i = 0; i < msm_ctx::N_WS; i++) {
     st.n_pairs += sts[i].n_pairs;
@@ -1165,6 +1215,24 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   return MSM_OK;
 }
 
+
+// Workspace buffers only grow, and a call with another shape (window size, curve of the point set, sort path) leaves buffers
+// behind that the next shape does not use: if the device runs out of memory the workspaces are dropped and the call runs
+// once more from a clean slate, where the budget model of window_sums_once holds again.
+int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, int k_lo, int k_hi,
+                     const Plan& pl, std::vector<uint32_t>& words, msm_result* stats, uint64_t p_off = 0) {
+  try {
+    return window_sums_once(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats, p_off);
+  } catch (const HipFail& f) {
+    if (f.e != hipErrorOutOfMemory) throw;
+  }
+  (void)hipGetLastError();
+  for (auto& w : ctx->ws) {
+    (void)hipStreamSynchronize(w.stream);
+    for (DevBuf* b : w.all) ctx->release(*b);
+  }
+  return window_sums_once(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats, p_off);
+}
 
 // Multi-device context: one MSM over the devices of the list, each from its own host thread on its own context.
 //   by points (default): device d runs ALL windows [k_lo, k_hi) on its share [n d / G, n (d + 1) / G) of the points and needs
@@ -2258,6 +2326,27 @@ int msm_device_upload(msm_ctx* ctx, void* dev_ptr, const void* host, uint64_t by
     }
     return MSM_OK;
   } MSM_CATCH_ALL(ctx)
+}
+
+int msm_set_workspace_limit(msm_ctx* ctx, uint64_t bytes) {
+  if (!ctx) return MSM_ERR_ARG;
+  ctx->ws_limit = bytes;
+  if (!bytes) {   // back to automatic: small calls use the creation-time rule again
+    try {
+      HIPCHK(hipSetDevice(ctx->device));
+      size_t free_b = 0, total_b = 0;
+      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      uint64_t held = 0;
+      for (auto& w : ctx->ws)
+        for (DevBuf* b : w.all) held += b->cap;
+      ctx->ws_budget = (uint64_t)((free_b + held) * 0.55L);
+    } MSM_CATCH_ALL(ctx)
+  }
+  for (msm_ctx* c : ctx->children) {
+    int rc = msm_set_workspace_limit(c, bytes);
+    if (rc != MSM_OK) return rc;
+  }
+  return MSM_OK;
 }
 
 // ---- multi-device context ---------------------------------------------------------------------------------------

@@ -269,3 +269,31 @@ def test_big_host_buffers_cross_in_staged_chunks():
     other_host, _ = other.run(host)
     assert other_host.as_tuple() == on_dev.as_tuple()
     other.close(); ctx.close()
+
+
+@pytest.mark.parametrize("curve", ["bls12-377", "ed377"])
+def test_workspace_limit_runs_windows_over_point_ranges(curve):
+    """msm_set_workspace_limit: with room for a third of a window's buffers every window runs over ranges of the points, the
+    sums of the ranges added on the host -- the path 2^29 points take on their own (tools/huge_check.py).  Same result as
+    without a limit, more tree rounds."""
+    from montgomery_amd import _lib
+    from montgomery_amd.api import MsmContext
+
+    te = curve == "ed377"
+    ctx = MsmContext(_lib.CURVE_ED_ON_BLS12_377 if te else _lib.CURVE_BLS12_377_G1)
+    n = (1 << 18) + 321
+    ctx.generate_points(n, seed=61)
+    dev, _ = ctx.generate_scalars(n, seed=62)
+    c = 12 if te else 13
+    ref, info0 = ctx.run_device(dev, n, c=c)
+    ctx.set_workspace_limit(40 << 20 if te else 60 << 20)
+    got, info1 = ctx.run_device(dev, n, c=c)
+    assert got.as_tuple() == ref.as_tuple()
+    assert info1["rounds"] > info0["rounds"], (info0["rounds"], info1["rounds"])
+    K = info0["K"]
+    part, _ = ctx.window_sums(dev, n, 0, K, c=c, on_device=True)   # the shard entry takes the same path
+    assert ctx.combine(part, K, c).as_tuple() == ref.as_tuple()
+    ctx.set_workspace_limit(0)
+    again, info2 = ctx.run_device(dev, n, c=c)
+    assert again.as_tuple() == ref.as_tuple() and info2["rounds"] == info0["rounds"]
+    ctx.close()
