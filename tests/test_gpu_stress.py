@@ -65,3 +65,43 @@ def test_two_live_contexts_interleaved():
     finally:
         c1.close()
         c2.close()
+
+
+def test_two_contexts_from_two_threads():
+    """"Calls on one context are serialised, distinct contexts are independent" (include/msm_hip.h): two host threads, a context
+    each, MSMs of different curves and sizes at the same time (ctypes drops the GIL inside the library), host-buffer and
+    device-buffer scalars mixed.  Every result must be the one the context gives alone."""
+    import threading
+
+    from montgomery_amd.api import MsmContext
+
+    jobs = [(curve("bls12-377"), (1 << 19) + 5, 11), (curve("bls12-381"), (1 << 18) + 9, 12)]
+    ctxs, refs, outs, errs = [], [], [[], []], []
+    for (cid, B), n, seed in jobs:
+        ctx = MsmContext(cid)
+        ctx.generate_points(n, seed=seed)
+        dev, host = ctx.generate_scalars(n, seed=seed + 100, to_host=True)
+        refs.append(ctx.run_device(dev, n)[0].as_tuple())
+        ctxs.append((ctx, dev, host, n))
+
+    def work(i):
+        try:
+            ctx, dev, host, n = ctxs[i]
+            for rep in range(6):
+                r, _ = ctx.run(host) if rep % 2 else ctx.run_device(dev, n)
+                outs[i].append(r.as_tuple())
+        except Exception as e:   # noqa: BLE001 -- reported by the assertion below
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    try:
+        assert not errs, errs
+        for i in range(2):
+            assert outs[i] == [refs[i]] * 6
+    finally:
+        for ctx, *_ in ctxs:
+            ctx.close()
