@@ -699,14 +699,14 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   const uint32_t* round1_slots = (const uint32_t*)w.slots.p;
   const uint16_t* round1_oidx = nullptr;
   uint64_t rec_y_off = 0;   // 12-word fields: where the y records of round 1's results start inside w.rows1
-  bool chunked = false;   // round 1 walks chunk-ordered pairs and writes element rows, round 2 reads them
+  bool chunked = false;   // round 1 walks chunk-ordered pairs and writes element records, round 2 reads them
   {
     long long chunk_rows_log = 22;   // 2^22 rows of 256 bytes = 1 GB
     MSM_KNOB(chunk_rows_log, "MSM_CHUNK_LOG", 10);
     long long want_chunks = (!te && pl.c >= 18 && n > (1ull << chunk_rows_log)) ? 1 : 0;
     MSM_KNOB(want_chunks, "MSM_CHUNKED", 0);
     const uint64_t nch = (n + (1ull << chunk_rows_log) - 1) >> chunk_rows_log;
-    // (round 2 must be an index-free round to read the element rows round 1 then writes: logG >= 2)
+    // (round 2 must be an index-free round to read the element records round 1 then writes: logG >= 2)
     if (want_chunks && !te && logG >= 2 && total_slots >= 2 && nch >= 2 && nch + 1 <= (uint64_t)CO_MAX_KEYS) {
       const uint64_t n_pairs = total_slots / 2;
       ctx->ensure(w.slots2, total_slots * 4);
@@ -750,7 +750,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     uint64_t cnt = total_slots;
     for (uint32_t r = 1; r <= logG; r++) {
       cnt /= 2;
-      if (r == 1 && chunked) continue;   // element rows (w.rows1), not planes
+      if (r == 1 && chunked) continue;   // element records (w.rows1), not planes
       (which ? capB : capA) = std::max<uint64_t>(which ? capB : capA, cnt);
       which ^= 1;
     }
