@@ -313,6 +313,8 @@ struct Plan {
   bool no_glv;
   bool strict = false;   // msm_opts.strict: scalars >= q fail the call instead of being reduced
   bool lone = false;   // one window, one group: nothing else shares the GPU (see round_geom)
+  bool merged = false; // a full MSM (msm_run): a window group may hand back sum_k 2^(c (k - k_first)) P_k in the slot of its
+                       // first window instead of one P_k per slot (reduce_buckets); msm_window_sums never sets it
 };
 
 int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
@@ -392,30 +394,29 @@ void fe6_to_bytes(uint8_t* out, const msm_host::Fe6& a) {
     for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(a.v[i] >> (8 * j));
 }
 
-// device-Montgomery packed partial (36 words) -> host projective point (host Montgomery form)
+// Window sums travel as 36 words (X, Y, Z: 12 packed words each, device Montgomery form, below 2p).  A projective point is a
+// class of triples, so the host neither converts them on the way in nor on the way out: read as host Montgomery values the
+// three words of a device point carry one common factor (2^6 for 13 limbs), which is the same point, and so is every sum the
+// host forms of such points.  Only affine values need the exact radix (horner_to_affine divides the factor out with Z).
 msm_host::Proj6 partial_to_host(const msm_ctx* ctx, const uint32_t* w) {
+  const auto& F = ctx->hc.F;
   msm_host::Proj6 P;
-  msm_host::Fe6 t;
-  words_to_fe6(t, w);      ctx->hc.F.mul(P.X, t, ctx->k_dev_to_host);
-  words_to_fe6(t, w + 12); ctx->hc.F.mul(P.Y, t, ctx->k_dev_to_host);
-  words_to_fe6(t, w + 24); ctx->hc.F.mul(P.Z, t, ctx->k_dev_to_host);
+  msm_host::Fe6* co[3] = {&P.X, &P.Y, &P.Z};
+  for (int j = 0; j < 3; j++) {
+    words_to_fe6(*co[j], w + 12 * j);
+    while (msm_host::Field6::ge(*co[j], F.p)) F.sub_raw(*co[j], *co[j], F.p);
+  }
   return P;
 }
 
-// host projective point -> the packed device-Montgomery form the pipeline carries (x 2^6: 2^384 -> 2^390)
-void host_to_partial(const msm_ctx* ctx, const msm_host::Proj6& P, uint32_t* out36) {
-  const auto& C = ctx->hc;
+// host projective point -> the packed form the pipeline carries (canonical values; see above for the radix)
+void host_to_partial(const msm_ctx*, const msm_host::Proj6& P, uint32_t* out36) {
   const msm_host::Fe6* co[3] = {&P.X, &P.Y, &P.Z};
-  for (int j = 0; j < 3; j++) {
-    msm_host::Fe6 t = *co[j];
-    for (int d = 0; d < 6; d++) C.F.add(t, t, t);
-    msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
-    C.F.mul(t, t, one);
+  for (int j = 0; j < 3; j++)
     for (int q = 0; q < 6; q++) {
-      out36[12 * j + 2 * q] = (uint32_t)t.v[q];
-      out36[12 * j + 2 * q + 1] = (uint32_t)(t.v[q] >> 32);
+      out36[12 * j + 2 * q] = (uint32_t)co[j]->v[q];
+      out36[12 * j + 2 * q + 1] = (uint32_t)(co[j]->v[q] >> 32);
     }
-  }
 }
 
 // Bucket reduction of kc windows of L buckets each: P_k = sum_l l * B_(k,l) (reduceBucketsColumnProjective + the partition
@@ -423,7 +424,7 @@ void host_to_partial(const msm_ctx* ctx, const msm_host::Proj6& P, uint32_t* out
 // sums come as projective points from k_bucket_finish (`bucket_proj`) or as the first element of every bucket in the tree
 // buffer (`fin`, `off_fin`).  Runs on w.stream, records w.ev[4] behind its last kernel and returns when the sums are on the host.
 void reduce_buckets(msm_ctx* ctx, msm_ctx::Workspace& w, const uint4* fin, uint64_t fin_cap, const uint32_t* off_fin,
-                    const uint32_t* bucket_proj, uint32_t L, int kc, uint32_t* h_partials_out) {
+                    const uint32_t* bucket_proj, uint32_t L, int kc, uint32_t* h_partials_out, bool merged = false) {
   hipStream_t s = w.stream;
   const bool te = ctx->is_te();
   const uint64_t nb = (uint64_t)kc * L;
@@ -488,6 +489,29 @@ void reduce_buckets(msm_ctx* ctx, msm_ctx::Workspace& w, const uint4* fin, uint6
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     const auto& C = ctx->hc;
+    if (merged) {
+      // The caller only wants S_g = sum_kk 2^(c kk) P_kk of the whole group (a full MSM on this device: the Horner step over
+      // the windows follows anyway).  One double-and-add pass over the c kc bit positions then does both jobs -- inside window
+      // kk the sum S_b sits at bit log2(TC) + b, the triangle sum at bit 0 -- with c kc doublings instead of (c - 1) kc for
+      // the windows plus c (kc - 1) for their combination.  S_g goes into the slot of the group's first window, the identity
+      // into the others: sum_k 2^(c k) (slot k) is the same group element as with one P_k per slot.
+      uint32_t lt = 0, cbits = 1;
+      while ((1u << lt) < TC) lt++;
+      while ((1u << (cbits - 1)) < L) cbits++;
+      msm_host::Proj6 acc = C.zero();
+      for (int kk = kc - 1; kk >= 0; kk--) {
+        const uint32_t* base = w.h_part + (size_t)kk * (nbits + 1) * 36;
+        for (int pos = (int)cbits - 1; pos >= 0; pos--) {
+          acc = C.dbl(acc);
+          const int b = pos - (int)lt;
+          if (b >= 0 && b < (int)nbits) acc = C.add(acc, partial_to_host(ctx, base + (size_t)b * 36));
+          if (pos == 0) acc = C.add(acc, partial_to_host(ctx, base + (size_t)nbits * 36));
+        }
+      }
+      memset(h_partials_out, 0, (size_t)kc * 36 * 4);
+      host_to_partial(ctx, acc, h_partials_out);
+      return;
+    }
     for (int kk = 0; kk < kc; kk++) {
       const uint32_t* base = w.h_part + (size_t)kk * (nbits + 1) * 36;
       msm_host::Proj6 acc = C.zero();
@@ -873,7 +897,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   if (total_slots == 0) HIPCHK(hipEventRecord(w.ev[6], s));
   HIPCHK(hipEventRecord(w.ev[3], s));
 
-  reduce_buckets(ctx, w, fin, fin_cap, off_fin, bucket_proj, L, kc, h_partials_out);
+  reduce_buckets(ctx, w, fin, fin_cap, off_fin, bucket_proj, L, kc, h_partials_out, pl.merged);
   float ms;
   HIPCHK(hipEventElapsedTime(&ms, w.ev[0], w.ev[1])); st.ms_digits += ms;
   HIPCHK(hipEventElapsedTime(&ms, w.ev[1], w.ev[2])); st.ms_sort += ms;
@@ -973,7 +997,8 @@ void te_horner_points(const msm_host::TeCurve6& C, const std::vector<msm_host::E
   out->is_infinity = 0;
 }
 
-// device window sum (X, Y, Z, T: 8 words each, Montgomery radix 2^270, < 2p) -> host extended point
+// device window sum (X, Y, Z, T: 8 words each, below 2p) -> host extended point: as for the Weierstrass sums no change of
+// radix -- (X, Y, Z, T) with T = X Y / Z stays a valid extended point when all four carry one common factor
 msm_host::Ext6 te_partial_to_host(const msm_ctx* ctx, const uint32_t* w) {
   const auto& C = ctx->hte;
   msm_host::Ext6 P;
@@ -981,25 +1006,20 @@ msm_host::Ext6 te_partial_to_host(const msm_ctx* ctx, const uint32_t* w) {
   for (int j = 0; j < 4; j++) {
     msm_host::Fe6 t = {{0, 0, 0, 0, 0, 0}};
     for (int i = 0; i < 4; i++) t.v[i] = (uint64_t)w[8 * j + 2 * i] | ((uint64_t)w[8 * j + 2 * i + 1] << 32);
-    if (msm_host::Field6::ge(t, C.F.p)) C.F.sub_raw(t, t, C.F.p);   // device values are < 2p
-    C.F.mul(*dst[j], t, ctx->k_te_to_host);
+    while (msm_host::Field6::ge(t, C.F.p)) C.F.sub_raw(t, t, C.F.p);
+    *dst[j] = t;
   }
   return P;
 }
 
-// host extended point -> the device window-sum form (X, Y, Z, T: 8 words each, radix 2^270): x 2^384 -> x 2^270
-void te_host_to_partial(const msm_ctx* ctx, const msm_host::Ext6& P, uint32_t* out32) {
-  const auto& C = ctx->hte;
-  const msm_host::Fe6 k = C.F.pow2(270);
+// host extended point -> the window-sum form (X, Y, Z, T: 8 words each)
+void te_host_to_partial(const msm_ctx*, const msm_host::Ext6& P, uint32_t* out32) {
   const msm_host::Fe6* co[4] = {&P.X, &P.Y, &P.Z, &P.T};
-  for (int j = 0; j < 4; j++) {
-    msm_host::Fe6 t;
-    C.F.mul(t, *co[j], k);
+  for (int j = 0; j < 4; j++)
     for (int i = 0; i < 4; i++) {
-      out32[8 * j + 2 * i] = (uint32_t)t.v[i];
-      out32[8 * j + 2 * i + 1] = (uint32_t)(t.v[i] >> 32);
+      out32[8 * j + 2 * i] = (uint32_t)co[j]->v[i];
+      out32[8 * j + 2 * i + 1] = (uint32_t)(co[j]->v[i] >> 32);
     }
-  }
 }
 
 void te_horner_to_affine(const msm_ctx* ctx, const std::vector<uint32_t>& words, int K, int c, msm_result* out) {
@@ -1687,6 +1707,7 @@ static int run_impl(msm_ctx* ctx, const void* scalars, const void* const* placed
                 (unsigned long long)(opts ? opts->point_lo : 0), (unsigned long long)n, (unsigned long long)ctx->n_points);
   Plan pl;
   if (make_plan(ctx, n, opts, pl)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);
+  pl.merged = true;
   memset(out, 0, sizeof(*out));
   out->c = pl.c;
   out->K = pl.K;
