@@ -666,28 +666,26 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   uint64_t total_slots = 0;
   uint32_t max_bucket = 0;
   {
-    // largest bucket -> number of tail rounds (first of two small read-backs), then the multi-block scan
+    // largest bucket -> number of tail rounds RT, then the multi-block scan of RT + 2 quantities.  The scan kernels take RT
+    // from the device (pscan_nq), so ONE read-back behind them brings the largest bucket and the totals together.
     HIPCHK(hipMemsetAsync(w.info.p, 0, 64 * 4, s));
     hipLaunchKernelGGL(k_bucket_max, dim3((uint32_t)std::min<uint64_t>(1024, (nb + 255) / 256)), dim3(256), 0, s,
                        (const uint32_t*)w.counts.p, (uint32_t)nb, (uint32_t*)w.info.p);
-    HIPCHK(hipMemcpyAsync(w.h_info, w.info.p, 4 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    max_bucket = w.h_info[1];
-    uint32_t capmax = (max_bucket + (1u << logG) - 1) >> logG;
-    while ((1u << RT) < capmax) RT++;
-    const int nq = RT + 2;
     const uint32_t nblocks = (uint32_t)((nb + PS_SPAN - 1) / PS_SPAN);
-    ctx->ensure(w.scan_partial, (size_t)nq * nblocks * 4);
-    hipLaunchKernelGGL(k_pscan_partial, dim3(nblocks), dim3(PS_BLOCK), 0, s, (const uint32_t*)w.counts.p, (uint32_t)nb, logG, nq,
-                       (uint32_t*)w.scan_partial.p, nblocks);
-    hipLaunchKernelGGL(k_pscan_top, dim3(1), dim3(SCAN_THREADS), 0, s, (uint32_t*)w.scan_partial.p, nblocks, nq,
+    ctx->ensure(w.scan_partial, (size_t)PS_MAX_NQ * nblocks * 4);
+    hipLaunchKernelGGL(k_pscan_partial, dim3(nblocks), dim3(PS_BLOCK), 0, s, (const uint32_t*)w.counts.p, (uint32_t)nb, logG,
+                       (const uint32_t*)w.info.p, (uint32_t*)w.scan_partial.p, nblocks);
+    hipLaunchKernelGGL(k_pscan_top, dim3(1), dim3(SCAN_THREADS), 0, s, (uint32_t*)w.scan_partial.p, nblocks, logG,
                        (uint32_t*)w.info.p);
-    hipLaunchKernelGGL(k_pscan_final, dim3(nblocks), dim3(PS_BLOCK), 0, s, (const uint32_t*)w.counts.p, (uint32_t)nb, logG, nq,
+    hipLaunchKernelGGL(k_pscan_final, dim3(nblocks), dim3(PS_BLOCK), 0, s, (const uint32_t*)w.counts.p, (uint32_t)nb, logG,
                        (const uint32_t*)w.scan_partial.p, nblocks, (uint32_t*)w.cursor.p, (uint32_t*)w.tail_off.p,
                        (const uint32_t*)w.info.p);
     HIPCHK(hipMemcpyAsync(w.h_info, w.info.p, 64 * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     total_slots = w.h_info[0];
+    max_bucket = w.h_info[1];
+    const uint32_t capmax = (max_bucket + (1u << logG) - 1) >> logG;
+    while (RT < 32 && (1u << RT) < capmax) RT++;
   }
   st.max_bucket = std::max<uint64_t>(st.max_bucket, max_bucket);
 

@@ -46,8 +46,9 @@ MSM_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wave, uint32_t& total
 //   quantity 0      : padded slot count  roundup(n, G)          -> cursor (slot offsets), total -> info[0]
 //   quantity 1 + r  : ceil(ceil(n / G) / 2^r), r = 0..RT          -> tail_off[r] (nb + 1 entries), totals -> info[3 + r]
 // k_pscan_partial sums each quantity per block of PS_BLOCK * PS_ITEMS buckets, k_pscan_top scans the
-// block sums (one workgroup), k_pscan_final rescans each block with its base.  k_bucket_max gives the
-// largest bucket (host needs RT before it can size this scan).
+// block sums (one workgroup), k_pscan_final rescans each block with its base.  RT follows from the largest bucket, which
+// k_bucket_max leaves in info[1]: the scan kernels take it from there (pscan_nq), so the host reads the largest bucket back
+// together with the totals, in one read-back behind k_pscan_final, and sizes the scan for the largest RT there can be.
 // ---------------------------------------------------------------------------------------------
 
 constexpr int PS_BLOCK = 256;
@@ -61,6 +62,15 @@ MSM_DEV uint32_t scan_quantity(uint32_t n, uint32_t logG, int q) {
   return (cg + ((1u << r) - 1)) >> r;
 }
 
+constexpr int PS_MAX_NQ = 34;   // RT <= 32
+// number of scanned quantities = RT + 2 with 2^RT >= ceil(largest bucket / G)   (the host repeats this after its read-back)
+MSM_DEV int pscan_nq(const uint32_t* info, uint32_t logG) {
+  const uint32_t capmax = (info[1] + ((1u << logG) - 1)) >> logG;
+  int rt = 0;
+  while (rt < 32 && (1u << rt) < capmax) rt++;
+  return rt + 2;
+}
+
 __global__ void __launch_bounds__(256) k_bucket_max(const uint32_t* counts, uint32_t nb, uint32_t* info) {
   __shared__ uint32_t lds_max;
   if (threadIdx.x == 0) lds_max = 0;
@@ -72,9 +82,10 @@ __global__ void __launch_bounds__(256) k_bucket_max(const uint32_t* counts, uint
   if (threadIdx.x == 0) atomicMax(&info[1], lds_max);
 }
 
-__global__ void __launch_bounds__(PS_BLOCK) k_pscan_partial(const uint32_t* counts, uint32_t nb, uint32_t logG, int nq,
+__global__ void __launch_bounds__(PS_BLOCK) k_pscan_partial(const uint32_t* counts, uint32_t nb, uint32_t logG, const uint32_t* info,
                                                             uint32_t* partial, uint32_t nblocks) {
   __shared__ uint32_t lds_wave[PS_BLOCK / 64];
+  const int nq = pscan_nq(info, logG);
   const uint32_t b0 = blockIdx.x * PS_SPAN + threadIdx.x * PS_ITEMS;
   uint32_t n[PS_ITEMS];
 #pragma unroll
@@ -89,8 +100,9 @@ __global__ void __launch_bounds__(PS_BLOCK) k_pscan_partial(const uint32_t* coun
   }
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) k_pscan_top(uint32_t* partial, uint32_t nblocks, int nq, uint32_t* info) {
+__global__ void __launch_bounds__(SCAN_THREADS) k_pscan_top(uint32_t* partial, uint32_t nblocks, uint32_t logG, uint32_t* info) {
   __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
+  const int nq = pscan_nq(info, logG);
   for (int q = 0; q < nq; q++) {
     uint32_t* p = partial + (uint64_t)q * nblocks;
     uint32_t carry = 0;
@@ -108,10 +120,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_pscan_top(uint32_t* partial, u
   }
 }
 
-__global__ void __launch_bounds__(PS_BLOCK) k_pscan_final(const uint32_t* counts, uint32_t nb, uint32_t logG, int nq,
+__global__ void __launch_bounds__(PS_BLOCK) k_pscan_final(const uint32_t* counts, uint32_t nb, uint32_t logG,
                                                           const uint32_t* partial, uint32_t nblocks, uint32_t* cursor,
                                                           uint32_t* tail_off, const uint32_t* info) {
   __shared__ uint32_t lds_wave[PS_BLOCK / 64];
+  const int nq = pscan_nq(info, logG);
   const uint32_t b0 = blockIdx.x * PS_SPAN + threadIdx.x * PS_ITEMS;
   uint32_t n[PS_ITEMS];
 #pragma unroll
