@@ -69,35 +69,30 @@ struct Field6 {
   }
   void dbl(Fe6& r, const Fe6& a) const { add(r, a, a); }
 
-  // Montgomery product a*b*2^-384 mod p (CIOS), inputs canonical
+  // Montgomery product a*b*2^-384 mod p, inputs canonical.  CIOS with the product row and the reduction row of every round
+  // fused into one pass (two independent carry chains); p < 2^383 -- true of every modulus here (377, 381, 255, 253 bits) --
+  // means the top word of a round cannot overflow, so no extra carry word is kept.
   void mul(Fe6& r, const Fe6& a, const Fe6& b) const {
-    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
     for (int i = 0; i < 6; i++) {
-      u128 c = 0;
-      for (int j = 0; j < 6; j++) {
-        c += (u128)a.v[i] * b.v[j] + t[j];
-        t[j] = (uint64_t)c;
-        c >>= 64;
-      }
-      c += t[6];
-      t[6] = (uint64_t)c;
-      t[7] = (uint64_t)(c >> 64);
-      uint64_t m = t[0] * pinv;
-      c = (u128)m * p.v[0] + t[0];
-      c >>= 64;
+      u128 A = (u128)a.v[i] * b.v[0] + t[0];
+      const uint64_t m = (uint64_t)A * pinv;
+      u128 C = (u128)m * p.v[0] + (uint64_t)A;
+      uint64_t ca = (uint64_t)(A >> 64), cc = (uint64_t)(C >> 64);
+#pragma unroll
       for (int j = 1; j < 6; j++) {
-        c += (u128)m * p.v[j] + t[j];
-        t[j - 1] = (uint64_t)c;
-        c >>= 64;
+        A = (u128)a.v[i] * b.v[j] + t[j] + ca;
+        ca = (uint64_t)(A >> 64);
+        C = (u128)m * p.v[j] + (uint64_t)A + cc;
+        cc = (uint64_t)(C >> 64);
+        t[j - 1] = (uint64_t)C;
       }
-      c += t[6];
-      t[5] = (uint64_t)c;
-      t[6] = t[7] + (uint64_t)(c >> 64);
-      t[7] = 0;
+      t[5] = ca + cc;
     }
     Fe6 o;
     for (int i = 0; i < 6; i++) o.v[i] = t[i];
-    if (t[6] || ge(o, p)) sub_raw(o, o, p);
+    if (ge(o, p)) sub_raw(o, o, p);
     r = o;
   }
   void sqr(Fe6& r, const Fe6& a) const { mul(r, a, a); }
