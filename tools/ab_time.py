@@ -10,7 +10,7 @@ from montgomery_amd.api import MsmContext
 lg = int(sys.argv[1]); n = 1 << lg
 import os
 cc = int(os.environ.get('MSM_C', '0')) or None
-ctx = MsmContext()
+ctx = MsmContext(int(os.environ.get('AB_CURVE', '0')))
 ctx.generate_points(n, seed=7)
 dev, _ = ctx.generate_scalars(n, seed=9)
 serial = bool(int(os.environ.get('AB_SERIAL', '0')))
