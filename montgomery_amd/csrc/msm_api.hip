@@ -20,6 +20,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -1049,9 +1050,10 @@ void upload_staged(msm_ctx* ctx, void* dst, const void* src, size_t bytes) {
   const size_t n_chunks = (bytes + CH - 1) / CH;
   hipError_t rc[T];
   std::vector<std::thread> th;
+  th.reserve(T);
+  for (int t = 0; t < T; t++) rc[t] = hipSuccess;
   for (int t = 0; t < T; t++) {
-    rc[t] = hipSuccess;
-    th.emplace_back([&, t] {
+    auto job = [&, t] {
       hipError_t e = hipSetDevice(ctx->device);
       size_t turn = 0;
       for (size_t i = t; i < n_chunks && e == hipSuccess; i += T, turn++) {
@@ -1066,7 +1068,9 @@ void upload_staged(msm_ctx* ctx, void* dst, const void* src, size_t bytes) {
       }
       if (e == hipSuccess) e = hipEventRecord(ctx->stage_ev[t][S], ctx->stage_stream[t]);
       rc[t] = e;
-    });
+    };
+    // a thread that cannot be started (resource limits) must not leave joinable threads behind: its share runs here
+    try { th.emplace_back(job); } catch (const std::system_error&) { job(); }
   }
   for (auto& x : th) x.join();
   for (int t = 0; t < T; t++) HIPCHK(rc[t]);
