@@ -58,5 +58,8 @@ export function compute_msm(
   inputPoints: { x: bigint; y: bigint; isZero?: boolean }[] | Uint8Array,
   inputScalars: bigint[] | Uint8Array
 ): Promise<{ x: bigint; y: bigint }>;
+/** src/parallel.ts:291-320: no-ops here (the GPU grid is the worker pool); kept so that the reference's call sites run unchanged */
+export function startThreads(n?: number): Promise<void>;
+export function stopThreads(): Promise<void>;
 export function leBytesToBigint(buf: Uint8Array): bigint;
 export function bigintToLeBytes(x: bigint, n: number): Buffer;

@@ -126,4 +126,10 @@ async function compute_msm_on(curve, coordBytes, inputPoints, inputScalars) {
   }
 }
 
-module.exports = { hip, Weierstrass, TwistedEdwards, bls12377Params, bls12381Params, pallasParams, edOnBls12377Params, compute_msm_on, compute_msm: compute_msm_on, leBytesToBigint, bigintToLeBytes };
+// `startThreads(n)` / `stopThreads()` of src/parallel.ts:291-320 -- the reference's callers bracket every MSM with them
+// (scripts/msm-weierstrass.ts:14,50, src/msm.test.ts:23,33).  The worker pool they manage is replaced by the GPU grid, which
+// needs no start-up: both resolve at once.  `n` is accepted and ignored (it sized the pool and the memory segmentation).
+async function startThreads(_n) {}
+async function stopThreads() {}
+
+module.exports = { hip, startThreads, stopThreads, Weierstrass, TwistedEdwards, bls12377Params, bls12381Params, pallasParams, edOnBls12377Params, compute_msm_on, compute_msm: compute_msm_on, leBytesToBigint, bigintToLeBytes };

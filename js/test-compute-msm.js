@@ -10,6 +10,7 @@ const subEd = require("./submission.js");
 function assert(c, msg) { if (!c) { console.error("FAILED: " + msg); process.exit(1); } }
 
 async function main() {
+  await M.startThreads(16);   // the reference's call sites bracket their MSMs with these (scripts/msm-weierstrass.ts:14,50)
   // --- BLS12-377 G1 (submission-test-bls377.ts:6-45)
   const bls = M.Weierstrass.create(M.bls12377Params);
   const point = {
@@ -115,6 +116,7 @@ async function main() {
     console.log(params.label, "ok:", g.msm.length, "golden cases + generated 2^12");
     cv.close();
   }
+  await M.stopThreads();
   console.log("ALL OK");
 }
 main().catch((e) => { console.error(e); process.exit(1); });

@@ -11,5 +11,7 @@ from .api import (  # noqa: F401
     compute_msm,
     compute_msm_ed,
     create_weierstrass,
+    startThreads,
+    stopThreads,
 )
 from ._lib import MsmError  # noqa: F401

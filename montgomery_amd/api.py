@@ -635,6 +635,15 @@ class _LazyCurve:
         return getattr(self._get(), name)
 
 
+def startThreads(n: Optional[int] = None) -> None:
+    """`startThreads(n)` of src/parallel.ts:291-309, which the reference's callers run before any MSM
+    (scripts/msm-weierstrass.ts:14, src/msm.test.ts:23).  The worker pool it starts is replaced by the GPU grid: nothing to do."""
+
+
+def stopThreads() -> None:
+    """`stopThreads()` of src/parallel.ts:317-320: nothing to stop (contexts are closed through their curve objects)."""
+
+
 BLS12377 = _LazyCurve(BLS12_377_PARAMS)
 BLS12381 = _LazyCurve(BLS12_381_PARAMS)  # src/concrete/bls12-381.ts
 

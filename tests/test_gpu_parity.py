@@ -351,8 +351,10 @@ def test_msm_large_linearity(gpu_ctx):
 
 def test_reference_shaped_api(gpu_ctx):
     """`Weierstraß.create(...).Parallel.msm` / `compute_msm` facade (src/parallel.ts, submission-bls377.ts)."""
+    from montgomery_amd import startThreads, stopThreads
     from montgomery_amd.api import BLS12_377_PARAMS, Weierstrass, compute_msm
 
+    startThreads(16)   # the reference's callers bracket their MSMs with these (scripts/msm-weierstrass.ts:14,50): no-ops here
     cv = Weierstrass.create(BLS12_377_PARAMS)
     pts, _ = O.random_points_bls377("gpu/api", 50)
     sc = O.prng_ints("gpu/api/s", 50, C.q)
@@ -369,6 +371,7 @@ def test_reference_shaped_api(gpu_ctx):
     r = compute_msm(O.points_to_bytes([P, P], 48), O.scalars_to_bytes([2, C.q - 1]), curve=cv)
     assert (r["x"], r["y"]) == P
     cv.context.close()
+    stopThreads()
 
 
 def test_config1_inputs_2p14_on_gpu(gpu_ctx):
