@@ -39,6 +39,8 @@ export interface Curve {
 /** device: a GPU index, or a list of indices: one curve object over several GPUs of the node (windows sharded inside the library) */
 export const Weierstrass: { create(params: CurveParams, device?: number | number[]): Curve };
 export const TwistedEdwards: { create(params: CurveParams, device?: number | number[]): Curve };
+/** the reference's spelling (src/parallel.ts:40) */
+export const Weierstraß: typeof Weierstrass;
 export const bls12377Params: CurveParams;
 export const bls12381Params: CurveParams;
 export const pallasParams: CurveParams;

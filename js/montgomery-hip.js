@@ -132,4 +132,4 @@ async function compute_msm_on(curve, coordBytes, inputPoints, inputScalars) {
 async function startThreads(_n) {}
 async function stopThreads() {}
 
-module.exports = { hip, startThreads, stopThreads, Weierstrass, TwistedEdwards, bls12377Params, bls12381Params, pallasParams, edOnBls12377Params, compute_msm_on, compute_msm: compute_msm_on, leBytesToBigint, bigintToLeBytes };
+module.exports = { hip, startThreads, stopThreads, Weierstrass, Weierstraß: Weierstrass /* the reference's spelling, src/parallel.ts:40 */, TwistedEdwards, bls12377Params, bls12381Params, pallasParams, edOnBls12377Params, compute_msm_on, compute_msm: compute_msm_on, leBytesToBigint, bigintToLeBytes };

@@ -635,6 +635,9 @@ class _LazyCurve:
         return getattr(self._get(), name)
 
 
+Weierstraß = Weierstrass   # the reference's spelling, src/parallel.ts:40
+
+
 def startThreads(n: Optional[int] = None) -> None:
     """`startThreads(n)` of src/parallel.ts:291-309, which the reference's callers run before any MSM
     (scripts/msm-weierstrass.ts:14, src/msm.test.ts:23).  The worker pool it starts is replaced by the GPU grid: nothing to do."""
