@@ -30,9 +30,18 @@ export interface Parallel {
   msmProjective(scalarPtr: ScalarPtr, pointPtr: PointPtr, N: number, options?: MsmOptions): Promise<MsmOutput>;
 }
 
+/** opaque stand-in for a wasm pointer of the reference (`Field.getPointer(size)`) */
+export type ValuePtr = { size: number; value: AffineResult | null };
 export interface Curve {
   params: CurveParams;
   Parallel: Parallel;
+  /** the reference's way from `result` to bigints (scripts/msm-weierstrass.ts:89-91); values are already affine here */
+  Field: { getPointer(size: number): ValuePtr; getPointers(n: number, size: number): ValuePtr[] };
+  Affine: { size: number; toBigint(ptr: ValuePtr | AffineResult): AffineResult };
+  Projective: { size: number; toAffine(scratch: unknown, affinePtr: ValuePtr, result: AffineResult): void };
+  /** twisted Edwards call sites (scripts/msm-twisted-edwards.ts:87, scripts/zprize23/submission.ts:33-34) */
+  Curve: { toBigint(result: AffineResult | ValuePtr): { X: bigint; Y: bigint; Z: bigint; T: bigint } };
+  Bigint: { toAffine(P: { X: bigint; Y: bigint; Z: bigint }): { x: bigint; y: bigint } };
   close(): void;
 }
 

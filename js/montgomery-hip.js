@@ -90,7 +90,26 @@ function createCurve(params, curveId, coordBytes, device, wireBytes) {
       return Parallel.msm(scalarPtr, pointPtr, N, verboseTiming, options);   // the GPU kernels always handle the edge cases
     },
   };
-  return { params, Parallel, close() { hip.destroyContext(ctx); } };
+  // What the reference's callers do with `result` (scripts/msm-weierstrass.ts:89-91):
+  //     let sAffinePtr = Curve.Field.getPointer(Curve.Affine.size);
+  //     Curve.Projective.toAffine(scratch, sAffinePtr, result);
+  //     let s = Curve.Affine.toBigint(sAffinePtr);
+  // There `result` points at a projective point in wasm memory; here the library has already normalised it, so the three
+  // calls only hand the value through: pointers are small objects, toAffine stores, toBigint returns {x, y, isZero}.
+  const newPtr = (size) => ({ size, value: null });
+  const Field = { getPointer: newPtr, getPointers(n, size) { return Array.from({ length: n }, () => newPtr(size)); } };
+  const toBigint = (ptr) => { const r = (ptr && ptr.value) || ptr; return { x: r.x, y: r.y, isZero: !!r.isZero }; };
+  const Affine = { size: 2 * wireBytes + 4, toBigint };                                   // src/curve-affine.ts:77, 220-233
+  const Projective = { size: 3 * wireBytes + 4, toAffine(_scratch, affinePtr, result) { affinePtr.value = toBigint(result); } };   // src/curve-projective.ts:335-349
+  // twisted Edwards callers: `Curve.Curve.toBigint(result)` -> extended bigint point, `Curve.Bigint.toAffine(P)` -> {x, y}
+  // (scripts/msm-twisted-edwards.ts:87, scripts/zprize23/submission.ts:33-34)
+  const P_MOD = params.modulus;
+  const modInv = (a) => { let [r0, r1, s0, s1] = [((a % P_MOD) + P_MOD) % P_MOD, P_MOD, BigInt(1), BigInt(0)];
+    while (r1 !== BigInt(0)) { const q = r0 / r1; [r0, r1] = [r1, r0 - q * r1]; [s0, s1] = [s1, s0 - q * s1]; }
+    return ((s0 % P_MOD) + P_MOD) % P_MOD; };
+  const Curve = { toBigint(result) { const r = toBigint(result); return { X: r.x, Y: r.y, Z: BigInt(1), T: (r.x * r.y) % P_MOD }; } };
+  const Bigint = { toAffine(P) { const zi = modInv(P.Z); return { x: (P.X * zi) % P_MOD, y: (P.Y * zi) % P_MOD }; } };
+  return { params, Parallel, Field, Affine, Projective, Curve, Bigint, close() { hip.destroyContext(ctx); } };
 }
 
 const weierstrassIds = { "bls12-377": hip.CURVE_BLS12_377_G1, "bls12-381": hip.CURVE_BLS12_381_G1, "pallas": hip.CURVE_PALLAS };

@@ -46,6 +46,11 @@ async function main() {
     if (c.result === null) assert(result.isZero, c.name + " should be the identity");
     else assert(!result.isZero && result.x === BigInt(c.result[0]) && result.y === BigInt(c.result[1]), "golden " + c.name);
     assert(log.length > 0, "log");
+    // the reference's own way from `result` to bigints (scripts/msm-weierstrass.ts:89-91)
+    const scratch = bls.Field.getPointers(20, 48), sAffinePtr = bls.Field.getPointer(bls.Affine.size);
+    bls.Projective.toAffine(scratch, sAffinePtr, result);
+    const s = bls.Affine.toBigint(sAffinePtr);
+    assert(s.isZero === result.isZero && s.x === result.x && s.y === result.y, "Projective.toAffine / Affine.toBigint " + c.name);
   }
   console.log("golden bls12-377 ok:", gold.cases.length, "cases");
   {
@@ -84,6 +89,17 @@ async function main() {
   for (const c of goldEd.cases) {
     const rr = await M.compute_msm(ed, 32, Buffer.from(c.points, "hex"), Buffer.from(c.scalars, "hex"));
     assert(rr.x === BigInt(c.result[0]) && rr.y === BigInt(c.result[1]), "golden ed " + c.name);
+  }
+  {
+    // the reference's way from `result` to affine bigints on this curve (scripts/zprize23/submission.ts:33-34)
+    const c = goldEd.cases[0], pts = Buffer.from(c.points, "hex"), sc = Buffer.from(c.scalars, "hex");
+    const pp = ed.Parallel.getPointer(pts.length), sp = ed.Parallel.getScalarPointer(sc.length);
+    await ed.Parallel.pointsFromBytes(pp, pts, c.n);
+    await ed.Parallel.scalarsFromBytes(sp, sc, c.n);
+    const { result } = await ed.Parallel.msm(sp, pp, c.n);
+    const big = ed.Curve.toBigint(result), aff = ed.Bigint.toAffine(big);
+    assert(aff.x === BigInt(c.result[0]) && aff.y === BigInt(c.result[1]) && big.T === (big.X * big.Y) % M.edOnBls12377Params.modulus, "Curve.toBigint / Bigint.toAffine");
+    pp.free();
   }
   console.log("ed-on-bls12-377 ok");
   ed.close();

@@ -580,6 +580,74 @@ class _Parallel:
         return self.msm(scalarPtr, pointPtr, N, verboseTiming, options)
 
 
+class _ValuePtr:
+    """Stand-in for a wasm pointer of the reference (`Field.getPointer(size)`): holds the value written through it."""
+
+    def __init__(self, size: int = 0):
+        self.size, self.value = size, None
+
+
+class _FieldShim:
+    """`Curve.Field.getPointer / getPointers` as the reference's callers use them around an MSM."""
+
+    @staticmethod
+    def getPointer(size: int = 0) -> _ValuePtr:
+        return _ValuePtr(size)
+
+    @staticmethod
+    def getPointers(n: int, size: int = 0) -> List[_ValuePtr]:
+        return [_ValuePtr(size) for _ in range(n)]
+
+
+class _AffineShim:
+    """`Curve.Affine.toBigint(ptr)` (src/curve-affine.ts:220-233) -> {"x", "y", "isZero"}; the value behind the pointer is
+    already canonical affine here."""
+
+    def __init__(self, coord_bytes: int):
+        self.size = 2 * coord_bytes + 4
+
+    @staticmethod
+    def toBigint(ptr) -> Dict:
+        r = ptr.value if isinstance(ptr, _ValuePtr) else ptr
+        return {"x": r.x, "y": r.y, "isZero": bool(r.isZero)}
+
+
+class _ProjectiveShim:
+    """`Curve.Projective.toAffine(scratch, affinePtr, result)` (src/curve-projective.ts:335-349): the reference's callers pass
+    the `result` of `Parallel.msm` through it (scripts/msm-weierstrass.ts:89-91).  The library has normalised the sum already,
+    so this only stores it behind the pointer."""
+
+    def __init__(self, coord_bytes: int):
+        self.size = 3 * coord_bytes + 4
+
+    @staticmethod
+    def toAffine(_scratch, affinePtr: _ValuePtr, result: AffineResult) -> None:
+        affinePtr.value = result
+
+
+class _TeCurveShim:
+    """`Curve.Curve.toBigint(result)` of the twisted-Edwards module -> extended point {"X", "Y", "Z", "T"}
+    (scripts/msm-twisted-edwards.ts:87, scripts/zprize23/submission.ts:33)."""
+
+    def __init__(self, p: int):
+        self.p = p
+
+    def toBigint(self, result) -> Dict:
+        r = result.value if isinstance(result, _ValuePtr) else result
+        return {"X": r.x, "Y": r.y, "Z": 1, "T": r.x * r.y % self.p}
+
+
+class _TeBigintShim:
+    """`Curve.Bigint.toAffine(P)` (src/bigint/twisted-edwards.ts): {"X", "Y", "Z", ...} -> {"x", "y"}."""
+
+    def __init__(self, p: int):
+        self.p = p
+
+    def toAffine(self, P: Dict) -> Dict:
+        zi = pow(P["Z"], -1, self.p)
+        return {"x": P["X"] * zi % self.p, "y": P["Y"] * zi % self.p}
+
+
 class Weierstrass:
     """Curve module as `Weierstraß.create(params)` returns it (src/parallel.ts:147-160), MSM path only."""
 
@@ -592,6 +660,9 @@ class Weierstrass:
         self.params = params
         self.context = MsmContext(_WEIERSTRASS_CURVE_IDS[params.label], device, devices=devices)
         self.Parallel = _Parallel(self.context, params)
+        self.Field = _FieldShim()
+        self.Affine = _AffineShim(self.context.coord_bytes)
+        self.Projective = _ProjectiveShim(self.context.coord_bytes)
 
     @classmethod
     def create(cls, params: WeierstrassParams, device: int = 0, devices: Optional[Sequence[int]] = None) -> "Weierstrass":
@@ -613,6 +684,9 @@ class TwistedEdwards:
         self.params = params
         self.context = MsmContext(_lib.CURVE_ED_ON_BLS12_377, device, devices=devices)
         self.Parallel = _Parallel(self.context, params)
+        self.Field = _FieldShim()
+        self.Curve = _TeCurveShim(params.modulus)
+        self.Bigint = _TeBigintShim(params.modulus)
 
     @classmethod
     def create(cls, params: TwistedEdwardsParams, device: int = 0, devices: Optional[Sequence[int]] = None) -> "TwistedEdwards":

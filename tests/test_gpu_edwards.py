@@ -222,4 +222,9 @@ def test_reference_shaped_api():
     par.scalarsFromBytes(sp, O.scalars_to_bytes(sc), 30)
     out = par.msm(sp, pp, 30, True, {"c": 6})
     assert (out["result"].x, out["result"].y) == O.msm_basic_te(sc, pts, c=6)
+    # the reference's way from `result` to affine bigints on this curve (scripts/zprize23/submission.ts:33-34)
+    big = cv.Curve.toBigint(out["result"])
+    assert big["Z"] == 1 and big["T"] == big["X"] * big["Y"] % E.p
+    aff = cv.Bigint.toAffine({k: v * 5 % E.p for k, v in big.items()})   # any projective representative
+    assert (aff["x"], aff["y"]) == O.msm_basic_te(sc, pts, c=6)
     cv.context.close()

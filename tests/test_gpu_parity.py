@@ -365,6 +365,11 @@ def test_reference_shaped_api(gpu_ctx):
     out = par.msmUnsafe(sp, pp, 50, True, {"c": 6})
     exp = O.msm_batched_affine(sc, pts, c=6)
     assert out["result"].as_tuple() == exp and out["log"]
+    # the reference's own way from `result` to bigints (scripts/msm-weierstrass.ts:89-91)
+    scratch, sAffinePtr = cv.Field.getPointers(20), cv.Field.getPointer(cv.Affine.size)
+    cv.Projective.toAffine(scratch, sAffinePtr, out["result"])
+    s = cv.Affine.toBigint(sAffinePtr)
+    assert (s["x"], s["y"]) == exp and s["isZero"] is False
     r = compute_msm([{"x": x, "y": y, "isZero": False} for x, y in pts], sc, curve=cv)
     assert (r["x"], r["y"]) == exp
     P = O.ZPRIZE_BLS377_POINT
