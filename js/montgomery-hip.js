@@ -46,6 +46,9 @@ function createCurve(params, curveId, coordBytes, device, wireBytes) {
   wireBytes = wireBytes || coordBytes;   // the reference's packed coordinate size = the C ABI's: 48, or 32 for the 255-bit fields
   const ctx = hip.createContext(curveId, device || 0);   // device: an index, or a list of indices (one context over several GPUs)
   const pointBytes = 2 * coordBytes;
+  // `let [pointPtr] = await Parallel.randomPointsFast(N)` -- the reference hands back one pointer per point / scalar and its
+  // callers keep the first (scripts/msm-weierstrass.ts:18,21,29); a handle here stands for the whole array, so it unpacks to itself
+  const firstOf = (ptr) => { ptr[Symbol.iterator] = function* () { yield ptr; }; return ptr; };
   const Parallel = {
     // every point pointer is its own resident point set of the context, as every pointer of the reference is its own
     // allocation; msm() selects the set of the pointer it is given
@@ -68,10 +71,10 @@ function createCurve(params, curveId, coordBytes, device, wireBytes) {
     async randomPointsFast(n, options) {   // src/curve-random.ts:14-92; generated on the GPU, explicit seed
       const pointPtr = Parallel.getPointer(n * 2 * wireBytes);
       pointPtr.n = hip.generatePoints(ctx, n, (options && options.seed) || 1);
-      return pointPtr;
+      return firstOf(pointPtr);
     },
     async randomScalars(n, options) {      // src/curve-random.ts:151-194
-      return { size: n * 32, bytes: hip.generateScalars(ctx, n, (options && options.seed) || 1), n };
+      return firstOf({ size: n * 32, bytes: hip.generateScalars(ctx, n, (options && options.seed) || 1), n });
     },
     async msm(scalarPtr, pointPtr, N, verboseTiming, options) {
       const c = (options && options.c) || 0;

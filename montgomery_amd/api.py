@@ -454,6 +454,11 @@ class PointPtr:
         if ctx is not None and self.set_id > 0 and getattr(ctx, "_h", None):
             ctx.pointset_destroy(self.set_id)
 
+    def __iter__(self):
+        """`[pointPtr] = Parallel.randomPointsFast(N)`: the reference returns one pointer per point and its callers keep the first
+        (scripts/msm-weierstrass.ts:18); a handle here stands for the whole array and unpacks to itself."""
+        yield self
+
     def __enter__(self) -> "PointPtr":
         return self
 
@@ -479,6 +484,10 @@ class ScalarPtr:
         if ctx is not None and self.dev_ptr and getattr(ctx, "_h", None):
             ctx.device_free(self.dev_ptr)
         self.dev_ptr = 0
+
+    def __iter__(self):
+        """`[scalarPtr] = Parallel.randomScalars(N)` (scripts/msm-weierstrass.ts:21,29): unpacks to itself."""
+        yield self
 
     def __enter__(self) -> "ScalarPtr":
         return self

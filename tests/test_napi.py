@@ -50,6 +50,18 @@ def test_js_facade_on_gpu(addon):
 
 
 @pytest.mark.gpu
+def test_js_benchmark_with_the_reference_protocol(addon):
+    """js/bench-msm.js: the call sequence of scripts/msm-weierstrass.ts:12-51 on this facade, unchanged call by call
+    (startThreads, `let [ptr] = await randomPointsFast(N)`, 15 runs of msmUnsafe, Projective.toAffine / Affine.toBigint)."""
+    import json
+
+    out = subprocess.run([NODE, "js/bench-msm.js", "14"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["consistent"] and rep["runs"] == 10 and rep["n"] == 14 and rep["median_ms"] > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("curve", [0, 1, 2, 3])
 def test_plain_c_host_of_the_abi(curve):
     """examples/msm_demo.c: a C program on the C ABI alone (what a cgo / JNI binding would do): generates inputs on
