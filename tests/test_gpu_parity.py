@@ -375,6 +375,10 @@ def test_reference_shaped_api(gpu_ctx):
     P = O.ZPRIZE_BLS377_POINT
     r = compute_msm(O.points_to_bytes([P, P], 48), O.scalars_to_bytes([2, C.q - 1]), curve=cv)
     assert (r["x"], r["y"]) == P
+    # `let [pointPtr] = await Parallel.randomPointsFast(N)` (scripts/msm-weierstrass.ts:18,21): handles unpack to themselves
+    [rp] = par.randomPointsFast(300, seed=3)
+    [rs] = par.randomScalars(300, seed=4)
+    assert par.msmUnsafe(rs, rp, 300)["result"].as_tuple() == par.msmProjective(rs, rp, 300)["result"].as_tuple() is not None
     cv.context.close()
     stopThreads()
 
