@@ -40,6 +40,7 @@ async function benchmarkMsm(params, n) {
   const other = Curve.Affine.toBigint((await Parallel.msmProjective(scalarPtr, pointPtr, N)).result);
   if (s.isZero !== other.isZero || s.x !== other.x || s.y !== other.y) throw new Error("msm and msmProjective disagree");
   log.forEach((l) => console.log(...l));
+  console.log(times.map((t) => +t.toFixed(2)));
   const out = { curve: params.label, n, median_ms: median(times), std_ms: sampleStd(times), points_per_s: N / (median(times) * 1e-3), runs: times.length, consistent: true };
   console.log(`msm (n=${n})... ${out.median_ms.toFixed(2)}ms ± ${out.std_ms.toFixed(2)}ms`);
   console.log(JSON.stringify(out));

@@ -155,13 +155,14 @@ def test_combine_host_edwards():
 
 
 @pytest.mark.timeout(300)
-def test_sharded_msm_world2_gloo():
+@pytest.mark.parametrize("world", [2, 3])   # 3: windows and points that do not divide evenly, a rank without points
+def test_sharded_msm_gloo(world):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = q.get(timeout=240)
