@@ -1143,7 +1143,14 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
         groups.push_back({k, k + 1, lo, hi - lo});
       }
   } else {
-    for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg), 0, n});
+    long long first_group = 0;   // experiment: windows in the first of two uneven groups
+    MSM_KNOB(first_group, "MSM_WPG_A", 1);
+    if (first_group > 0 && first_group < nwin) {
+      groups.push_back({k_lo, k_lo + (int)first_group, 0, n});
+      groups.push_back({k_lo + (int)first_group, k_hi, 0, n});
+    } else {
+      for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg), 0, n});
+    }
   }
   std::vector<std::vector<uint32_t>> split_part(split_points ? groups.size() : 0);
   HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
