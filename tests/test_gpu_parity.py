@@ -427,6 +427,9 @@ def test_big_windows_chunk_ordered_round1(gpu_ctx, c_oracle, c):
     assert res.as_tuple() == O.aff_scale(k, (C.gx, C.gy), P_MOD), info
     res16, _ = gpu_ctx.run_device(dev, n)
     assert res16.as_tuple() == res.as_tuple()
+    if c == 20:   # msmProjective's window structure (whole 253-bit scalars, no endomorphism: K = 13) through the same path
+        resp, infop = gpu_ctx.run_device(dev, n, c=c, no_glv=True)
+        assert infop["K"] == 13 and resp.as_tuple() == res.as_tuple()
 
 
 def test_skewed_buckets_tail_rounds(gpu_ctx, c_oracle):
