@@ -105,3 +105,34 @@ def test_two_contexts_from_two_threads():
     finally:
         for ctx, *_ in ctxs:
             ctx.close()
+
+
+def test_degenerate_inputs_through_the_big_window_paths():
+    """2^23 copies of one point, then P and -P alternating, at c = 22: every pair of the tree is a doubling or a cancellation,
+    and it goes through the three-pass sort, the chunk-ordered round 1 and the element records.  Expected: (sum of the signed
+    scalars) P."""
+    import numpy as np
+
+    from montgomery_amd.api import MsmContext
+
+    C = O.BLS12_377
+    P = O.ZPRIZE_BLS377_POINT
+    n = 1 << 23
+    rng = np.random.default_rng(23)
+    sc = rng.integers(0, 256, size=n * 32, dtype=np.uint8)
+    sc[31::32] &= 0x0F                                           # < 2^252 < q
+    cols = sc.reshape(n, 32).astype(np.int64)
+
+    def scalar_sum(signs=None):
+        m = cols if signs is None else cols * signs[:, None]
+        return sum(int(m[:, j].sum()) << (8 * j) for j in range(32))
+
+    ctx = MsmContext()
+    try:
+        for pts, signs in (([P, P], None), ([P, O.aff_neg(P, C.p)], np.tile(np.array([1, -1], dtype=np.int64), n // 2))):
+            ctx.set_points(O.points_to_bytes(pts, 48) * (n // 2))
+            k = scalar_sum(signs) % C.q
+            res, info = ctx.run(sc.tobytes(), c=22)
+            assert info["c"] == 22 and res.as_tuple() == (O.aff_scale(k, P, C.p) if k else None), info
+    finally:
+        ctx.close()
