@@ -5,13 +5,15 @@
 
 One "step" = one MSM over resident base points with FRESH scalars already in HBM (the reference's
 protocol: points pre-loaded, new random scalars every run, scripts/msm-weierstrass.ts:12-51).
-N = 1: the whole MSM on one GPU.  N > 1 (launched by torch.distributed.run, one rank per GPU): the
-same MSM sharded across the ranks -- `--split windows`: by scalar window (every rank holds all points and
-scalars and computes the window sums P_k of its windows); `--split points`: every rank runs all K windows
-on its share of the points and needs only that share of the scalars; `auto` takes the one the single-GPU
-proxy (tools/shard_time.py) times faster.  Either way ONE RCCL all-gather of K x 144
-bytes per rank, rank 0 does the Horner combination.  Total work is fixed as N grows:
-scaling = "strong".
+N = 1: the whole MSM on one GPU.  N > 1, one rank per GPU: the same MSM sharded across the ranks.  The headline is
+`--split windows` (BASELINE configs[4], the north star: every rank holds all points and scalars and computes the
+window sums P_k of its windows; windows are independent until src/msm-batched-affine.ts:312-333); the other split
+(`points`: every rank runs all K windows on its share of the points and needs only that share of the scalars) is
+timed by the same run and reported as `other_splits`.  Either way ONE RCCL all-gather of K x 144 bytes per rank,
+rank 0 does the Horner combination.  Total work is fixed as N grows: scaling = "strong".
+Launch: under torch.distributed.run (the driver's form: WORLD_SIZE must equal --gpus, anything else is an error),
+or plainly as `python bench.py --gpus N`: the script then starts the N ranks itself, as fresh child processes of
+torch.distributed.run, BEFORE it imports torch or touches the GPU, relays their output and exits with their code.
 
 Prints ONE JSON line on rank 0 with the driver's contract plus
   `roofline`      dominant kernel k_batch_add, HIP-event timed inside the library on its own stream,
@@ -239,6 +241,24 @@ def bench_ed377(args, torch):
         sys.exit("bench: the Edwards MSM result failed the known-discrete-log check")
 
 
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: N fresh ranks under torch.distributed.run (the driver's own command
+    line), started before this process has imported torch or made any HIP call -- a process that has initialised the GPU
+    must not be replaced or forked into ranks.  The children inherit stdout / stderr, so rank 0's JSON line is this
+    command's JSON line; returns their exit code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,13 +271,22 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the known-discrete-log check of the last timed result")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the in-process runs of BASELINE configs[1] (2^20 BLS12-377) and configs[3] (2^20 Ed-on-BLS12-377)")
-    ap.add_argument("--split", choices=["auto", "windows", "points"], default="auto",
-                    help="N > 1: shard the MSM by scalar window or by points (auto: montgomery_amd.distributed.choose_split)")
+    ap.add_argument("--split", choices=["auto", "windows", "points"], default="windows",
+                    help="N > 1: the headline sharding -- by scalar window (default: BASELINE configs[4]) or by points; "
+                         "auto = montgomery_amd.distributed.choose_split.  The other one is timed too (other_splits)")
+    ap.add_argument("--no-other-splits", action="store_true", help="N > 1: time the headline split only")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (functional check of the sharded path on one GPU)")
     ap.add_argument("--curve", choices=["bls12-377", "bls12-381", "ed377"], default="bls12-377",
                     help="ed377 = BASELINE configs[3]: twisted Edwards msmBasic path (single GPU, use --log2n 20); "
                          "bls12-381 = the same batched-affine path over the BLS12-381 G1 constants (no CPU baseline leg)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))       # nothing has touched the GPU yet: torch is not even imported
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"bench: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: refusing to measure a different job "
+                 f"than the one asked for (launch with --nproc-per-node {args.gpus}, or without a launcher)")
 
     import torch
 
@@ -269,7 +298,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if local_rank >= torch.cuda.device_count():   # several ranks on one GPU: only meaningful with --dist-backend gloo
+        if local_rank >= torch.cuda.device_count():   # several ranks on one GPU: a functional check only, and only over gloo
+            if args.dist_backend == "nccl":
+                sys.exit(f"bench: rank {rank} has no GPU of its own ({torch.cuda.device_count()} visible, {world} ranks): RCCL "
+                         "needs one device per rank (use --dist-backend gloo for a functional run on fewer GPUs)")
             local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
@@ -278,8 +310,6 @@ def main():
             dist.init_process_group(backend=args.dist_backend)
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     from montgomery_amd.api import AffineResult, MsmContext
     from montgomery_amd.distributed import choose_split, point_shards, sharded_msm, sharded_msm_points, window_shards
@@ -306,11 +336,17 @@ def main():
     for i, t in enumerate(scal):
         ctx.generate_scalars(n, seed=1000 + i, into=t.data_ptr())
 
-    def step(i):
+    ddev = dev if args.dist_backend == "nccl" else "cpu"
+    exchange = None
+    if world > 1:
+        from montgomery_amd.distributed import PARTIAL_BYTES, ShardExchange
+
+        exchange = ShardExchange(PARTIAL_BYTES * K, ddev)   # one pinned row + device twin + gathered tensor for every step
+
+    def step(i, how):
         if world == 1:
             return ctx.run_device(scal[i % n_sets].data_ptr(), n, c=c)
         box = {}
-        ddev = dev if args.dist_backend == "nccl" else "cpu"
 
         def my_window_sums(lo, hi):
             parts, box["info"] = ctx.window_sums(scal[i % n_sets].data_ptr(), n, lo, hi, c=c, on_device=True)
@@ -322,10 +358,10 @@ def main():
             return parts
 
         tm = {}
-        if split == "points":
-            out = sharded_msm_points(my_point_sums, n, K, c, device=ddev, curve=ctx.curve, timing=tm)
+        if how == "points":
+            out = sharded_msm_points(my_point_sums, n, K, c, device=ddev, curve=ctx.curve, timing=tm, exchange=exchange)
         else:
-            out = sharded_msm(my_window_sums, K, c, device=ddev, curve=ctx.curve, timing=tm)
+            out = sharded_msm(my_window_sums, K, c, device=ddev, curve=ctx.curve, timing=tm, exchange=exchange)
         if box.get("info") is not None:
             box["info"]["all_gather_ms"] = tm.get("all_gather_ms")
         res = None
@@ -339,38 +375,58 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    sync()
-    t0 = time.perf_counter()
-    infos, step_ms = [], []
-    last, last_set = None, 0
-    for i in range(args.steps):
-        last_set = (args.warmup + i) % n_sets
-        ts = time.perf_counter()
-        last, info = step(args.warmup + i)    # msm_run / the all-gather are synchronous: per-step wall time is meaningful
-        step_ms.append((time.perf_counter() - ts) * 1e3)
-        infos.append(info)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def timed_loop(how):
+        """W untimed + K timed steps of one sharding, bracketed by barrier + device synchronisation; the time is the MAX over
+        the ranks.  Returns (seconds, per-step ms, infos, last result, its scalar set, per-rank summaries)."""
+        for i in range(args.warmup):
+            step(i, how)
+        sync()
+        t0 = time.perf_counter()
+        infos, step_ms = [], []
+        last, last_set = None, 0
+        for i in range(args.steps):
+            last_set = (args.warmup + i) % n_sets
+            ts = time.perf_counter()
+            last, info = step(args.warmup + i, how)    # msm_run / the all-gather are synchronous: per-step wall time is meaningful
+            step_ms.append((time.perf_counter() - ts) * 1e3)
+            infos.append(info)
+        sync()
+        dt = time.perf_counter() - t0
+        ranks_info = None
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=ddev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+            # outside the timed region: what every rank spent where, so that a scaling run explains itself
+            mine = [x for x in infos if x]
+            summary = {"rank": rank, "shard": (list(point_shards(n, world)[rank]) if how == "points" else list(shards[rank])),
+                       "steps_with_work": len(mine)}
+            if mine:
+                summary["phase_ms"] = {k: sum(x["phase_ms"][k] for x in mine) / len(mine) for k in mine[0]["phase_ms"]}
+                ag = [x["all_gather_ms"] for x in mine if x.get("all_gather_ms") is not None]
+                summary["all_gather_ms"] = sum(ag) / len(ag) if ag else None
+                summary["step_ms"] = sum(step_ms) / len(step_ms)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, summary)
+            ranks_info = gathered
+        return dt, step_ms, infos, last, last_set, ranks_info
 
-    ranks_info = None
-    if world > 1:   # outside the timed region: what every rank spent where, so that a scaling run explains itself
-        mine = [x for x in infos if x]
-        summary = {"rank": rank, "shard": (list(point_shards(n, world)[rank]) if split == "points" else list(shards[rank])),
-                   "steps_with_work": len(mine)}
-        if mine:
-            summary["phase_ms"] = {k: sum(x["phase_ms"][k] for x in mine) / len(mine) for k in mine[0]["phase_ms"]}
-            ag = [x["all_gather_ms"] for x in mine if x.get("all_gather_ms") is not None]
-            summary["all_gather_ms"] = sum(ag) / len(ag) if ag else None
-            summary["step_ms"] = sum(step_ms) / len(step_ms)
-        gathered = [None] * world
-        dist.all_gather_object(gathered, summary)
-        ranks_info = gathered
+    def check(last, last_set):
+        """the checker leg (outside every timed region): a result against the known discrete logs of the generated points"""
+        _, s_host = ctx.generate_scalars(n, seed=1000 + last_set, to_host=True, raw=True)   # the same stream, read back
+        exp = expected_from_logs(args.curve, a_host, s_host, n)
+        return bool(last is not None and last.as_tuple() == exp)
+
+    failed = None
+    dt, step_ms, infos, last, last_set, ranks_info = timed_loop(split)
+    other_splits = None
+    if world > 1 and not args.no_other_splits:
+        other = "points" if split == "windows" else "windows"
+        o_dt, o_step_ms, _, o_last, o_set, o_ranks = timed_loop(other)
+        if rank == 0:
+            other_splits = [{"split": other, "value": n * args.steps / o_dt, "unit": "points/s", "ms_per_step": o_dt / args.steps * 1e3,
+                             **step_stats(o_step_ms), "verified": check(o_last, o_set) if verify else None, "ranks": o_ranks}]
+
     if rank == 0:
         infos = [x for x in infos if x]
         acc_ms = sum(x["phase_ms"]["accumulate"] for x in infos)
@@ -379,12 +435,7 @@ def main():
         phase = {k: sum(x["phase_ms"][k] for x in infos) / max(len(infos), 1) for k in infos[0]["phase_ms"]} if infos else {}
         achieved = pairs * PAIR_ALGO_BYTES / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
         # ---- checker leg (outside the timed region): the last timed result against the known discrete logs -------
-        verified = None
-        if verify:
-            _, s_host = ctx.generate_scalars(n, seed=1000 + last_set, to_host=True, raw=True)   # the same stream, read back
-            exp = expected_from_logs(args.curve, a_host, s_host, n)
-            verified = bool(last is not None and last.as_tuple() == exp)
-            del s_host
+        verified = check(last, last_set) if verify else None
         # Big inputs run as two window groups on two streams, so the event-timed launch durations above are those of
         # kernels SHARING the GPU.  One extra, untimed step with the groups serialised gives the exclusive figures.
         excl = None
@@ -488,7 +539,9 @@ def main():
                         "(DESIGN.md section 5)",
             },
             "phase_ms": phase,
+            "split": split,
             "ranks": ranks_info,
+            "other_splits": other_splits,
             "pcie_inclusive": pcie,
             "result_is_infinity": bool(last.isZero) if last is not None else None,
         }
@@ -498,12 +551,14 @@ def main():
             # the other size BASELINE.json's metric names and configs[3], timed by the same process (value stays the headline size)
             out["other_configs"] = [timed_config("bls12-377", 20, torch), timed_config("ed377", 20, torch)]
         print(json.dumps(out), flush=True)
-        if verified is False:
-            sys.exit("bench: the MSM result failed the known-discrete-log check")
+        if verified is False or any(o["verified"] is False for o in (other_splits or [])):
+            failed = "bench: the MSM result failed the known-discrete-log check"
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if failed:
+        sys.exit(failed)
 
 
 if __name__ == "__main__":

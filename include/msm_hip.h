@@ -47,6 +47,15 @@ enum {
                                    * the Edwards curve; window sums stay 144-byte (X, Y, Z) records for every curve */
 };
 
+/* Layout version of this header.  The symbol names do not change when a struct grows or an argument changes meaning, so a
+ * binding built against another version of the header would misread memory silently: msm_abi_version() returns the version the
+ * LIBRARY was built with, msm_abi_struct_bytes(0 / 1) its sizeof(msm_opts) / sizeof(msm_result).  The Python loader and the N-API
+ * addon compare both at load time and refuse a mismatch.  History: 3 = round 3 (msm_generate_scalars writes to a caller-owned
+ * buffer; msm_opts.point_lo / by_window); 4 = msm_result.n_pairs_algo. */
+#define MSM_ABI_VERSION 4
+uint32_t msm_abi_version(void);
+uint32_t msm_abi_struct_bytes(int which);
+
 typedef struct msm_ctx msm_ctx;
 
 /* Options of one msm call; mirrors `{c, useSafeAdditions}` of src/msm-batched-affine.ts:74-77.
@@ -85,8 +94,10 @@ typedef struct msm_result {
   int32_t K;            /* number of windows */
   int32_t rounds;       /* accumulation tree rounds (k_batch_add launches) summed over all window groups */
   float phase_ms[MSM_N_PHASES];
-  uint64_t n_pairs;     /* affine pair additions issued (all rounds, all windows) */
+  uint64_t n_pairs;     /* affine pair additions issued (all rounds, all windows), padding lanes of the tree included */
   uint64_t max_bucket;  /* largest bucket population seen */
+  uint64_t n_pairs_algo; /* pair additions the bucket sums NEED: sum over the non-empty buckets of (population - 1); the
+                            basis of roofline figures (n_pairs is ~2.5 % above it at 2^26) */
 } msm_result;
 
 /* Context: binds one curve to one GPU (device index as seen by HIP). Replaces

@@ -17,6 +17,7 @@ CURVE_BLS12_377_G1 = 0
 CURVE_ED_ON_BLS12_377 = 1
 CURVE_BLS12_381_G1 = 2
 CURVE_PALLAS = 3
+ABI_VERSION = 4   # MSM_ABI_VERSION of the include/msm_hip.h this binding was written against
 N_PHASES = 8
 PHASE_NAMES = ("total", "upload", "digits", "sort", "accumulate", "reduce", "final", "accumulate_round1")
 
@@ -31,6 +32,7 @@ EXPORTS = (
     "msm_device_alloc", "msm_device_free", "msm_device_upload",
     "msm_test_fp_raw", "msm_test_curve_op", "msm_test_batch_add_mode",
     "msm_run_placed", "msm_combine_groups", "msm_test_bucket_reduce", "msm_set_workspace_limit",
+    "msm_abi_version", "msm_abi_struct_bytes",
 )
 
 
@@ -50,6 +52,7 @@ class MsmResult(C.Structure):
         ("phase_ms", C.c_float * N_PHASES),
         ("n_pairs", C.c_uint64),
         ("max_bucket", C.c_uint64),
+        ("n_pairs_algo", C.c_uint64),
     ]
 
 
@@ -71,6 +74,17 @@ def load() -> C.CDLL:
         raise ImportError(f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950); there is no CPU fallback")
     lib = C.CDLL(LIB_PATH)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
+    # a library built from another version of include/msm_hip.h keeps its symbol names but not its struct layouts
+    if not hasattr(lib, "msm_abi_version"):
+        raise ImportError(f"{LIB_PATH} predates msm_abi_version(): rebuild it (`make`)")
+    lib.msm_abi_version.restype = C.c_uint32
+    lib.msm_abi_struct_bytes.argtypes = [C.c_int]
+    lib.msm_abi_struct_bytes.restype = C.c_uint32
+    got = (lib.msm_abi_version(), lib.msm_abi_struct_bytes(0), lib.msm_abi_struct_bytes(1))
+    want = (ABI_VERSION, C.sizeof(MsmOpts), C.sizeof(MsmResult))
+    if got != want:
+        raise ImportError(f"{LIB_PATH}: ABI (version, sizeof msm_opts, sizeof msm_result) = {got}, this binding expects {want}; "
+                          "rebuild the library and the binding from the same include/msm_hip.h")
     lib.msm_ctx_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
     lib.msm_ctx_create.restype = C.c_int
     lib.msm_ctx_destroy.argtypes = [vp]
@@ -107,7 +121,7 @@ def load() -> C.CDLL:
     lib.msm_test_batch_add_mode.argtypes = [vp, vp, vp, vp, u64, C.c_int, C.c_uint32]
     lib.msm_test_bucket_reduce.argtypes = [vp, vp, i32, C.c_uint32, C.c_int, C.c_int, vp, C.POINTER(C.c_float)]
     for name in EXPORTS:
-        if name not in ("msm_ctx_destroy", "msm_last_error"):
+        if name not in ("msm_ctx_destroy", "msm_last_error", "msm_abi_version", "msm_abi_struct_bytes"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

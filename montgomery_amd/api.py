@@ -142,6 +142,7 @@ def _result_to_dict(res: MsmResult) -> Dict:
         "K": res.K,
         "rounds": res.rounds,
         "n_pairs": int(res.n_pairs),
+        "n_pairs_algo": int(res.n_pairs_algo),
         "max_bucket": int(res.max_bucket),
         "phase_ms": {name: float(res.phase_ms[i]) for i, name in enumerate(_lib.PHASE_NAMES)},
     }

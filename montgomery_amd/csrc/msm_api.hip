@@ -43,6 +43,16 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+// a DevBuf local to one call: freed on every way out of the scope, exceptions included
+struct ScopedDevBuf : DevBuf {
+  ScopedDevBuf() = default;
+  ScopedDevBuf(const ScopedDevBuf&) = delete;
+  ScopedDevBuf& operator=(const ScopedDevBuf&) = delete;
+  ~ScopedDevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
 struct HipFail {
   hipError_t e;
   const char* what;
@@ -339,6 +349,7 @@ int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
 
 struct GroupStats {
   uint64_t n_pairs = 0;
+  uint64_t n_pairs_algo = 0;
   uint64_t max_bucket = 0;
   int rounds = 0;
   float ms_digits = 0, ms_sort = 0, ms_acc = 0, ms_red = 0, ms_r1 = 0;
@@ -685,6 +696,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     HIPCHK(hipStreamSynchronize(s));
     total_slots = w.h_info[0];
     max_bucket = w.h_info[1];
+    st.n_pairs_algo += (uint64_t)w.h_info[INFO_ALGO_PAIRS] | ((uint64_t)w.h_info[INFO_ALGO_PAIRS + 1] << 32);
     const uint32_t capmax = (max_bucket + (1u << logG) - 1) >> logG;
     while (RT < 32 && (1u << RT) < capmax) RT++;
   }
@@ -1115,6 +1127,9 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     ctx->ws_budget = (uint64_t)((free_b + held) * 0.85L);
   }
   int wpg = std::min(windows_per_group(ctx, n, pl), 128);
+  // the radix-split and three-pass sorts describe their windows in a WinSplit of 16 entries (sort_kernels.h): a group that
+  // may take one of them holds at most 16 windows (msmProjective with a small explicit window: K = 17 .. 29 at c = 15 .. 9)
+  if (pl.c - 1 > (int)RX_FINE_BITS) wpg = std::min(wpg, 16);
   const int nwin = k_hi - k_lo;
   // measured on MI355X: two groups win 14 % at 2^23 / 2^24, 3 % at 2^22, nothing at 2^21 -- below that the fixed
   // per-group latencies (read-backs, bucket reduction depth) cost more than the overlap returns
@@ -1217,6 +1232,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   }
   for (int i = 0; i < msm_ctx::N_WS; i++) {
     st.n_pairs += sts[i].n_pairs;
+    st.n_pairs_algo += sts[i].n_pairs_algo;
     st.max_bucket = std::max(st.max_bucket, sts[i].max_bucket);
     st.rounds += sts[i].rounds;   // tree rounds (k_batch_add launches) of ALL window groups, like n_pairs and ms_acc
     st.ms_digits += sts[i].ms_digits; st.ms_sort += sts[i].ms_sort; st.ms_acc += sts[i].ms_acc;
@@ -1236,6 +1252,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     stats->phase_ms[MSM_T_ACC_ROUND1] = st.ms_r1;
     stats->phase_ms[MSM_T_REDUCE] = st.ms_red;
     stats->n_pairs = st.n_pairs;
+    stats->n_pairs_algo = st.n_pairs_algo;
     stats->max_bucket = st.max_bucket;
     stats->rounds = st.rounds;
     stats->c = pl.c;
@@ -1250,17 +1267,31 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
 // once more from a clean slate, where the budget model of window_sums_once holds again.
 int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, int k_lo, int k_hi,
                      const Plan& pl, std::vector<uint32_t>& words, msm_result* stats, uint64_t p_off = 0) {
-  try {
-    return window_sums_once(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats, p_off);
-  } catch (const HipFail& f) {
-    if (f.e != hipErrorOutOfMemory) throw;
+  // The budget model is an estimate and other contexts may take memory while the call runs, so one clean-slate retry is not a
+  // guarantee: every further attempt also halves what the workspaces may take (more window groups, then ranges of the points),
+  // which trades time for memory as include/msm_hip.h promises.  The caller's own limit is restored afterwards.
+  const uint64_t limit0 = ctx->ws_limit;
+  for (int attempt = 0;; attempt++) {
+    try {
+      const int rc = window_sums_once(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats, p_off);
+      ctx->ws_limit = limit0;
+      return rc;
+    } catch (const HipFail& f) {
+      if (f.e != hipErrorOutOfMemory || attempt >= 4) {
+        ctx->ws_limit = limit0;
+        throw;
+      }
+    } catch (...) {
+      ctx->ws_limit = limit0;
+      throw;
+    }
+    (void)hipGetLastError();
+    for (auto& w : ctx->ws) {
+      (void)hipStreamSynchronize(w.stream);
+      for (DevBuf* b : w.all) ctx->release(*b);
+    }
+    if (attempt >= 1) ctx->ws_limit = std::max<uint64_t>(ctx->ws_budget / 2, (uint64_t)64 << 20);
   }
-  (void)hipGetLastError();
-  for (auto& w : ctx->ws) {
-    (void)hipStreamSynchronize(w.stream);
-    for (DevBuf* b : w.all) ctx->release(*b);
-  }
-  return window_sums_once(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats, p_off);
 }
 
 // Multi-device context: one MSM over the devices of the list, each from its own host thread on its own context.
@@ -1343,6 +1374,7 @@ int multi_window_sums(msm_ctx* ctx, const void* scalars, const void* const* plac
   if (stats) {
     for (int d = 0; d < ndev; d++) {
       stats->n_pairs += st[d].n_pairs;
+      stats->n_pairs_algo += st[d].n_pairs_algo;
       stats->rounds += st[d].rounds;
       stats->max_bucket = std::max(stats->max_bucket, st[d].max_bucket);
       for (int j = 0; j < MSM_N_PHASES; j++) stats->phase_ms[j] = std::max(stats->phase_ms[j], st[d].phase_ms[j]);
@@ -1392,6 +1424,9 @@ int on_all_devices(msm_ctx* ctx, F f) {
 // =============================================================================================
 
 extern "C" {
+
+uint32_t msm_abi_version(void) { return MSM_ABI_VERSION; }
+uint32_t msm_abi_struct_bytes(int which) { return which == 0 ? (uint32_t)sizeof(msm_opts) : which == 1 ? (uint32_t)sizeof(msm_result) : 0u; }
 
 int msm_ctx_create(msm_ctx** out, int curve, int device) {
   if (!out) return MSM_ERR_ARG;
@@ -2058,7 +2093,7 @@ int msm_test_bucket_reduce(msm_ctx* ctx, const uint8_t* buckets, int32_t K, uint
     hipStream_t s = w.stream;
     const uint64_t nb = (uint64_t)K * L;
     const uint64_t cap = nb + 2 * 257 * 512 + 256;   // plane capacity: idle lanes read (and ignore) past the end
-    DevBuf wire, rows, planes, desc, scr;
+    ScopedDevBuf wire, rows, planes, desc, scr;   // released on every path, a HIPCHK / MsmFail thrown in between included
     const size_t pb = 2 * ctx->coord_bytes();
     const int nw = ctx->nw(), np = nw / 4;
     ctx->ensure(wire, nb * pb);

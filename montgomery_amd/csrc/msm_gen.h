@@ -121,21 +121,34 @@ inline int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_o
       B = C.dbl(B);
       if ((b.v[bit / 64] >> (bit % 64)) & 1) B = C.add(B, G);
     }
+    // the table's multiples, then ONE inversion for all of them (Montgomery's trick; the reference batch-normalises too,
+    // src/curve-random.ts:60-75)
+    std::vector<Proj6> mult(TBL);
+    std::vector<Fe6> pre(TBL);
     Proj6 acc = C.zero();
     U256 sacc = {{0, 0, 0, 0}};
+    Fe6 run = C.F.one;
     for (int t = 0; t < TBL; t++) {
       acc = C.add(acc, B);
       addmod_q(sacc, sacc, b, q);
       tbl_scalar[(size_t)j * TBL + t] = sacc;
+      mult[t] = acc;
+      pre[t] = run;
+      if (!C.is_zero(acc)) C.F.mul(run, run, acc.Z);
+    }
+    Fe6 inv_run;
+    C.F.inv(inv_run, run);
+    for (int t = TBL - 1; t >= 0; t--) {
       Fe6 zi, x, y;
       uint8_t* w = &wire[((size_t)j * TBL + t) * pb];
-      if (C.is_zero(acc)) {
+      if (C.is_zero(mult[t])) {
         memset(w, 0, pb);
         continue;
       }
-      C.F.inv(zi, acc.Z);
-      C.F.mul(x, acc.X, zi);
-      C.F.mul(y, acc.Y, zi);
+      C.F.mul(zi, inv_run, pre[t]);
+      C.F.mul(inv_run, inv_run, mult[t].Z);
+      C.F.mul(x, mult[t].X, zi);
+      C.F.mul(y, mult[t].Y, zi);
       C.F.mul(x, x, one_plain);
       C.F.mul(y, y, one_plain);
       for (size_t i = 0; i < cb / 8; i++)
@@ -145,7 +158,7 @@ inline int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_o
         }
     }
   }
-  DevBuf d_wire, d_tbl;
+  ScopedDevBuf d_wire, d_tbl;   // freed on every path
   ctx->ensure(d_wire, wire.size());
   ctx->ensure(d_tbl, (size_t)N_BASIS * TBL * msm::ROW_WORDS * 4);
   HIPCHK(hipMemcpyAsync(d_wire.p, wire.data(), wire.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -200,16 +213,27 @@ inline int generate_points_te(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* 
       B = C.add(B, B);
       if ((b.v[bit / 64] >> (bit % 64)) & 1) B = C.add(B, G);
     }
+    std::vector<Ext6> mult(TBL);
+    std::vector<Fe6> pre(TBL);
     Ext6 acc = C.zero();
     U256 sacc = {{0, 0, 0, 0}};
-    for (int t = 0; t < TBL; t++) {
+    Fe6 run = C.F.one;
+    for (int t = 0; t < TBL; t++) {   // Z is never zero on the Edwards curve (complete addition law)
       acc = C.add(acc, B);
       addmod_q(sacc, sacc, b, q);
       tbl_scalar[(size_t)j * TBL + t] = sacc;
+      mult[t] = acc;
+      pre[t] = run;
+      C.F.mul(run, run, acc.Z);
+    }
+    Fe6 inv_run;
+    C.F.inv(inv_run, run);
+    for (int t = TBL - 1; t >= 0; t--) {
       Fe6 zi, x, y;
-      C.F.inv(zi, acc.Z);
-      C.F.mul(x, acc.X, zi);
-      C.F.mul(y, acc.Y, zi);
+      C.F.mul(zi, inv_run, pre[t]);
+      C.F.mul(inv_run, inv_run, mult[t].Z);
+      C.F.mul(x, mult[t].X, zi);
+      C.F.mul(y, mult[t].Y, zi);
       C.F.mul(x, x, one_plain);
       C.F.mul(y, y, one_plain);
       uint8_t* w = &wire[((size_t)j * TBL + t) * 64];
@@ -220,7 +244,7 @@ inline int generate_points_te(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* 
         }
     }
   }
-  DevBuf d_wire, d_tbl, d_pts;
+  ScopedDevBuf d_wire, d_tbl, d_pts;
   ctx->ensure(d_wire, wire.size());
   ctx->ensure(d_tbl, (size_t)N_BASIS * TBL * msm::te::TE_ROW_WORDS * 4);
   ctx->ensure(d_pts, std::max<uint64_t>(n, 1) * 64);

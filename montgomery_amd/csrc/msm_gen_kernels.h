@@ -6,7 +6,7 @@
 namespace msm_gen {
 
 constexpr int N_BASIS = 5;
-constexpr int TBL_BITS = 10;
+constexpr int TBL_BITS = 13;   // 5 tables of 2^13 multiples: the reference's defaults, 65 bits of entropy per point (src/curve-random.ts:14-92)
 constexpr int TBL = 1 << TBL_BITS;
 
 __host__ __device__ inline uint64_t mix64(uint64_t seed, uint64_t ctr) {
@@ -42,8 +42,12 @@ struct Q256 {
 
 // ---- points ----------------------------------------------------------------------------------
 
+// index of point i into table j: bits [13 j, 13 j + 13) of a 128-bit draw (two words of the stream)
 __host__ __device__ inline uint32_t table_index(uint64_t seed, uint64_t i, int j) {
-  return (uint32_t)(mix64(seed ^ 0x90117500000000ull, i) >> (TBL_BITS * j)) & (TBL - 1);
+  const uint64_t lo = mix64(seed ^ 0x90117500000000ull, 2 * i), hi = mix64(seed ^ 0x90117500000000ull, 2 * i + 1);
+  const int sh = TBL_BITS * j;
+  const uint64_t v = sh < 64 ? (lo >> sh) | (sh && sh + TBL_BITS > 64 ? hi << (64 - sh) : 0) : hi >> (sh - 64);
+  return (uint32_t)v & (TBL - 1);
 }
 
 // tables: N_BASIS * TBL point rows (x, y used); rows_out: n point rows

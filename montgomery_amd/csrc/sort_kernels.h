@@ -71,15 +71,30 @@ MSM_DEV int pscan_nq(const uint32_t* info, uint32_t logG) {
   return rt + 2;
 }
 
+// info[1] = the largest bucket; info[40..41] (one 64-bit counter) = sum over the non-empty buckets of (size - 1): the pair
+// additions the bucket sums need whatever the tree looks like (msm_result.n_pairs_algo; the tree also issues the additions
+// of its padding lanes, msm_result.n_pairs)
+constexpr int INFO_ALGO_PAIRS = 40;
 __global__ void __launch_bounds__(256) k_bucket_max(const uint32_t* counts, uint32_t nb, uint32_t* info) {
   __shared__ uint32_t lds_max;
-  if (threadIdx.x == 0) lds_max = 0;
+  __shared__ unsigned long long lds_sum;
+  if (threadIdx.x == 0) { lds_max = 0; lds_sum = 0; }
   __syncthreads();
   uint32_t mx = 0;
-  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) mx = max(mx, counts[b]);
+  unsigned long long sum = 0;
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+    const uint32_t cnt = counts[b];
+    mx = max(mx, cnt);
+    sum += cnt ? cnt - 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
   atomicMax(&lds_max, mx);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&lds_sum, sum);
   __syncthreads();
-  if (threadIdx.x == 0) atomicMax(&info[1], lds_max);
+  if (threadIdx.x == 0) {
+    atomicMax(&info[1], lds_max);
+    atomicAdd(reinterpret_cast<unsigned long long*>(info + INFO_ALGO_PAIRS), lds_sum);
+  }
 }
 
 __global__ void __launch_bounds__(PS_BLOCK) k_pscan_partial(const uint32_t* counts, uint32_t nb, uint32_t logG, const uint32_t* info,

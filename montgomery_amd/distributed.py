@@ -80,21 +80,65 @@ def combine_groups_host(partials: bytes, G: int, K: int, c: int, curve: int = _l
     return int.from_bytes(bytes(res.x), "little"), int.from_bytes(bytes(res.y), "little")
 
 
+class ShardExchange:
+    """The one collective of a sharded MSM: every rank contributes `row` bytes, every rank receives world x row bytes.
+    Buffers live as long as the object: a pinned host row, its device twin and the gathered tensor, so that one step is
+    copy-in (asynchronous), all-gather, copy-out with ONE synchronisation at the end (the `.cpu()` of rank 0) instead of a
+    fresh tensor and a blocking copy on either side.  On a CPU process group (gloo) the host row is the collective's operand."""
+
+    def __init__(self, row: int, device="cpu", group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.row = row
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        self.host = torch.zeros(row, dtype=torch.uint8, pin_memory=self.on_gpu)
+        self.dev = torch.zeros(row, dtype=torch.uint8, device=self.device) if self.on_gpu else self.host
+        self.gathered = torch.zeros(self.world * row, dtype=torch.uint8, device=self.device)
+
+    def all_gather(self, mine: bytes, timing: Optional[dict] = None) -> Optional[bytes]:
+        """`mine` (row bytes) from every rank -> world x row bytes on rank 0 (None elsewhere).  timing["all_gather_ms"] is the
+        collective alone: device events around it on a GPU group (read after the step's one synchronisation -- a host
+        clock around the call would only time the enqueue), the host clock on a CPU group, where the call blocks."""
+        import time
+
+        torch = self.torch
+        if len(mine) != self.row:
+            raise MsmError(_lib.MSM_ERR_ARG, f"expected {self.row} bytes for the all-gather, got {len(mine)}")
+        self.host.copy_(torch.frombuffer(bytearray(mine), dtype=torch.uint8))
+        ev = None
+        if self.on_gpu:
+            self.dev.copy_(self.host, non_blocking=True)
+            if timing is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+        t0 = time.perf_counter()
+        self.dist.all_gather_into_tensor(self.gathered, self.dev, group=self.group)
+        if ev:
+            ev[1].record()
+        elif timing is not None:
+            timing["all_gather_ms"] = (time.perf_counter() - t0) * 1e3
+        out = self.gathered.cpu().numpy().tobytes() if self.rank == 0 else None   # rank 0: the step's one blocking copy
+        if ev:
+            ev[1].synchronize()
+            timing["all_gather_ms"] = ev[0].elapsed_time(ev[1])
+        return out
+
+
 def sharded_msm_points(point_sums: Callable[[int, int], bytes], n: int, K: int, c: int, device="cpu", group=None,
-                       curve: int = _lib.CURVE_BLS12_377_G1, timing: Optional[dict] = None):
+                       curve: int = _lib.CURVE_BLS12_377_G1, timing: Optional[dict] = None, exchange: Optional[ShardExchange] = None):
     """One points-split MSM on the current process group.
 
     point_sums(first, count) -> K * 144 bytes: the K window sums over this rank's share of the points
     (product: `MsmContext.window_sums(..., point_lo=first)`; the CPU tests inject a checker).
+    `exchange`: a ShardExchange of K * 144 bytes per rank kept by the caller across steps (default: one per call).
     Returns (True, affine-or-None) on rank 0 and None elsewhere."""
-    import time
-
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    first, count = point_shards(n, world)[rank]
+    ex = exchange or ShardExchange(PARTIAL_BYTES * K, device, group)
+    first, count = point_shards(n, ex.world)[ex.rank]
     # a rank without points contributes K identities: Z = 0 (Weierstrass), (0 : 1 : 1) (twisted Edwards)
     if curve == _lib.CURVE_ED_ON_BLS12_377:
         one = (1).to_bytes(48, "little")
@@ -104,47 +148,33 @@ def sharded_msm_points(point_sums: Callable[[int, int], bytes], n: int, K: int, 
     part = point_sums(first, count) if count else ident
     if len(part) != PARTIAL_BYTES * K:
         raise MsmError(_lib.MSM_ERR_ARG, "point_sums returned the wrong number of bytes")
-    mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(device)
-    gathered = torch.zeros(world * PARTIAL_BYTES * K, dtype=torch.uint8, device=device)
-    t0 = time.perf_counter()
-    dist.all_gather_into_tensor(gathered, mine, group=group)
-    if timing is not None:
-        timing["all_gather_ms"] = (time.perf_counter() - t0) * 1e3
-    if rank != 0:
+    g = ex.all_gather(part, timing)
+    if g is None:
         return None
-    return True, combine_groups_host(gathered.cpu().numpy().tobytes(), world, K, c, curve)
+    return True, combine_groups_host(g, ex.world, K, c, curve)
 
 
 def sharded_msm(window_sums: Callable[[int, int], bytes], K: int, c: int, device="cpu", group=None,
-                curve: int = _lib.CURVE_BLS12_377_G1, timing: Optional[dict] = None) -> Optional[Tuple[bool, Optional[Tuple[int, int]]]]:
+                curve: int = _lib.CURVE_BLS12_377_G1, timing: Optional[dict] = None,
+                exchange: Optional[ShardExchange] = None) -> Optional[Tuple[bool, Optional[Tuple[int, int]]]]:
     """Runs one window-sharded MSM on the current process group.
 
     window_sums(k_lo, k_hi) -> (k_hi - k_lo) * 144 bytes: this rank's partition sums
     (product: `MsmContext.window_sums`, i.e. the HIP path; the CPU tests inject a checker).
+    `exchange`: a ShardExchange of K * 144 bytes per rank kept by the caller across steps (default: one per call).
     Returns (True, affine-or-None) on rank 0 and None elsewhere."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    shards = window_shards(K, world)
-    lo, hi = shards[rank]
-    mine = torch.zeros(PARTIAL_BYTES * K, dtype=torch.uint8, device=device)
+    ex = exchange or ShardExchange(PARTIAL_BYTES * K, device, group)
+    shards = window_shards(K, ex.world)
+    lo, hi = shards[ex.rank]
+    mine = bytearray(PARTIAL_BYTES * K)   # the row of every rank has all K slots; a rank fills those of its windows
     if hi > lo:
         part = window_sums(lo, hi)
         if len(part) != PARTIAL_BYTES * (hi - lo):
             raise MsmError(_lib.MSM_ERR_ARG, "window_sums returned the wrong number of bytes")
-        mine[PARTIAL_BYTES * lo : PARTIAL_BYTES * hi] = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(device)
-    gathered = torch.zeros(world * PARTIAL_BYTES * K, dtype=torch.uint8, device=device)
-    import time
-
-    t0 = time.perf_counter()
-    dist.all_gather_into_tensor(gathered, mine, group=group)
-    if timing is not None:
-        timing["all_gather_ms"] = (time.perf_counter() - t0) * 1e3
-    if rank != 0:
+        mine[PARTIAL_BYTES * lo : PARTIAL_BYTES * hi] = part
+    g = ex.all_gather(bytes(mine), timing)
+    if g is None:
         return None
-    g = gathered.cpu().numpy().tobytes()
     row = PARTIAL_BYTES * K
     allp = b"".join(g[r * row + PARTIAL_BYTES * a : r * row + PARTIAL_BYTES * b] for r, (a, b) in enumerate(shards))
     return True, combine_host(allp, K, c, curve)

@@ -27,14 +27,40 @@ def test_library_exports_every_declared_symbol():
 def test_result_struct_layout_matches_header():
     from montgomery_amd._lib import MsmOpts, MsmResult
 
-    # msm_opts: 9 x 32-bit fields; msm_result: 96 B + 4 x int32 + 8 floats + 2 x u64
+    # msm_opts: 9 x 32-bit fields; msm_result: 96 B + 4 x int32 + 8 floats + 3 x u64
     assert ctypes.sizeof(MsmOpts) == 36
     text = open(os.path.join(ROOT, "include", "msm_hip.h")).read()
     body = re.sub(r"/\*.*?\*/", "", text[text.index("typedef struct msm_opts {"):text.index("} msm_opts;")], flags=re.S)
     fields = re.findall(r"u?int32_t\s+([a-z_0-9, ]+);", body)
     names = [n.strip() for f in fields for n in f.split(",")]
     assert names == [f[0] for f in MsmOpts._fields_], (names, MsmOpts._fields_)
-    assert ctypes.sizeof(MsmResult) == 96 + 16 + 32 + 16
+    assert ctypes.sizeof(MsmResult) == 96 + 16 + 32 + 24
+
+
+def test_abi_version_is_checked_at_load():
+    """The library reports the header version and struct sizes it was built with (no GPU needed); the Python loader compares
+    them with its own and refuses a library from another version of include/msm_hip.h instead of misreading its structs."""
+    from montgomery_amd import _lib
+
+    text = open(os.path.join(ROOT, "include", "msm_hip.h")).read()
+    ver = int(re.search(r"#define\s+MSM_ABI_VERSION\s+(\d+)", text).group(1))
+    assert ver == _lib.ABI_VERSION
+    lib = _lib.load()
+    assert lib.msm_abi_version() == ver
+    assert lib.msm_abi_struct_bytes(0) == ctypes.sizeof(_lib.MsmOpts)
+    assert lib.msm_abi_struct_bytes(1) == ctypes.sizeof(_lib.MsmResult)
+    # a binding written against another version must be refused
+    saved = (_lib._lib, _lib.ABI_VERSION)
+    try:
+        _lib._lib, _lib.ABI_VERSION = None, ver + 1
+        try:
+            _lib.load()
+        except ImportError as e:
+            assert "ABI" in str(e)
+        else:
+            raise AssertionError("a library of another ABI version was accepted")
+    finally:
+        _lib._lib, _lib.ABI_VERSION = saved
 
 
 def test_no_cpu_fallback_without_gpu():

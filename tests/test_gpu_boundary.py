@@ -174,7 +174,7 @@ def test_curve_facade_takes_a_device_list():
     te.context.close()
 
 
-def _sharded_bench(world, log2n, split="auto"):
+def _sharded_bench(world, log2n, split="windows"):
     import json
     import os
     import socket
@@ -202,7 +202,7 @@ def test_points_shards_on_one_gpu(world):
     rank 0 adds the groups per window (msm_combine_groups) and verifies the result against the discrete logs; the line
     carries what every rank spent where."""
     d = _sharded_bench(world, 18, "points")
-    assert d["n_gpus"] == world and d["verified"] is True, d
+    assert d["n_gpus"] == world and d["verified"] is True and d["other_splits"][0]["split"] == "windows", d
     assert f"points-shard x{world}" in d["config"]["parallelism"]
     assert len(d["ranks"]) == world and all(r["shard"][1] == (1 << 18) // world for r in d["ranks"])
     assert all("phase_ms" in r and r["all_gather_ms"] is not None for r in d["ranks"])
@@ -217,32 +217,44 @@ def test_four_and_eight_rank_window_shards_on_one_gpu(world):
     assert f"window-shard x{world}" in d["config"]["parallelism"]
 
 
-def test_two_rank_sharded_bench_in_child_processes():
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), here with both ranks on
-    the one GPU of the box and gloo as the process group: every rank computes the window sums of its shard through the
-    HIP path, one all-gather, rank 0 combines and checks the result against the known discrete logs.  Fresh child
-    processes (never a re-exec of this one)."""
+def test_two_rank_bench_launches_itself():
+    """`python bench.py --gpus 2` with NO launcher: the script starts its two ranks itself (torch.distributed.run children,
+    before it has imported torch), here with both ranks on the one GPU of the box and gloo as the process group.  The headline
+    is the window split of BASELINE configs[4]; the points split is timed by the same run (`other_splits`); both results are
+    verified against the known discrete logs, and every rank reports its phases and its all-gather."""
     import json
     import os
-    import socket
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--log2n", "20", "--dist-backend", "gloo", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log2n", "20",
+           "--dist-backend", "gloo", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["verified"] is True, d
     assert d["config"]["workload"] == "bls12-377-g1-msm-2^20" and "window-shard x2" in d["config"]["parallelism"]
+    assert d["split"] == "windows" and [r["shard"] for r in d["ranks"]] == [[0, 4], [4, 8]]
+    assert all("phase_ms" in r and r["all_gather_ms"] is not None for r in d["ranks"])
+    (o,) = d["other_splits"]
+    assert o["split"] == "points" and o["verified"] is True and o["value"] > 0
+    assert [r["shard"] for r in o["ranks"]] == [[0, 1 << 19], [1 << 19, 1 << 19]]
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """Under a launcher with WORLD_SIZE != --gpus bench.py must fail, not print a line labelled with the wrong GPU count."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--log2n", "16"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
 def test_big_host_buffers_cross_in_staged_chunks():
