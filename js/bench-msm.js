@@ -1,7 +1,7 @@
 // The reference's benchmark of one curve, through this facade with the reference's own calls
 // (scripts/msm-weierstrass.ts:12-51: start the workers, random points once, fresh random scalars per run, a warm-up, 15 timed
-// runs of which the first 5 are dropped, median and sample standard deviation).  The scalars are host Buffers here, so
-// every timed call includes their way over PCIe; bench.py times the resident-scalar form the driver reads.
+// runs of which the first 5 are dropped, median and sample standard deviation).  randomScalars generates into a device
+// buffer of the context (the reference: into wasm memory), so the timed call is the resident-scalar form bench.py times.
 //     node js/bench-msm.js [log2 n = 16] [curve = bls12-377 | bls12-381 | pallas]
 "use strict";
 const { Weierstraß, startThreads, stopThreads, bls12377Params, bls12381Params, pallasParams } = require("./montgomery-hip.js");
@@ -26,6 +26,7 @@ async function benchmarkMsm(params, n) {
   await Parallel.msmUnsafe(scalarPtr, pointPtr, Math.min(N, 1 << 15), true);   // warm-up (workspace allocation)
   const times = [];
   for (let i = 0; i < 15; i++) {
+    scalarPtr.free();   // (the reference's scalars sit in a scoped arena; here the handle owns a device buffer)
     [scalarPtr] = await Parallel.randomScalars(N, { seed: 100 + i });
     const t0 = process.hrtime.bigint();
     await Parallel.msmUnsafe(scalarPtr, pointPtr, N, true);
@@ -45,6 +46,7 @@ async function benchmarkMsm(params, n) {
   console.log(`msm (n=${n})... ${out.median_ms.toFixed(2)}ms ± ${out.std_ms.toFixed(2)}ms`);
   console.log(JSON.stringify(out));
   pointPtr.free();
+  scalarPtr.free();
   Curve.close();
   await stopThreads();
   return out;

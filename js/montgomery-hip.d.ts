@@ -4,11 +4,14 @@ export type CurveParams = { label: string; modulus: bigint; order: bigint };
 
 /** one resident point set of the context (its own allocation, like every pointer of the reference) */
 export type PointPtr = { size: number; n: number; set: number; free(): void };
-export type ScalarPtr = { size: number; bytes: Buffer | null; n: number };
+/** one device buffer of the context from scalarsFromBytes / randomScalars on (the reference's scalars live in wasm memory);
+ * free() returns it at once, a dropped pointer returns it when collected */
+export type ScalarPtr = { size: number; n: number; dev: unknown | null; free(): void; toBytes?: () => Buffer };
 
 /** canonical affine result: what `Affine.toBigint(Projective.toAffine(result))` yields in the reference */
 export type AffineResult = { x: bigint; y: bigint; isZero: boolean };
 export type MsmOptions = { c?: number; useSafeAdditions?: boolean; noGlv?: boolean };
+/** log: the reference's shape (src/msm-common.ts:176-214) -- [{n, K, c}], then ["label... x.xms"] per phase, "msm total" last */
 export type MsmOutput = { result: AffineResult; log: unknown[][] };
 
 export interface Parallel {
@@ -24,7 +27,7 @@ export interface Parallel {
   randomScalars(n: number, options?: { seed?: number }): Promise<ScalarPtr>;
   /** src/msm-batched-affine.ts:69-340 */
   msm(scalarPtr: ScalarPtr, pointPtr: PointPtr, N: number, verboseTiming?: boolean, options?: MsmOptions): Promise<MsmOutput>;
-  /** src/msm-batched-affine.ts:587-598 (the GPU kernels always handle the edge cases) */
+  /** src/msm-batched-affine.ts:587-598: msm with useSafeAdditions = false (msm_opts.unsafe) */
   msmUnsafe(scalarPtr: ScalarPtr, pointPtr: PointPtr, N: number, verboseTiming?: boolean, options?: MsmOptions): Promise<MsmOutput>;
   /** src/parallel.ts:69-87: window structure of msmBasic, no endomorphism split */
   msmProjective(scalarPtr: ScalarPtr, pointPtr: PointPtr, N: number, options?: MsmOptions): Promise<MsmOutput>;

@@ -53,7 +53,10 @@ function createCurve(params, curveId, coordBytes, device, wireBytes) {
     // every point pointer is its own resident point set of the context, as every pointer of the reference is its own
     // allocation; msm() selects the set of the pointer it is given
     getPointer(size) { return { size, n: 0, set: hip.pointsetCreate(ctx), free() { hip.pointsetDestroy(ctx, this.set); } }; },
-    getScalarPointer(size) { return { size, bytes: null, n: 0 }; },
+    // A scalar pointer owns ONE device buffer from scalarsFromBytes / randomScalars on: the reference's scalars live in the
+    // memory its kernels compute in (src/parallel.ts:119-133), so msm() crosses no PCIe.  free() gives the buffer back at
+    // once; a pointer that is simply dropped gives it back when it is collected (the addon registers a finalizer).
+    getScalarPointer(size) { return newScalarPtr(size); },
     async pointsFromBytes(pointPtr, input, n) {
       let b = Buffer.from(input.buffer, input.byteOffset, n * 2 * wireBytes);
       if (wireBytes !== coordBytes) {
@@ -64,8 +67,10 @@ function createCurve(params, curveId, coordBytes, device, wireBytes) {
       hip.pointsetSelect(ctx, pointPtr.set);
       pointPtr.n = hip.setPoints(ctx, b, pointBytes, 0);
     },
-    async scalarsFromBytes(scalarPtr, input, n) {
-      scalarPtr.bytes = Buffer.from(Buffer.from(input.buffer, input.byteOffset, n * 32));
+    async scalarsFromBytes(scalarPtr, input, n) {   // src/parallel.ts:119-133: one upload, then resident
+      scalarPtr.free();
+      scalarPtr.dev = hip.deviceAlloc(ctx, Math.max(32 * n, 32));
+      hip.deviceUpload(ctx, scalarPtr.dev, Buffer.from(input.buffer, input.byteOffset, n * 32));
       scalarPtr.n = n;
     },
     async randomPointsFast(n, options) {   // src/curve-random.ts:14-92; generated on the GPU, explicit seed
@@ -73,26 +78,53 @@ function createCurve(params, curveId, coordBytes, device, wireBytes) {
       pointPtr.n = hip.generatePoints(ctx, n, (options && options.seed) || 1);
       return firstOf(pointPtr);
     },
-    async randomScalars(n, options) {      // src/curve-random.ts:151-194
-      return firstOf({ size: n * 32, bytes: hip.generateScalars(ctx, n, (options && options.seed) || 1), n });
+    async randomScalars(n, options) {      // src/curve-random.ts:151-194: generated in HBM, nothing crosses PCIe
+      const ptr = newScalarPtr(n * 32);
+      const seed = (options && options.seed) || 1;
+      ptr.dev = hip.deviceAlloc(ctx, Math.max(32 * n, 32));
+      hip.generateScalars(ctx, n, seed, ptr.dev);
+      ptr.n = n;
+      ptr.toBytes = () => hip.generateScalars(ctx, n, seed);   // the same stream read back (tests)
+      return firstOf(ptr);
     },
     async msm(scalarPtr, pointPtr, N, verboseTiming, options) {
       const c = (options && options.c) || 0;
       if (N > pointPtr.n) throw new Error(`msm: ${N} scalars but ${pointPtr.n} points behind this pointer`);
+      if (!scalarPtr.dev || N > scalarPtr.n) throw new Error(`msm: ${N} scalars requested but the scalar pointer holds ${scalarPtr.dev ? scalarPtr.n : 0}`);
       hip.pointsetSelect(ctx, pointPtr.set);
-      const r = hip.msm(ctx, scalarPtr.bytes.slice(0, 32 * N), c, coordBytes, options && options.noGlv ? 1 : 0);
+      const unsafe = options && options.useSafeAdditions === false ? 1 : 0;
+      const r = hip.msmDevice(ctx, scalarPtr.dev, N, c, options && options.noGlv ? 1 : 0, unsafe);
       const result = { x: leBytesToBigint(r.x), y: leBytesToBigint(r.y), isZero: r.isZero };
-      const log = verboseTiming ? [[{ n: Math.ceil(Math.log2(Math.max(N, 1))), K: r.K, c: r.c }], [`msm total... ${r.phaseMs[0].toFixed(3)}ms`]] : [];
-      return { result, log };
+      return { result, log: verboseTiming ? buildLog(N, r) : [] };
     },
     msmProjective(scalarPtr, pointPtr, N, options) {
       // src/parallel.ts:69-87: signed windows of the whole scalar, no endomorphism split (same group element)
       return Parallel.msm(scalarPtr, pointPtr, N, false, Object.assign({}, options, { noGlv: true }));
     },
-    msmUnsafe(scalarPtr, pointPtr, N, verboseTiming, options) {
-      return Parallel.msm(scalarPtr, pointPtr, N, verboseTiming, options);   // the GPU kernels always handle the edge cases
+    msmUnsafe(scalarPtr, pointPtr, N, verboseTiming, options) {   // src/msm-batched-affine.ts:587-598
+      return Parallel.msm(scalarPtr, pointPtr, N, verboseTiming, Object.assign({}, options, { useSafeAdditions: false }));
     },
   };
+  function newScalarPtr(size) {
+    return { size, n: 0, dev: null, free() { if (this.dev) { const d = this.dev; this.dev = null; this.n = 0; hip.deviceFree(ctx, d); } } };
+  }
+  // `log` in the reference's shape (createLog, src/msm-common.ts:176-214; filled at src/msm-batched-affine.ts:79-338): one
+  // entry with the parameters, then one "label... x.xms" line per phase, "msm total" last.  The phases are the library's
+  // eight device timings (msm_result.phase_ms) under the reference's labels where a counterpart exists.
+  function buildLog(N, r) {
+    const t = r.phaseMs, line = (label, ms) => [`${label}... ${ms.toFixed(1)}ms`];
+    return [
+      [{ n: Math.ceil(Math.log2(Math.max(N, 1))), K: r.K, c: r.c }],   // log({ n, K, c }), src/msm-batched-affine.ts:93
+      line("scalars to device", t[1]),
+      line("slice scalars & count buckets", t[2]),
+      line("sort points", t[3]),
+      line("bucket accumulation (first round)", t[7]),
+      line("bucket accumulation", t[4]),
+      line("bucket reduction (local)", t[5]),
+      line("final sum", t[6]),
+      line("msm total", t[0]),
+    ];
+  }
   // What the reference's callers do with `result` (scripts/msm-weierstrass.ts:89-91):
   //     let sAffinePtr = Curve.Field.getPointer(Curve.Affine.size);
   //     Curve.Projective.toAffine(scratch, sAffinePtr, result);
@@ -136,8 +168,8 @@ async function compute_msm_on(curve, coordBytes, inputPoints, inputScalars) {
   if (Buffer.isBuffer(inputPoints) || inputPoints instanceof Uint8Array) pbytes = Buffer.from(inputPoints);
   else pbytes = Buffer.concat(inputPoints.map((P) => (P.isZero ? Buffer.alloc(pointBytes) : Buffer.concat([bigintToLeBytes(BigInt(P.x), coordBytes), bigintToLeBytes(BigInt(P.y), coordBytes)]))));
   const pp = curve.Parallel.getPointer(pbytes.length);
-  try {   // the point set is freed whatever the conversion or the MSM throws (bad point, HIP error): `curve` outlives the call
-    const sp = curve.Parallel.getScalarPointer(sbytes.length);
+  const sp = curve.Parallel.getScalarPointer(sbytes.length);
+  try {   // point set and scalar buffer are freed whatever the conversion or the MSM throws (bad point, HIP error): `curve` outlives the call
     await curve.Parallel.pointsFromBytes(pp, pbytes, n);
     await curve.Parallel.scalarsFromBytes(sp, sbytes, n);
     const same = n > 1 && pbytes.slice(0, pointBytes).equals(pbytes.slice(pointBytes, 2 * pointBytes));
@@ -145,6 +177,7 @@ async function compute_msm_on(curve, coordBytes, inputPoints, inputScalars) {
     return { x: result.x, y: result.y, isZero: result.isZero };
   } finally {
     pp.free();
+    sp.free();
   }
 }
 

@@ -126,9 +126,25 @@ async function main() {
     // randomPointsFast / randomScalars (src/curve-random.ts), as src/msm.test.ts:49-50 uses them: msm == msmProjective
     const n = 1 << 12;
     const rp = await cv.Parallel.randomPointsFast(n, { seed: 5 }), rs = await cv.Parallel.randomScalars(n, { seed: 6 });
-    assert(rp.n === n && rs.bytes.length === 32 * n, "generators");
-    const m1 = (await cv.Parallel.msmUnsafe(rs, rp, n)).result, m2 = (await cv.Parallel.msmProjective(rs, rp, n)).result;
+    assert(rp.n === n && rs.n === n && rs.dev && rs.toBytes().length === 32 * n, "generators");
+    const out1 = await cv.Parallel.msmUnsafe(rs, rp, n, true);
+    const m1 = out1.result, m2 = (await cv.Parallel.msmProjective(rs, rp, n)).result;
     assert(!m1.isZero && m1.x === m2.x && m1.y === m2.y, params.label + ": msm == msmProjective on generated inputs");
+    // the scalars are resident: the same values uploaded from host bytes (scalarsFromBytes: one upload, then resident) and
+    // the safe entry give the same element; the log has the reference's shape (src/msm-common.ts:176-214)
+    const sp2 = cv.Parallel.getScalarPointer(32 * n);
+    await cv.Parallel.scalarsFromBytes(sp2, rs.toBytes(), n);
+    const m3 = (await cv.Parallel.msm(sp2, rp, n)).result;
+    assert(m3.x === m1.x && m3.y === m1.y, params.label + ": uploaded scalars == generated scalars, safe == unsafe");
+    const log = out1.log;
+    assert(log.length >= 7 && log[0][0].K > 0 && log[0][0].c > 0 && typeof log[0][0].n === "number", "log: parameters first");
+    assert(log.slice(1).every((l) => /^[a-z &()]+\.\.\. \d+\.\dms$/.test(l[0])), "log: 'label... x.xms' lines");
+    assert(log[log.length - 1][0].startsWith("msm total..."), "log: msm total last");
+    assert((await cv.Parallel.msm(rs, rp, n)).log.length === 0, "log: empty unless verboseTiming");
+    sp2.free(); rs.free();
+    let threw = false;
+    try { await cv.Parallel.msm(rs, rp, n); } catch (e) { threw = true; }
+    assert(threw, "a freed scalar pointer must be refused");
     console.log(params.label, "ok:", g.msm.length, "golden cases + generated 2^12");
     cv.close();
   }

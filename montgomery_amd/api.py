@@ -346,6 +346,8 @@ class MsmContext:
         out = (C.c_uint8 * (144 * max(k_hi - k_lo, 1)))()
         if on_device:
             ptr = C.c_void_p(int(scalars))
+        elif isinstance(scalars, C.Array):
+            ptr = scalars   # handed over as it is (no copy of a 2 GB buffer)
         else:
             ptr = (C.c_uint8 * max(32 * n, 1)).from_buffer_copy(bytes(scalars) or b"\0")
         self._check(self._lib.msm_window_sums(self._h, ptr, n, int(on_device), C.byref(opts), out, C.byref(res)))

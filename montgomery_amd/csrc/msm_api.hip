@@ -193,6 +193,8 @@ struct msm_ctx {
   char* stage_pin = nullptr;
   hipStream_t stage_stream[STAGE_THREADS] = {};
   hipEvent_t stage_ev[STAGE_THREADS][STAGE_SLOTS + 1] = {};
+  static constexpr int MAX_PIECES = 4;   // ranges of the points a host-scalar MSM is pipelined over (PieceUpload)
+  hipEvent_t piece_ev[MAX_PIECES][STAGE_THREADS] = {};
   uint64_t ws_budget = 0;          // bytes the per-group workspaces may take in total
   uint64_t ws_limit = 0;           // msm_set_workspace_limit: the caller's cap on ws_budget (0 = automatic)
 
@@ -1043,6 +1045,17 @@ void te_horner_to_affine(const msm_ctx* ctx, const std::vector<uint32_t>& words,
 // ~20 GB/s through one hipMemcpy, which stages it through pinned memory on one thread.  Here a few host threads copy 16 MB
 // chunks into pinned slots of their own and queue each chunk's transfer behind it, so the host copies and the DMA overlap.
 // Ordered into ctx->stream: work queued there afterwards sees the whole buffer.
+void ensure_staging(msm_ctx* ctx) {
+  constexpr int T = msm_ctx::STAGE_THREADS, S = msm_ctx::STAGE_SLOTS;
+  if (ctx->stage_pin) return;
+  HIPCHK(hipHostMalloc((void**)&ctx->stage_pin, (size_t)T * S * msm_ctx::STAGE_CHUNK, hipHostMallocDefault));
+  for (int t = 0; t < T; t++) {
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stage_stream[t], hipStreamNonBlocking));
+    for (int q = 0; q <= S; q++) HIPCHK(hipEventCreateWithFlags(&ctx->stage_ev[t][q], hipEventDisableTiming));
+    for (int q = 0; q < msm_ctx::MAX_PIECES; q++) HIPCHK(hipEventCreateWithFlags(&ctx->piece_ev[q][t], hipEventDisableTiming));
+  }
+}
+
 void upload_staged(msm_ctx* ctx, void* dst, const void* src, size_t bytes) {
   constexpr int T = msm_ctx::STAGE_THREADS, S = msm_ctx::STAGE_SLOTS;
   constexpr size_t CH = msm_ctx::STAGE_CHUNK;
@@ -1050,13 +1063,7 @@ void upload_staged(msm_ctx* ctx, void* dst, const void* src, size_t bytes) {
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return;
   }
-  if (!ctx->stage_pin) {
-    HIPCHK(hipHostMalloc((void**)&ctx->stage_pin, (size_t)T * S * CH, hipHostMallocDefault));
-    for (int t = 0; t < T; t++) {
-      HIPCHK(hipStreamCreateWithFlags(&ctx->stage_stream[t], hipStreamNonBlocking));
-      for (int q = 0; q <= S; q++) HIPCHK(hipEventCreateWithFlags(&ctx->stage_ev[t][q], hipEventDisableTiming));
-    }
-  }
+  ensure_staging(ctx);
   HIPCHK(hipStreamSynchronize(ctx->stream));   // dst may still be in use by what the stream holds
   for (int t = 0; t < T; t++) HIPCHK(hipStreamSynchronize(ctx->stage_stream[t]));   // and the slots by an earlier upload
   const size_t n_chunks = (bytes + CH - 1) / CH;
@@ -1089,6 +1096,101 @@ void upload_staged(msm_ctx* ctx, void* dst, const void* src, size_t bytes) {
   for (int t = 0; t < T; t++) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[t][S], 0));
 }
 
+// The same staged transfer running BEHIND the call that consumes it: a host scalar buffer of a big MSM crosses PCIe in the
+// background while the MSM already runs over the ranges of the points ("pieces") whose scalars have arrived -- 2 GB take
+// ~45 ms at the rate of the link, a 2^26 MSM ~150 ms, and the sort of a window needs every digit of its range, so the
+// unit of overlap is a range of the points, not a chunk (window_sums_once picks growing ranges: the first one is small so the
+// GPU starts early, the last one is half the input so most of the work runs at full-size efficiency).
+// Chunks go out in address order over the staging threads as in upload_staged; when a thread has queued its last chunk of
+// piece q it records piece_ev[q][t] on its copy stream, and wait_piece(q, stream) makes `stream` wait for all of them.
+// The reference's counterpart is scalarsFromBytes into shared wasm memory before the call, src/parallel.ts:119-133.
+class PieceUpload {
+ public:
+  static constexpr int T = msm_ctx::STAGE_THREADS, S = msm_ctx::STAGE_SLOTS;
+  static constexpr size_t CH = msm_ctx::STAGE_CHUNK;
+  PieceUpload(msm_ctx* ctx, void* dst, const void* src, size_t bytes, const std::vector<size_t>& piece_end_bytes)
+      : ctx_(ctx), dst_((char*)dst), src_((const char*)src), bytes_(bytes), ends_(piece_end_bytes), enq_(piece_end_bytes.size(), 0) {
+    ensure_staging(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // dst may still be in use by what the stream holds
+    for (int t = 0; t < T; t++) HIPCHK(hipStreamSynchronize(ctx->stage_stream[t]));
+    for (int t = 0; t < T; t++) rc_[t] = hipSuccess;
+    t0_ = std::chrono::steady_clock::now();
+    for (int t = 0; t < T; t++) {
+      try { th_.emplace_back([this, t] { run(t); }); } catch (const std::system_error&) { run(t); }
+    }
+  }
+  ~PieceUpload() { join(); }
+  // host: blocks until every staging thread has queued its part of piece q; device: `stream` then waits for those copies
+  void wait_piece(int q, hipStream_t stream) {
+    {
+      std::unique_lock<std::mutex> l(mu_);
+      cv_.wait(l, [&] { return enq_[q] == T; });
+    }
+    for (int t = 0; t < T; t++) {
+      if (rc_[t] != hipSuccess) throw HipFail{rc_[t], "staged upload of the scalars", __LINE__};
+      HIPCHK(hipStreamWaitEvent(stream, ctx_->piece_ev[q][t], 0));
+    }
+  }
+  // joins the staging threads, waits for the last copy and returns the wall time of the whole transfer in ms
+  float finish() {
+    join();
+    for (int t = 0; t < T; t++) HIPCHK(rc_[t]);
+    for (int t = 0; t < T; t++) HIPCHK(hipStreamSynchronize(ctx_->stage_stream[t]));
+    return ms_;
+  }
+
+ private:
+  void join() {
+    for (auto& x : th_) if (x.joinable()) x.join();
+  }
+  void run(int t) {
+    hipError_t e = hipSetDevice(ctx_->device);
+    const size_t n_chunks = (bytes_ + CH - 1) / CH;
+    size_t turn = 0;
+    int q = 0;
+    auto mark = [&](int upto) {   // this thread has nothing more to send for the pieces below `upto`
+      for (; q < upto; q++) {
+        if (e == hipSuccess) e = hipEventRecord(ctx_->piece_ev[q][t], ctx_->stage_stream[t]);
+        std::lock_guard<std::mutex> l(mu_);
+        rc_[t] = e;
+        enq_[q]++;
+        cv_.notify_all();
+      }
+    };
+    for (size_t i = t; i < n_chunks && e == hipSuccess; i += T, turn++) {
+      const size_t off = i * CH, len = std::min(CH, bytes_ - off);
+      int upto = q;
+      while (upto < (int)ends_.size() && ends_[upto] <= off) upto++;   // pieces that end at or before this chunk
+      mark(upto);
+      const int slot = (int)(turn % S);
+      char* pin = ctx_->stage_pin + ((size_t)t * S + slot) * CH;
+      if (turn >= (size_t)S) e = hipEventSynchronize(ctx_->stage_ev[t][slot]);
+      if (e != hipSuccess) break;
+      memcpy(pin, src_ + off, len);
+      e = hipMemcpyAsync(dst_ + off, pin, len, hipMemcpyHostToDevice, ctx_->stage_stream[t]);
+      if (e == hipSuccess) e = hipEventRecord(ctx_->stage_ev[t][slot], ctx_->stage_stream[t]);
+    }
+    mark((int)ends_.size());   // on an error too: nobody may wait for ever
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx_->stage_stream[t]);
+    std::lock_guard<std::mutex> l(mu_);
+    rc_[t] = e;
+    const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0_).count();
+    ms_ = std::max(ms_, ms);
+  }
+  msm_ctx* ctx_;
+  char* dst_;
+  const char* src_;
+  size_t bytes_;
+  std::vector<size_t> ends_;   // byte offset where piece q ends (multiples of the chunk size, the last = bytes)
+  std::vector<int> enq_;
+  hipError_t rc_[T];
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::chrono::steady_clock::time_point t0_;
+  float ms_ = 0;
+};
+
 int stage_scalars(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const uint32_t** d_out) {
   if (on_device) {
     *d_out = (const uint32_t*)scalars;
@@ -1105,7 +1207,17 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
                      const Plan& pl, std::vector<uint32_t>& words, msm_result* stats, uint64_t p_off) {
   const uint32_t* d_scal = nullptr;
   HIPCHK(hipEventRecord(ctx->ev[8], ctx->stream));
-  stage_scalars(ctx, scalars, n, on_device, &d_scal);
+  // Host scalars of a big call cross PCIe BEHIND the computation, range by range of the points (PieceUpload); everything
+  // else is staged before the window groups start.
+  std::vector<uint64_t> piece_end;   // pipelined upload: point index where piece q ends (the last = n)
+  if (!on_device && n >= (1ull << 24)) {
+    const uint64_t gran = msm_ctx::STAGE_CHUNK / 32;   // scalars per staging chunk
+    const int shifts[3] = {3, 2, 1};                    // 1/8, 1/4, 1/2 of the points, then the rest
+    for (int i = n >= (1ull << 25) ? 0 : 1; i < 3; i++) piece_end.push_back(((n >> shifts[i]) / gran) * gran);
+    piece_end.push_back(n);
+  }
+  std::unique_ptr<PieceUpload> pipe;
+  if (piece_end.empty()) stage_scalars(ctx, scalars, n, on_device, &d_scal);
   HIPCHK(hipEventRecord(ctx->ev[9], ctx->stream));
   GroupStats st;
   const int pw = ctx->is_te() ? 32 : 36;
@@ -1113,7 +1225,8 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   // window groups: as large as the workspace budget allows; for big inputs two of them on two streams.  The streams
   // run in step (both sort, both gather, ...): what the second one buys is two tree kernels sharing the chip -- forward
   // (memory-heavy) and backward (issue-heavy) sweeps of different waves mix, the small last rounds fill each other's
-  // idle CUs -- not a sort hidden under an accumulation
+  // idle CUs -- not a sort hidden under an accumulation (a sort started under the other group's tree finds no free
+  // registers on any CU and takes four times as long: profiles/r04_experiments.txt item 1)
   if (ctx->ws_limit) {
     ctx->ws_budget = ctx->ws_limit;
   } else if (n >= (1ull << 22)) {
@@ -1139,6 +1252,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   struct Group {
     int ka, kb;
     uint64_t p_lo, p_n;
+    int piece;   // pipelined upload: the piece whose arrival the group waits for (-1: the scalars are in place)
   };
   std::vector<Group> groups;
   // A single window (the 8-GPU shard) has no second window group to hide its sort and tails under: split it by
@@ -1150,26 +1264,50 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   if (nwin == 1 && want_groups == 1 && !ctx->is_te() && n >= (1ull << 24) && !MSM_KNOB_SET("MSM_GROUPS")) pieces = 2;
   pieces = std::max(pieces, point_pieces(ctx, n, pl));
   MSM_KNOB(pieces, "MSM_PIECES", 1);
-  const bool split_points = pieces > 1;
-  if (split_points) {
+  if (!piece_end.empty() && (point_pieces(ctx, n, pl) > 1 || MSM_KNOB_SET("MSM_PIECES"))) {
+    // the workspace forces its own ranges: plain staged upload first (rare: 2^29 points, or a tight msm_set_workspace_limit)
+    piece_end.clear();
+    stage_scalars(ctx, scalars, n, on_device, &d_scal);
+  }
+  if (!piece_end.empty()) {
+    // pipelined host scalars: per arriving range of the points the usual window groups (two above 2^22 points), in order
+    ctx->ensure(ctx->scal, n * 32);
+    d_scal = (const uint32_t*)ctx->scal.p;
+    uint64_t lo = 0;
+    for (size_t q = 0; q < piece_end.size(); q++) {
+      const uint64_t cnt = piece_end[q] - lo;
+      const int g = (nwin >= 2 && cnt >= (1ull << 22)) ? 2 : 1;
+      const int per = std::max(1, std::min(wpg, (nwin + g - 1) / g));
+      for (int k = k_lo; k < k_hi; k += per) groups.push_back({k, std::min(k_hi, k + per), lo, cnt, (int)q});
+      lo = piece_end[q];
+    }
+  } else if (pieces > 1) {
     for (int k = k_lo; k < k_hi; k++)
       for (uint64_t q = 0; q < pieces; q++) {
         const uint64_t lo = n * q / pieces, hi = n * (q + 1) / pieces;
-        groups.push_back({k, k + 1, lo, hi - lo});
+        groups.push_back({k, k + 1, lo, hi - lo, -1});
       }
   } else {
     long long first_group = 0;   // experiment: windows in the first of two uneven groups
     MSM_KNOB(first_group, "MSM_WPG_A", 1);
     if (first_group > 0 && first_group < nwin) {
-      groups.push_back({k_lo, k_lo + (int)first_group, 0, n});
-      groups.push_back({k_lo + (int)first_group, k_hi, 0, n});
+      groups.push_back({k_lo, k_lo + (int)first_group, 0, n, -1});
+      groups.push_back({k_lo + (int)first_group, k_hi, 0, n, -1});
     } else {
-      for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg), 0, n});
+      for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg), 0, n, -1});
     }
   }
+  // does more than one group contribute to a window?  Then the sums of its ranges are added on the host below.
+  bool split_points = false;
+  for (const Group& g : groups) split_points |= g.p_n != n;
   std::vector<std::vector<uint32_t>> split_part(split_points ? groups.size() : 0);
   HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));   // staged scalars are in place before the group streams start
+  if (!piece_end.empty()) {
+    std::vector<size_t> ends;
+    for (uint64_t e : piece_end) ends.push_back((size_t)e * 32);
+    pipe.reset(new PieceUpload(ctx, ctx->scal.p, scalars, n * 32, ends));
+  }
   std::atomic<int> next{0};
   GroupStats sts[msm_ctx::N_WS];
   auto worker = [&](int slot) {
@@ -1181,6 +1319,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       std::vector<uint32_t> part((size_t)(kb - ka) * pw);
       Plan pg = pl;
       pg.lone = groups.size() == 1 && kb - ka == 1;
+      if (groups[gi].piece >= 0) pipe->wait_piece(groups[gi].piece, ctx->ws[slot].stream);
       run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, part.data(), sts[slot], p_off);
       if (split_points) split_part[gi] = part;
       else memcpy(&words[(size_t)(ka - k_lo) * pw], part.data(), part.size() * 4);
@@ -1213,19 +1352,25 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (pl.strict && (ctx->h_info[0] & 4u)) throw MsmFail{MSM_ERR_SCALAR, "a scalar is >= the group order q (msm_opts.strict)"};
   }
+  float upload_ms = -1;
+  if (pipe) upload_ms = pipe->finish();   // joins the staging threads; their last copy is done
   if (split_points) {
-    // P_k = sum over the ranges; an all-zero partial (Z = 0) is the identity
+    // P_k = sum over the ranges of the points (groups of one or several windows each); an all-zero partial (Z = 0) is the
+    // identity.  (Plan.merged: a group then carries sum_kk 2^(c kk) P_kk in its first slot and identities in the others --
+    // slot-wise sums of such groups are still a valid set of slots for the Horner step.)
     for (int k = k_lo; k < k_hi; k++) {
       uint32_t* out = &words[(size_t)(k - k_lo) * pw];
       if (ctx->is_te()) {
         msm_host::Ext6 acc = ctx->hte.zero();
         for (size_t gi = 0; gi < groups.size(); gi++)
-          if (groups[gi].ka == k && !split_part[gi].empty()) acc = ctx->hte.add(acc, te_partial_to_host(ctx, split_part[gi].data()));
+          if (groups[gi].ka <= k && k < groups[gi].kb && !split_part[gi].empty())
+            acc = ctx->hte.add(acc, te_partial_to_host(ctx, split_part[gi].data() + (size_t)(k - groups[gi].ka) * pw));
         te_host_to_partial(ctx, acc, out);
       } else {
         msm_host::Proj6 acc = ctx->hc.zero();
         for (size_t gi = 0; gi < groups.size(); gi++)
-          if (groups[gi].ka == k && !split_part[gi].empty()) acc = ctx->hc.add(acc, partial_to_host(ctx, split_part[gi].data()));
+          if (groups[gi].ka <= k && k < groups[gi].kb && !split_part[gi].empty())
+            acc = ctx->hc.add(acc, partial_to_host(ctx, split_part[gi].data() + (size_t)(k - groups[gi].ka) * pw));
         host_to_partial(ctx, acc, out);
       }
     }
@@ -1243,7 +1388,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   if (stats) {
     float ms;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[9]));
-    stats->phase_ms[MSM_T_UPLOAD] = ms;
+    stats->phase_ms[MSM_T_UPLOAD] = upload_ms >= 0 ? upload_ms : ms;   // pipelined: host clock of the background transfer
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[10]));
     stats->phase_ms[MSM_T_TOTAL] = ms;
     stats->phase_ms[MSM_T_DIGITS] = st.ms_digits;
@@ -1506,6 +1651,7 @@ void msm_ctx_destroy(msm_ctx* ctx) {
   if (ctx->stage_pin) (void)hipHostFree(ctx->stage_pin);
   for (auto& st : ctx->stage_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   for (auto& row : ctx->stage_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
+  for (auto& row : ctx->piece_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

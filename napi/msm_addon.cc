@@ -8,8 +8,12 @@
 //
 // Exports: createContext(curve, device | [devices]) -> external handle, destroyContext(h), setPoints(h, Buffer, pointBytes, check),
 //          pointsetCreate(h) -> id, pointsetSelect(h, id), pointsetDestroy(h, id),
-//          msm(h, Buffer scalars, c) -> {x: Buffer, y: Buffer, isZero, c, K, phaseMs: Float64Array(8)},
-//          plan(h, n, c) -> {c, K}, generatePoints(h, n, seed) -> n, generateScalars(h, n, seed) -> Buffer
+//          msm(h, Buffer scalars, c, coordBytes, noGlv, unsafe) -> {x: Buffer, y: Buffer, isZero, c, K, phaseMs: number[8], nPairs},
+//          deviceAlloc(h, bytes) -> device buffer handle, deviceUpload(h, dbuf, Buffer), deviceFree(h, dbuf),
+//          msmDevice(h, dbuf, n, c, noGlv, unsafe) -> as msm: the scalars already sit in HBM (the reference keeps them in the
+//          memory its kernels compute in, src/parallel.ts:119-133, scripts/msm-weierstrass.ts:29-32),
+//          plan(h, n, c) -> {c, K}, generatePoints(h, n, seed) -> n, generateScalars(h, n, seed[, dbuf]) -> Buffer | n
+// The addon is built against include/msm_hip.h and checks at load that the library it found was too (msm_abi_version).
 #include <node_api.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,7 +41,19 @@ typedef struct {
   msm_ctx* ctx;      /* NULL after destroyContext: a second destroy or any later call throws instead of double-freeing */
   int32_t curve;
   size_t coord_bytes, point_bytes;
+  uint32_t refs;     /* the JS handle + every live device-buffer handle: the struct outlives whichever is collected last */
 } js_ctx;
+
+/* a device buffer of the context (msm_device_alloc): one per scalar pointer of the JS facade */
+typedef struct {
+  js_ctx* owner;
+  void* dev;         /* NULL after deviceFree */
+  uint64_t bytes;
+} js_dbuf;
+
+static void ctx_unref(js_ctx* h) {
+  if (--h->refs == 0) free(h);
+}
 
 static js_ctx* get_handle(napi_env env, napi_value v) {
   void* p = NULL;
@@ -59,8 +75,34 @@ static msm_ctx* get_ctx(napi_env env, napi_value v) {
 static void finalize_handle(napi_env env, void* data, void* hint) {
   (void)env; (void)hint;
   js_ctx* h = (js_ctx*)data;
-  if (h->ctx) msm_ctx_destroy(h->ctx);
-  free(h);
+  if (h->ctx) msm_ctx_destroy(h->ctx);   /* frees every device buffer the context still holds */
+  h->ctx = NULL;
+  ctx_unref(h);
+}
+/* a collected scalar pointer gives its device memory back (if its context is still alive and nobody freed it by hand) */
+static void finalize_dbuf(napi_env env, void* data, void* hint) {
+  (void)hint;
+  js_dbuf* b = (js_dbuf*)data;
+  if (b->dev && b->owner->ctx) {
+    msm_device_free(b->owner->ctx, b->dev);
+    int64_t adj;
+    napi_adjust_external_memory(env, -(int64_t)b->bytes, &adj);
+  }
+  ctx_unref(b->owner);
+  free(b);
+}
+static js_dbuf* get_dbuf(napi_env env, js_ctx* h, napi_value v) {
+  void* p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+    napi_throw_type_error(env, NULL, "expected a device buffer from deviceAlloc()");
+    return NULL;
+  }
+  js_dbuf* b = (js_dbuf*)p;
+  if (b->owner != h || !b->dev) {
+    napi_throw_error(env, NULL, b->owner != h ? "this device buffer belongs to another context" : "this device buffer has been freed");
+    return NULL;
+  }
+  return b;
 }
 
 static napi_value CreateContext(napi_env env, napi_callback_info info) {
@@ -99,6 +141,7 @@ static napi_value CreateContext(napi_env env, napi_callback_info info) {
     return NULL;
   }
   h->ctx = ctx;
+  h->refs = 1;
   h->curve = curve;
   h->coord_bytes = (curve == MSM_CURVE_ED_ON_BLS12_377 || curve == MSM_CURVE_PALLAS) ? 32 : 48;   /* per field */
   h->point_bytes = 2 * h->coord_bytes;
@@ -143,9 +186,34 @@ static napi_value SetPoints(napi_env env, napi_callback_info info) {  // pointsF
   return n;
 }
 
+static napi_value result_object(napi_env env, const js_ctx* h, const msm_result* res) {
+  const size_t coord = h->coord_bytes;   // of the context's curve, never taken from JS
+  napi_value out, x, y, v, ph;
+  NAPI_OK(napi_create_object(env, &out));
+  NAPI_OK(napi_create_buffer_copy(env, coord, res->x, NULL, &x));
+  NAPI_OK(napi_create_buffer_copy(env, coord, res->y, NULL, &y));
+  NAPI_OK(napi_set_named_property(env, out, "x", x));
+  NAPI_OK(napi_set_named_property(env, out, "y", y));
+  NAPI_OK(napi_get_boolean(env, res->is_infinity != 0, &v));
+  NAPI_OK(napi_set_named_property(env, out, "isZero", v));
+  NAPI_OK(napi_create_int32(env, res->c, &v));
+  NAPI_OK(napi_set_named_property(env, out, "c", v));
+  NAPI_OK(napi_create_int32(env, res->K, &v));
+  NAPI_OK(napi_set_named_property(env, out, "K", v));
+  NAPI_OK(napi_create_double(env, (double)res->n_pairs_algo, &v));
+  NAPI_OK(napi_set_named_property(env, out, "nPairs", v));
+  NAPI_OK(napi_create_array_with_length(env, MSM_N_PHASES, &ph));
+  for (uint32_t i = 0; i < MSM_N_PHASES; i++) {
+    NAPI_OK(napi_create_double(env, res->phase_ms[i], &v));
+    NAPI_OK(napi_set_element(env, ph, i, v));
+  }
+  NAPI_OK(napi_set_named_property(env, out, "phaseMs", ph));
+  return out;
+}
+
 static napi_value Msm(napi_env env, napi_callback_info info) {  // msm / msmUnsafe, src/msm-batched-affine.ts:69-340
-  size_t argc = 5;   // (ctx, scalars, c, coordBytes, noGlv)
-  napi_value argv[5];
+  size_t argc = 6;   // (ctx, scalars, c, coordBytes, noGlv, unsafe)
+  napi_value argv[6];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   js_ctx* h = get_handle(env, argv[0]);
   if (!h) return NULL;
@@ -159,31 +227,114 @@ static napi_value Msm(napi_env env, napi_callback_info info) {  // msm / msmUnsa
   }
   msm_opts opts;
   memset(&opts, 0, sizeof opts);
-  int32_t coord = (int32_t)h->coord_bytes;   // of the context's curve; the fourth argument is accepted and ignored
-  if (argc > 2) napi_get_value_int32(env, argv[2], &opts.c);
+  if (argc > 2) napi_get_value_int32(env, argv[2], &opts.c);   // (the fourth argument, coordBytes, is accepted and ignored)
   if (argc > 4) napi_get_value_int32(env, argv[4], &opts.no_glv);   // msmProjective, src/parallel.ts:69-87
+  if (argc > 5) napi_get_value_int32(env, argv[5], &opts.unsafe);   // msmUnsafe, src/msm-batched-affine.ts:587-598
   msm_result res;
   int rc = msm_run(ctx, data, len / 32, 0, &opts, &res);
   if (rc != MSM_OK) return throw_msm(env, ctx, rc, "msm");
-  napi_value out, x, y, v, ph;
-  NAPI_OK(napi_create_object(env, &out));
-  NAPI_OK(napi_create_buffer_copy(env, (size_t)coord, res.x, NULL, &x));
-  NAPI_OK(napi_create_buffer_copy(env, (size_t)coord, res.y, NULL, &y));
-  NAPI_OK(napi_set_named_property(env, out, "x", x));
-  NAPI_OK(napi_set_named_property(env, out, "y", y));
-  NAPI_OK(napi_get_boolean(env, res.is_infinity != 0, &v));
-  NAPI_OK(napi_set_named_property(env, out, "isZero", v));
-  NAPI_OK(napi_create_int32(env, res.c, &v));
-  NAPI_OK(napi_set_named_property(env, out, "c", v));
-  NAPI_OK(napi_create_int32(env, res.K, &v));
-  NAPI_OK(napi_set_named_property(env, out, "K", v));
-  NAPI_OK(napi_create_array_with_length(env, MSM_N_PHASES, &ph));
-  for (uint32_t i = 0; i < MSM_N_PHASES; i++) {
-    NAPI_OK(napi_create_double(env, res.phase_ms[i], &v));
-    NAPI_OK(napi_set_element(env, ph, i, v));
+  return result_object(env, h, &res);
+}
+
+// device buffers: the scalars of a scalar pointer live in HBM from scalarsFromBytes / randomScalars on, as the reference's
+// live in wasm memory (src/parallel.ts:119-133); msm() then crosses no PCIe
+static napi_value DeviceAlloc(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  js_ctx* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  double bytes = 0;
+  NAPI_OK(napi_get_value_double(env, argv[1], &bytes));
+  if (!(bytes >= 0) || bytes > 9.0e15) {
+    napi_throw_range_error(env, NULL, "deviceAlloc: bad size");
+    return NULL;
   }
-  NAPI_OK(napi_set_named_property(env, out, "phaseMs", ph));
+  js_dbuf* b = (js_dbuf*)calloc(1, sizeof(js_dbuf));
+  if (!b) {
+    napi_throw_error(env, NULL, "out of memory");
+    return NULL;
+  }
+  b->bytes = (uint64_t)bytes < 32 ? 32 : (uint64_t)bytes;
+  int rc = msm_device_alloc(h->ctx, b->bytes, &b->dev);
+  if (rc != MSM_OK) {
+    free(b);
+    return throw_msm(env, h->ctx, rc, "deviceAlloc");
+  }
+  b->owner = h;
+  h->refs++;
+  napi_value out;
+  if (napi_create_external(env, b, finalize_dbuf, NULL, &out) != napi_ok) {
+    msm_device_free(h->ctx, b->dev);
+    h->refs--;
+    free(b);
+    napi_throw_error(env, NULL, "N-API call failed: napi_create_external");
+    return NULL;
+  }
+  int64_t adj;
+  napi_adjust_external_memory(env, (int64_t)b->bytes, &adj);   // lets the collector see what a dropped handle holds
   return out;
+}
+
+static napi_value DeviceUpload(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  js_ctx* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  js_dbuf* b = get_dbuf(env, h, argv[1]);
+  if (!b) return NULL;
+  void* data;
+  size_t len;
+  NAPI_OK(napi_get_buffer_info(env, argv[2], &data, &len));
+  if (len > b->bytes) {
+    napi_throw_range_error(env, NULL, "deviceUpload: the Buffer is larger than the device buffer");
+    return NULL;
+  }
+  int rc = msm_device_upload(h->ctx, b->dev, data, len);
+  if (rc != MSM_OK) return throw_msm(env, h->ctx, rc, "deviceUpload");
+  return NULL;
+}
+
+static napi_value DeviceFree(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  js_ctx* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  js_dbuf* b = get_dbuf(env, h, argv[1]);   // throws on a buffer that was freed before
+  if (!b) return NULL;
+  int rc = msm_device_free(h->ctx, b->dev);
+  b->dev = NULL;
+  int64_t adj;
+  napi_adjust_external_memory(env, -(int64_t)b->bytes, &adj);
+  if (rc != MSM_OK) return throw_msm(env, h->ctx, rc, "deviceFree");
+  return NULL;
+}
+
+static napi_value MsmDevice(napi_env env, napi_callback_info info) {  // msm over scalars resident in HBM
+  size_t argc = 6;   // (ctx, dbuf, n, c, noGlv, unsafe)
+  napi_value argv[6];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  js_ctx* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  js_dbuf* b = get_dbuf(env, h, argv[1]);
+  if (!b) return NULL;
+  uint32_t n = 0;
+  NAPI_OK(napi_get_value_uint32(env, argv[2], &n));
+  if ((uint64_t)n * 32 > b->bytes) {
+    napi_throw_range_error(env, NULL, "msmDevice: more scalars than the device buffer holds");
+    return NULL;
+  }
+  msm_opts opts;
+  memset(&opts, 0, sizeof opts);
+  if (argc > 3) napi_get_value_int32(env, argv[3], &opts.c);
+  if (argc > 4) napi_get_value_int32(env, argv[4], &opts.no_glv);
+  if (argc > 5) napi_get_value_int32(env, argv[5], &opts.unsafe);
+  msm_result res;
+  int rc = msm_run(h->ctx, b->dev, n, 1, &opts, &res);
+  if (rc != MSM_OK) return throw_msm(env, h->ctx, rc, "msmDevice");
+  return result_object(env, h, &res);
 }
 
 static napi_value Plan(napi_env env, napi_callback_info info) {  // windowSize, src/msm-common.ts:8-41
@@ -226,16 +377,33 @@ static napi_value GeneratePoints(napi_env env, napi_callback_info info) {
   return out;
 }
 
-// randomScalars, src/curve-random.ts:151-194: n uniform scalars < q, returned as n x 32 little-endian bytes
+// randomScalars, src/curve-random.ts:151-194: n uniform scalars < q.  (h, n, seed) -> n x 32 little-endian bytes in a Buffer;
+// (h, n, seed, dbuf) -> written to the device buffer, nothing crosses PCIe, returns n
 static napi_value GenerateScalars(napi_env env, napi_callback_info info) {
-  size_t argc = 3;
-  napi_value argv[3];
+  size_t argc = 4;
+  napi_value argv[4];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  msm_ctx* ctx = get_ctx(env, argv[0]);
-  if (!ctx) return NULL;
+  js_ctx* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  msm_ctx* ctx = h->ctx;
   uint32_t n = 0, seed = 1;
   napi_get_value_uint32(env, argv[1], &n);
   if (argc > 2) napi_get_value_uint32(env, argv[2], &seed);
+  napi_valuetype t3 = napi_undefined;
+  if (argc > 3) napi_typeof(env, argv[3], &t3);
+  if (t3 == napi_external) {
+    js_dbuf* b = get_dbuf(env, h, argv[3]);
+    if (!b) return NULL;
+    if ((uint64_t)n * 32 > b->bytes) {
+      napi_throw_range_error(env, NULL, "generateScalars: the device buffer is too small");
+      return NULL;
+    }
+    int rc = msm_generate_scalars(ctx, n, seed, b->dev, NULL);
+    if (rc != MSM_OK) return throw_msm(env, ctx, rc, "generateScalars");
+    napi_value out;
+    NAPI_OK(napi_create_uint32(env, n, &out));
+    return out;
+  }
   void* data = NULL;
   napi_value buf;
   NAPI_OK(napi_create_buffer(env, (size_t)n * 32, &data, &buf));
@@ -274,9 +442,16 @@ static napi_value PointsetSelect(napi_env env, napi_callback_info info) { return
 static napi_value PointsetDestroy(napi_env env, napi_callback_info info) { return PointsetOp(env, info, 1); }
 
 NAPI_MODULE_INIT() {
+  // the library found at run time must come from the header this addon was compiled against: same symbol names, other
+  // struct layouts would otherwise be read wrongly without a word
+  if (msm_abi_version() != MSM_ABI_VERSION || msm_abi_struct_bytes(0) != sizeof(msm_opts) || msm_abi_struct_bytes(1) != sizeof(msm_result)) {
+    napi_throw_error(env, NULL, "msm_hip.node: libmsm_hip.so was built from another version of include/msm_hip.h (msm_abi_version); rebuild both");
+    return NULL;
+  }
   struct { const char* name; napi_callback fn; } fns[] = {
       {"createContext", CreateContext}, {"destroyContext", DestroyContext}, {"setPoints", SetPoints}, {"msm", Msm}, {"plan", Plan},
       {"generatePoints", GeneratePoints}, {"generateScalars", GenerateScalars},
+      {"deviceAlloc", DeviceAlloc}, {"deviceUpload", DeviceUpload}, {"deviceFree", DeviceFree}, {"msmDevice", MsmDevice},
       {"pointsetCreate", PointsetCreate}, {"pointsetSelect", PointsetSelect}, {"pointsetDestroy", PointsetDestroy}};
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;
@@ -284,6 +459,8 @@ NAPI_MODULE_INIT() {
     if (napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) return NULL;
   }
   napi_value v;
+  napi_create_int32(env, MSM_ABI_VERSION, &v);
+  napi_set_named_property(env, exports, "ABI_VERSION", v);
   napi_create_int32(env, MSM_CURVE_BLS12_377_G1, &v);
   napi_set_named_property(env, exports, "CURVE_BLS12_377_G1", v);
   napi_create_int32(env, MSM_CURVE_ED_ON_BLS12_377, &v);

@@ -257,6 +257,35 @@ def test_bench_refuses_a_world_size_other_than_gpus():
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
+@pytest.mark.parametrize("n", [(1 << 24) + 777, 1 << 25])
+def test_host_scalars_pipelined_behind_the_msm(n):
+    """From 2^24 points a host scalar buffer crosses PCIe BEHIND the computation: the MSM runs range by range of the points
+    (three ranges at 2^24, four from 2^25; ragged sizes included) as their scalars arrive, the sums of the ranges are added
+    per window.  Same group element as over the same scalars resident in HBM, for the default window, a forced one and a
+    window shard, and against the known discrete logs of the generated points."""
+    from montgomery_amd.api import MsmContext
+    from oracle import c_oracle
+
+    ctx = MsmContext()
+    logs = ctx.generate_points(n, seed=77, want_scalars=True)
+    dev, host = ctx.generate_scalars(n, seed=78, to_host=True)
+    on_dev, _ = ctx.run_device(dev, n)
+    on_host, info = ctx.run(host)
+    assert on_host.as_tuple() == on_dev.as_tuple()
+    assert info["phase_ms"]["upload"] > 0 and info["n_pairs_algo"] > 0
+    k = c_oracle.dot_mod(logs, host, n, C.q)
+    assert on_dev.as_tuple() == O.aff_scale(k, (C.gx, C.gy), C.p)
+    assert ctx.run(host, c=13)[0].as_tuple() == on_dev.as_tuple()
+    a, _ = ctx.window_sums(host, n, 2, 5)            # host scalars through the sharded entry
+    b, _ = ctx.window_sums(dev, n, 2, 5, on_device=True)
+    K = ctx.plan(n)[1]
+    from montgomery_amd.distributed import combine_host
+
+    ident = bytes(144)
+    assert combine_host(ident * 2 + a + ident * (K - 5), K, ctx.plan(n)[0]) == combine_host(ident * 2 + b + ident * (K - 5), K, ctx.plan(n)[0])
+    ctx.close()
+
+
 def test_big_host_buffers_cross_in_staged_chunks():
     """Host scalars and wire points above 64 MB go through the library's pinned staging chunks (16 MB each, several host
     threads, the last chunk ragged): the MSM over host scalars must equal the one over the same scalars resident on the

@@ -332,6 +332,20 @@ def test_msm_2p26_known_discrete_logs(gpu_ctx, c_oracle):
     del a, s
     assert info["c"] == 16 and info["K"] == 8
     assert res.as_tuple() == O.aff_scale(k, (C.gx, C.gy), P_MOD), info
+    # the pair additions the bucket sums need: one per entry (2 N K, minus the ~2^-16 zero digits) less one per non-empty
+    # bucket (all K 2^15 of them at this size); the tree issues a few per cent more (padding lanes)
+    assert 2 * n * 8 * (1 - 2 ** -15) - 8 * (1 << 15) <= info["n_pairs_algo"] <= 2 * n * 8 - 8 * (1 << 15)
+    assert info["n_pairs_algo"] < info["n_pairs"] < 1.05 * info["n_pairs_algo"]
+    # BASELINE configs[4], per-rank workload: eight one-window shards at the FULL size (what each of 8 GPUs runs under
+    # `--split windows`), and eight points shards (`--split points`), each combined as rank 0 combines them
+    from montgomery_amd import _lib
+    from montgomery_amd.distributed import combine_groups_host, combine_host
+
+    parts = b"".join(gpu_ctx.window_sums(dev, n, kk, kk + 1, on_device=True)[0] for kk in range(8))
+    assert combine_host(parts, 8, 16, _lib.CURVE_BLS12_377_G1) == res.as_tuple()
+    share = n // 8
+    groups = b"".join(gpu_ctx.window_sums(dev + 32 * g * share, share, 0, 8, on_device=True, point_lo=g * share)[0] for g in range(8))
+    assert combine_groups_host(groups, 8, 8, 16, _lib.CURVE_BLS12_377_G1) == res.as_tuple()
 
 
 def test_msm_large_linearity(gpu_ctx):
@@ -474,6 +488,19 @@ def test_msm_projective_window_structure(gpu_ctx):
 
     with pytest.raises(MsmError):
         gpu_ctx.run(O.scalars_to_bytes([1]), c=3, no_glv=True)
+
+
+def test_projective_windows_above_16_per_group(gpu_ctx):
+    """msmProjective with a small explicit window over 2^21 points: K = ceil(254 / 13) = 20 windows in ONE window group whose
+    sort is the radix split -- its window table has 16 entries, so the group is cut at 16 windows (it used to fail with
+    MSM_ERR_INTERNAL).  Same group element as the default plan."""
+    n = 1 << 21
+    gpu_ctx.generate_points(n, seed=2113)
+    dev, _ = gpu_ctx.generate_scalars(n, seed=2114)
+    want, _ = gpu_ctx.run_device(dev, n)
+    for c in (13, 9):
+        got, info = gpu_ctx.run_device(dev, n, c=c, no_glv=True)
+        assert info["K"] == -(-254 // c) and got.as_tuple() == want.as_tuple(), info
 
 
 def test_single_window_shards_split_by_points(gpu_ctx):

@@ -26,7 +26,8 @@ def test_addon_loads_and_exports(addon):
                          cwd=ROOT, capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
     names = out.stdout.strip().split(",")
-    for n in ("createContext", "destroyContext", "setPoints", "msm", "plan"):
+    for n in ("createContext", "destroyContext", "setPoints", "msm", "plan", "deviceAlloc", "deviceUpload", "deviceFree", "msmDevice",
+              "ABI_VERSION"):
         assert n in names
 
 
@@ -59,6 +60,40 @@ def test_js_benchmark_with_the_reference_protocol(addon):
     assert out.returncode == 0, out.stdout + out.stderr
     rep = json.loads(out.stdout.strip().splitlines()[-1])
     assert rep["consistent"] and rep["runs"] == 10 and rep["n"] == 14 and rep["median_ms"] > 0
+    # the reference's `log`, printed by the script as the reference prints it: the parameters, then >= 6 "label... x.xms" lines
+    lines = out.stdout.splitlines()
+    assert sum(1 for l in lines if l.rstrip().endswith("ms") and "... " in l and not l.startswith("msm (n=")) >= 6, out.stdout
+    assert any(l.startswith("msm total... ") for l in lines)
+
+
+@pytest.mark.gpu
+def test_js_scalars_are_device_resident(addon):
+    """The JS facade keeps scalars in HBM from scalarsFromBytes / randomScalars on (src/parallel.ts:119-133): the timed msm
+    of js/bench-msm.js at 2^20 must be the resident-scalar time, i.e. close to the Python facade's run_device on the same box."""
+    import json
+    import statistics
+    import time
+
+    from montgomery_amd.api import MsmContext
+
+    out = subprocess.run([NODE, "js/bench-msm.js", "20"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    js_ms = json.loads(out.stdout.strip().splitlines()[-1])["median_ms"]
+    ctx = MsmContext()
+    n = 1 << 20
+    ctx.generate_points(n, seed=1)
+    dev, _ = ctx.generate_scalars(n, seed=2)
+    for _ in range(5):
+        ctx.run_device(dev, n)
+    ts = []
+    for _ in range(10):
+        t = time.perf_counter()
+        ctx.run_device(dev, n)
+        ts.append((time.perf_counter() - t) * 1e3)
+    ctx.close()
+    py_ms = statistics.median(ts)
+    # a host Buffer per call cost +0.9 ms of 3.9 at 2^20 (round 3); resident scalars must be within 10 % of the ctypes path
+    assert js_ms <= 1.10 * py_ms, (js_ms, py_ms)
 
 
 @pytest.mark.gpu
