@@ -47,9 +47,24 @@ INT_MAD_AT_2_WAVES = 28.2e12
 # regular rounds, 2.00 in the gather round, half the pairs each) against the 2.39 GHz the micro-benchmark kernels hold
 HELD_CLOCK_GHZ = 1.89
 UBENCH_CLOCK_GHZ = 2.39
-# HBM bytes per pair addition from the PMC passes committed in profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE runs at
-# 2^24, regular rounds; FETCH_SIZE doubled: gfx950 halves wide coalesced reads) -- see profiles/README.md
+# SURVEY.md section 8(d) prices a 377-bit multiplication at 300 word multiplications (6 x 300 = 1 800 per pair addition); the
+# kernel's own count for 13 limbs is PAIR_MADS.  `frac` uses PAIR_MADS, `frac_1800_basis` the survey's figure.
+PAIR_MADS_SURVEY = 1800
+# HBM bytes per pair addition of the tree kernel: from the PMC passes at the headline size committed under profiles/
+# (tools/pmc_headline.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled: gfx950 halves wide coalesced
+# reads); the round-3 constant (2^24, regular rounds only) if that file is missing
 PAIR_TRAFFIC_BYTES_PMC = 488
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_2p26.json")
+
+
+def pmc_bytes_per_pair():
+    """(bytes per algorithmic pair addition over all rounds, source) from the committed PMC summary."""
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+        return float(d["per_pair_addition"]["all_rounds"]["hbm_bytes_per_pair_add"]), os.path.relpath(PMC_FILE, ROOT)
+    except (OSError, KeyError, ValueError):
+        return float(PAIR_TRAFFIC_BYTES_PMC), "profiles/r03_pmc_2p24.json (regular rounds at 2^24)"
 MAX_SCALAR_SETS = 8            # distinct 2^n x 32-byte scalar sets kept in HBM; steps cycle through them
 
 
@@ -165,7 +180,7 @@ def timed_config(curve_name, log2n, torch, steps=10, warmup=5, c=0):
     exp = expected_from_logs(curve_name, a_host, s_host, n)
     verified = ((last.x, last.y) == exp) if te else (last.as_tuple() == exp)
     acc_ms = sum(x["phase_ms"]["accumulate"] for x in infos)
-    pairs = sum(x["n_pairs"] for x in infos)
+    pairs = sum(x["n_pairs_algo"] for x in infos)   # algorithmic pair additions (msm_result.n_pairs_algo)
     algo_bytes, mads = (384, 9 * 153) if te else (PAIR_ALGO_BYTES, PAIR_MADS)
     mad_rate = pairs * mads / (acc_ms * 1e-3)
     hbm = pairs * algo_bytes / (acc_ms * 1e-3) / 1e9
@@ -216,7 +231,7 @@ def bench_ed377(args, torch):
     _, s_host = ctx.generate_scalars(n, seed=1000 + last_set, to_host=True, raw=True)
     verified = (last.x, last.y) == expected_from_logs("ed377", a_host, s_host, n)
     acc_ms = sum(x["phase_ms"]["accumulate"] for x in infos)
-    pairs = sum(x["n_pairs"] for x in infos)
+    pairs = sum(x["n_pairs_algo"] for x in infos)
     # one unified extended addition: two 128-byte nodes in, one out; 9 multiplications of 9 limbs (2*81 - 9 MADs)
     algo_bytes, mads = 384, 9 * 153
     achieved = pairs * algo_bytes / (acc_ms * 1e-3) / 1e9
@@ -269,6 +284,7 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the known-discrete-log check of the last timed result")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-scalar (PCIe-inclusive) leg")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the in-process runs of BASELINE configs[1] (2^20 BLS12-377) and configs[3] (2^20 Ed-on-BLS12-377)")
     ap.add_argument("--split", choices=["auto", "windows", "points"], default="windows",
@@ -430,7 +446,10 @@ def main():
     if rank == 0:
         infos = [x for x in infos if x]
         acc_ms = sum(x["phase_ms"]["accumulate"] for x in infos)
-        pairs = sum(x["n_pairs"] for x in infos)
+        # ALGORITHMIC pair additions price the roofline (sum over the non-empty buckets of size - 1: msm_result.n_pairs_algo);
+        # the tree also issues the additions of its padding lanes (n_pairs, ~2.5 % more at 2^26)
+        pairs = sum(x["n_pairs_algo"] for x in infos)
+        pairs_issued = sum(x["n_pairs"] for x in infos)
         launches = sum(x["rounds"] for x in infos) or 1     # tree rounds of ALL window groups (summed by the library)
         phase = {k: sum(x["phase_ms"][k] for x in infos) / max(len(infos), 1) for k in infos[0]["phase_ms"]} if infos else {}
         achieved = pairs * PAIR_ALGO_BYTES / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
@@ -443,13 +462,17 @@ def main():
         if world == 1:
             _, xi = ctx.run_device(scal[0].data_ptr(), n, c=c, serial=True)
             x_ms = xi["phase_ms"]["accumulate"]
+            xp = xi["n_pairs_algo"]
             excl = {
                 "accumulate_ms": x_ms,
-                "achieved": xi["n_pairs"] * PAIR_ALGO_BYTES / (x_ms * 1e-3) / 1e9,
-                "frac": xi["n_pairs"] * PAIR_ALGO_BYTES / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "int_mad_frac": xi["n_pairs"] * PAIR_MADS / (x_ms * 1e-3) / INT_MAD_PEAK,
-                "int_mad_frac_at_2_waves_per_simd": xi["n_pairs"] * PAIR_MADS / (x_ms * 1e-3) / INT_MAD_AT_2_WAVES,
-                "int_mad_frac_at_held_clock": xi["n_pairs"] * PAIR_MADS / (x_ms * 1e-3) / (INT_MAD_PEAK * HELD_CLOCK_GHZ / UBENCH_CLOCK_GHZ),
+                "pair_adds": xp,
+                "pair_adds_issued": xi["n_pairs"],
+                "achieved": xp * PAIR_ALGO_BYTES / (x_ms * 1e-3) / 1e9,
+                "frac": xp * PAIR_ALGO_BYTES / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "int_mad_frac": xp * PAIR_MADS / (x_ms * 1e-3) / INT_MAD_PEAK,
+                "int_mad_frac_1800_basis": xp * PAIR_MADS_SURVEY / (x_ms * 1e-3) / INT_MAD_PEAK,
+                "int_mad_frac_at_2_waves_per_simd": xp * PAIR_MADS / (x_ms * 1e-3) / INT_MAD_AT_2_WAVES,
+                "int_mad_frac_at_held_clock": xp * PAIR_MADS / (x_ms * 1e-3) / (INT_MAD_PEAK * HELD_CLOCK_GHZ / UBENCH_CLOCK_GHZ),
                 "held_clock_ghz": HELD_CLOCK_GHZ,
                 "phase_ms": xi["phase_ms"],
                 # the counting sort (histogram + scans + scatter): 2 N K entries, each read twice as a 4-byte digit and
@@ -465,6 +488,7 @@ def main():
                     "frac": 2 * n * K * SORT_ALGO_BYTES / (xi["phase_ms"]["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 },
             }
+        if world == 1 and not args.no_pcie:
             # The same MSM with the scalars handed over as a HOST buffer (pageable memory; 2^n x 32 bytes cross PCIe inside the
             # call, behind the computation from 2^24 points up): never `value`.  Same protocol as the headline: 15 calls, the
             # first 5 discarded, median and sample standard deviation; every result must equal the device-resident one.
@@ -523,12 +547,18 @@ def main():
                 "peak": INT_MAD_PEAK,
                 "unit": "v_mad_u64_u32 lane-ops/s",
                 "frac": mad_rate / INT_MAD_PEAK,
-                "frac_basis": "exclusive (window groups serialised, one untimed step)" if excl else "overlapped streams",
+                "frac_1800_basis": mad_rate / PAIR_MADS * PAIR_MADS_SURVEY / INT_MAD_PEAK,
+                "frac_basis": ("exclusive (window groups serialised, one untimed step)" if excl else "overlapped streams")
+                              + "; algorithmic pair additions (sum over non-empty buckets of size - 1) x 1 872 multiply-adds "
+                                "(13-limb count); frac_1800_basis prices them at SURVEY section 8(d)'s 300 per multiplication",
                 "mads_per_pair_add": PAIR_MADS,
-                "traffic": pairs / launches * PAIR_TRAFFIC_BYTES_PMC,
-                "traffic_note": "HBM bytes per launch = pair additions per launch x the bytes per pair of the committed PMC passes "
-                                "(profiles/, regular rounds); not collected inside this run",
+                "traffic": pairs / launches * pmc_bytes_per_pair()[0],
+                "traffic_note": "HBM bytes per launch = algorithmic pair additions per launch x the measured bytes per pair addition of "
+                                + pmc_bytes_per_pair()[1] + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                                "command at this size; not collected inside this run)",
+                "traffic_bytes_per_pair_add": pmc_bytes_per_pair()[0],
                 "pair_adds_per_step": pairs / max(len(infos), 1),
+                "pair_adds_issued_per_step": pairs_issued / max(len(infos), 1),
                 "avg_launch_ms": acc_ms / launches,
                 "launches_per_step": launches / max(len(infos), 1),
                 "hbm": {

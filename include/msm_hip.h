@@ -104,10 +104,11 @@ typedef struct msm_result {
  * `Weierstraß.create(params)` / `TwistedEdwards.create(params)` (src/parallel.ts:40-66, 179-200). */
 int msm_ctx_create(msm_ctx** out, int curve, int device);
 /* The same over a device list ("create(curve id, device list)").  Every device holds the whole
- * point set; msm_run / msm_window_sums cut the window range into one contiguous shard per device (windows are
- * independent until the final sum, src/msm-batched-affine.ts:312-333), run the shards from one host thread per device
- * and combine the K x 144 bytes of partition sums on the host -- so a C or JS host can use a whole node without
- * torch.distributed.  Device scalars must live on devices[0]; they are copied peer-to-peer to the others.
+ * point set; msm_run / msm_window_sums give every device a share of the POINTS (all windows over n / G points, the
+ * default) or, with msm_opts.by_window, one contiguous shard of the window range (windows are independent until the
+ * final sum, src/msm-batched-affine.ts:312-333), run the shards from one host thread per device and combine the
+ * K x 144 bytes of partition sums per device on the host -- so a C or JS host can use a whole node without
+ * torch.distributed.  Device scalars must live on devices[0]; the other devices copy their part peer-to-peer.
  * (bench.py --gpus N keeps the one-process-per-GPU RCCL form of the north star.) */
 int msm_ctx_create_multi(msm_ctx** out, int curve, const int32_t* devices, int32_t n_devices);
 int msm_ctx_device_count(const msm_ctx* ctx);

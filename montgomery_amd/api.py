@@ -664,8 +664,10 @@ class Weierstrass:
     """Curve module as `Weierstraß.create(params)` returns it (src/parallel.ts:147-160), MSM path only."""
 
     def __init__(self, params: WeierstrassParams, device: int = 0, devices: Optional[Sequence[int]] = None):
-        """`devices`: a device list instead of one device -- every device holds the point set and `Parallel.msm` shards the
-        windows over them (msm_ctx_create_multi); the counterpart of the reference's thread count, src/parallel.ts:40-66."""
+        """`devices`: a device list instead of one device -- every device holds the whole point set and `Parallel.msm` runs
+        all windows on each device's share of the points (by points, the default; `by_window=True` on the context's run calls
+        shards by scalar window instead; msm_ctx_create_multi); the counterpart of the reference's thread count,
+        src/parallel.ts:40-66."""
         if params.label not in _WEIERSTRASS_CURVE_IDS:
             raise MsmError(_lib.MSM_ERR_ARG, f"curve {params.label!r} has no device constants "
                                              f"(have {sorted(_WEIERSTRASS_CURVE_IDS)})")

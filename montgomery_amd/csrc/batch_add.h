@@ -76,9 +76,6 @@ constexpr int BA_THREADS = 256;
 #define BA_INV(r, x) fe_inv<F>(r, x)
 #endif
 #endif
-#ifndef MSM_BA_FWD_DEPTH
-#define MSM_BA_FWD_DEPTH 1  // pairs whose x the forward sweep requests ahead of the one it multiplies in
-#endif
 #ifndef MSM_BA_WAVES
 #define MSM_BA_WAVES 2      // resident waves per SIMD the register allocation is held to (2: 256 VGPRs, 3: 168 + LDS parking)
 #endif
@@ -324,11 +321,7 @@ __device__ __forceinline__ uint32_t ba_denominator(Fe<F>& den, const PkW<F::NW>&
   {
     Pk pm;
     const uint32_t borrow = pk_sub(dx, x2, x1);
-#ifdef BA_X_UNSAFE   // experiment: price of the equal-x detection (P + P, P - P give garbage)
-    const bool z = false;
-#else
     const bool z = pk_is_zero(dx);           // x1, x2 canonical (or the identity's all-ones): equal iff the words are
-#endif
     pk_set_p_masked<F>(pm, borrow);
     pk_add(dx, dx, pm);                      // (x2 - x1) mod p
     pk_unpack<F>(den, dx);
@@ -385,36 +378,23 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
   fe_set_one<F>(acc);
 
   // ---- forward sweep: prefix products of the denominators ---------------------------------------
-  // The x of pair i + FWD_DEPTH is requested while pair i is multiplied in: one multiplication (~1 us) does not cover the
-  // latency of HBM under load, and the registers of the ring are free here -- the kernel's allocation is set by the backward
-  // sweep.  The ring is a fully unrolled inner loop, so every slot is a fixed set of registers.
   {
-    constexpr int D = MSM_BA_FWD_DEPTH;
-    PairLoc<MODE> RL[D];
-    Pk rx1[D], rx2[D];
-#pragma unroll
-    for (int d = 0; d < D; d++)
-      if ((uint32_t)d < steps) {
-        ba_locate<MODE>(RL[d], a, BA_STEP((uint32_t)d), T, t, is_active((uint32_t)d));
-        ba_load_x<F, MODE>(rx1[d], rx2[d], RL[d], a, t);
-      }
+    PairLoc<MODE> L;
+    Pk x1, x2;
+    ba_locate<MODE>(L, a, 0, T, t, is_active(0));
+    ba_load_x<F, MODE>(x1, x2, L, a, t);
 #pragma unroll 1
-    for (uint32_t i0 = 0; i0 < steps; i0 += D) {
-#pragma unroll
-      for (int d = 0; d < D; d++) {
-        const uint32_t i = i0 + d;
-        if (i >= steps) break;   // uniform
-        Fe<F> den;
-        ba_denominator<F, MODE, false>(den, rx1[d], rx2[d], nullptr, nullptr, RL[d], a, t, is_active(i));
-        if (i + D < steps) {   // this slot's registers are free now
-          ba_locate<MODE>(RL[d], a, BA_STEP(i + D), T, t, is_active(i + D));
-          ba_load_x<F, MODE>(rx1[d], rx2[d], RL[d], a, t);
-        }
-        ba_store_pre(a, BA_STEP(i), T, t, acc.l);
-        BA_FENCE();
-        BA_MUL(acc, acc, den);
-        BA_FENCE();
+    for (uint32_t i = 0; i < steps; i++) {
+      Fe<F> den;
+      ba_denominator<F, MODE, false>(den, x1, x2, nullptr, nullptr, L, a, t, is_active(i));
+      if (i + 1 < steps) {   // the next pair's x: its registers are free now, the multiplication covers the latency
+        ba_locate<MODE>(L, a, BA_STEP(i + 1), T, t, is_active(i + 1));
+        ba_load_x<F, MODE>(x1, x2, L, a, t);
       }
+      ba_store_pre(a, BA_STEP(i), T, t, acc.l);
+      BA_FENCE();
+      BA_MUL(acc, acc, den);
+      BA_FENCE();
     }
   }
 
@@ -449,9 +429,6 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
 #endif
     PairLoc<MODE> L, Ln;
     Pk x1, x2, y1, y2, nx1, nx2;
-#ifdef MSM_BA_Y_EARLY
-    Pk ny1, ny2;
-#endif
     Fe<F> pre, npre;
     ba_locate<MODE>(L, a, BA_STEP(steps - 1), T, t, is_active(steps - 1));
     ba_load_x<F, MODE>(x1, x2, L, a, t);
@@ -495,17 +472,11 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
         ba_locate<MODE>(Ln, a, BA_STEP((uint32_t)i - 1), T, t, is_active((uint32_t)i - 1));
         ba_load_x<F, MODE>(nx1, nx2, Ln, a, t);
         ba_load_pre(npre.l, a, BA_STEP((uint32_t)i - 1), T, t);
-#if defined(MSM_BA_Y_EARLY) && MSM_BA_Y_EARLY == 3
-        ba_load_y<F, MODE>(ny1, ny2, Ln, a, t);
-#endif
       }
       BA_FENCE();
       Fe<F> m;
       BA_MUL(m, num, d);
       BA_FENCE();
-#if defined(MSM_BA_Y_EARLY) && MSM_BA_Y_EARLY == 2
-      if (i > 0) ba_load_y<F, MODE>(ny1, ny2, Ln, a, t);
-#endif
       Pk x3, y3;
       {
         Fe<F> mm;
@@ -556,11 +527,7 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
       }
       asm volatile("" ::: "memory");
       BA_FENCE();
-#ifdef MSM_BA_Y_EARLY
-      y1 = ny1; y2 = ny2;
-#else
       if (i > 0) ba_load_y<F, MODE>(y1, y2, Ln, a, t);   // the next pair's y: in flight during the stores and d = inv * pre
-#endif
       if (!(kind & BA_SKIP)) {
         if (MODE == MODE_GATHER && a.out_rows) {
           // Uniform: chunk-ordered round 1.  The pair's element index comes from the table, and the element leaves as whole

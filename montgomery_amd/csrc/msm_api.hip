@@ -1698,7 +1698,8 @@ static int set_points_one(msm_ctx* ctx, const void* points, uint64_t n, int on_d
 
 int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, int check_curve) {
   if (!ctx || ctx->children.empty()) return set_points_one(ctx, points, n, on_device, check_curve);
-  // multi-device context: every device keeps the whole point set (the windows are sharded, not the points)
+  // multi-device context: every device keeps the whole point set (an MSM then runs over a share of the points per device by
+  // default, or over a share of the windows with msm_opts.by_window: either way without moving points)
   try {
     std::vector<uint8_t> host;
     const void* src = points;

@@ -1,0 +1,65 @@
+"""gpurun_out/pmc_<tag>_2p<lg>/ (tools/pmc_headline.sh) -> profiles/<tag>_pmc_2p<lg>.json: per-kernel counter sums of the four
+PMC passes, the clock every kernel held, and the figures bench.py quotes per pair addition of the tree kernel:
+HBM bytes (FETCH_SIZE x 2 -- gfx950 tallies wide coalesced reads at half their size, MI355X_MICROARCH.md -- plus WRITE_SIZE,
+both reported in KB) and SQ_INSTS_VALU / 64 lanes, each divided by the ALGORITHMIC pair additions of the MSMs in the run
+(msm_result.n_pairs_algo, read from the bench line of the same run)."""
+import collections, csv, glob, json, os, sys
+
+tag, lg = sys.argv[1], int(sys.argv[2])
+src = f"gpurun_out/pmc_{tag}_2p{lg}"
+out, clocks = {}, {}
+for kind in ("fetch", "write", "sq", "grbm"):
+    fs = sorted(glob.glob(f"{src}/pmc_{kind}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1:]
+    if not fs:
+        continue
+    agg = collections.OrderedDict()
+    clk = collections.OrderedDict()
+    for r in csv.DictReader(open(fs[0])):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        d = agg.setdefault(k, {})
+        d.setdefault("launches", set()).add(r["Dispatch_Id"])
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        if kind == "grbm" and r["Counter_Name"] == "GRBM_GUI_ACTIVE" and dur >= 300000:
+            c = clk.setdefault(k, [0.0, 0, 0])
+            c[0] += float(r["Counter_Value"]); c[1] += dur; c[2] += 1
+    for k in agg:
+        agg[k]["launches"] = len(agg[k]["launches"])
+    out[kind] = agg
+    if kind == "grbm":
+        clocks = {k: {"dispatches": n, "wall_ms": round(d / 1e6, 3), "ghz": round(c / 8 / d, 3)} for k, (c, d, n) in clk.items()}
+
+# the bench line of the fetch pass: pair additions of the MSMs the run held (timed step + serialised step)
+pairs_algo = pairs_issued = msms = None
+for line in open(f"{src}/pmc_fetch.log", errors="ignore"):
+    if line.startswith("{"):
+        b = json.loads(line)
+        msms = b["steps"] + b["warmup"] + 1
+        pairs_algo = b["roofline"]["pair_adds_per_step"] * msms
+        pairs_issued = b["roofline"]["pair_adds_issued_per_step"] * msms
+per_pair = {}
+if pairs_algo:
+    def tot(kind, ctr, key):
+        return sum(v.get(ctr, 0.0) for k, v in out.get(kind, {}).items() if key in k)
+    for name, key in (("gather_round", "k_batch_add<msm::CvBls377, 0>"), ("regular_rounds", "k_batch_add<msm::CvBls377, 1>"),
+                      ("all_rounds", "k_batch_add<msm::CvBls377")):
+        fetch, write, valu = tot("fetch", "FETCH_SIZE", key) * 1024, tot("write", "WRITE_SIZE", key) * 1024, tot("sq", "SQ_INSTS_VALU", key)
+        per_pair[name] = {"fetch_bytes_x2": 2 * fetch, "write_bytes": write, "valu_wave_insts": valu}
+    # pair additions per kind of round: the gather round does half of a bucket's additions (n - 1 of them for n entries split
+    # as n/2 in round 1, the rest later), so the split comes from the issued counts of the bench line where available
+    half = pairs_algo / 2
+    for name, denom in (("gather_round", half), ("regular_rounds", half), ("all_rounds", pairs_algo)):
+        p = per_pair[name]
+        p["pair_adds_basis"] = denom
+        p["hbm_bytes_per_pair_add"] = (p["fetch_bytes_x2"] + p["write_bytes"]) / denom
+        p["valu_insts_per_pair_add"] = p["valu_wave_insts"] / (denom / 64)
+os.makedirs("profiles", exist_ok=True)
+json.dump({"command": f"rocprofv3 --pmc <one counter group per run: FETCH_SIZE | WRITE_SIZE | SQ_* | GRBM_GUI_ACTIVE> -- python3 bench.py "
+                      f"--steps 1 --warmup 0 --log2n {lg} --no-cpu-baseline --no-verify --no-other-configs --no-pcie",
+           "note": "FETCH_SIZE / WRITE_SIZE in KB as reported (x 1024 below); FETCH_SIZE is doubled for HBM bytes (gfx950 halves wide "
+                   "coalesced reads, MI355X_MICROARCH.md); SQ_* cycle counters in quad-cycles; GRBM_GUI_ACTIVE summed over the 8 XCDs. "
+                   "Per-pair figures divide by algorithmic pair additions (half of them in the gather round).",
+           "msms_in_run": msms, "pair_adds_algorithmic": pairs_algo, "pair_adds_issued": pairs_issued,
+           "per_pair_addition": per_pair, "effective_clock_ghz": clocks, "counters": out},
+          open(f"profiles/{tag}_pmc_2p{lg}.json", "w"), indent=1)
+print("collected", tag, lg, json.dumps(per_pair.get("all_rounds", {})))
