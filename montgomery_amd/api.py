@@ -571,9 +571,14 @@ class _Parallel:
             res, info = self._ctx.run(scalarPtr.data[: 32 * N], options.get("c"), unsafe, no_glv=no_glv)
         log: List = []
         if verboseTiming:
+            # the reference's shape (createLog, src/msm-common.ts:176-214, filled at src/msm-batched-affine.ts:79-338): the
+            # parameters first, one "label... x.xms" line per phase under the reference's labels, "msm total" last
+            t = info["phase_ms"]
             log.append([{"n": (N - 1).bit_length() if N > 1 else 0, "K": info["K"], "c": info["c"]}])
-            for name, ms in info["phase_ms"].items():
-                log.append([f"{name}... {ms:.3f}ms"])
+            for label, key in (("scalars to device", "upload"), ("slice scalars & count buckets", "digits"), ("sort points", "sort"),
+                               ("bucket accumulation (first round)", "accumulate_round1"), ("bucket accumulation", "accumulate"),
+                               ("bucket reduction (local)", "reduce"), ("final sum", "final"), ("msm total", "total")):
+                log.append([f"{label}... {t[key]:.1f}ms"])
         return {"result": res, "log": log, "info": info}
 
     def msmProjective(self, scalarPtr: ScalarPtr, pointPtr: PointPtr, N: int, options: Optional[Dict] = None) -> Dict:

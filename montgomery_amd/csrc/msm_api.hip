@@ -566,10 +566,11 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
 
   // padding granule G = 2^g: about 1/8 of the mean bucket population (pads cost G/2 slots per bucket; what is
   // left after g regular rounds, ~8 elements per bucket, is finished without inversions by k_bucket_finish)
-  // Big buckets (>= 1024 entries) take G = mean / 16: half the pads (1/32 instead of 1/16 of all slots are identity
-  // pairs that occupy a lane for nothing) for twice the k_bucket_finish work, which is negligible there.
+  // Big buckets (>= 1024 entries) take G = mean / 32: a quarter of the pads (1/64 instead of 1/16 of all slots are identity
+  // pairs that occupy a lane for nothing) for more k_bucket_finish work, which is negligible there (2^26: 152.7 -> 152.1 ms
+  // from 16 to 32, no further gain at 64; profiles/r04_experiments.txt item 6).
   uint64_t mean = std::max<uint64_t>(1, two_n / L);
-  uint64_t per_bucket_left = mean >= 1024 ? 16 : 8;
+  uint64_t per_bucket_left = mean >= 1024 ? 32 : 8;
   MSM_KNOB(per_bucket_left, "MSM_PBL", 1);
   uint32_t logG = 1;
   while (logG < 10 && (1ull << (logG + 1)) * per_bucket_left <= mean) logG++;
@@ -1049,8 +1050,11 @@ void ensure_staging(msm_ctx* ctx) {
   constexpr int T = msm_ctx::STAGE_THREADS, S = msm_ctx::STAGE_SLOTS;
   if (ctx->stage_pin) return;
   HIPCHK(hipHostMalloc((void**)&ctx->stage_pin, (size_t)T * S * msm_ctx::STAGE_CHUNK, hipHostMallocDefault));
+  int prio_lo = 0, prio_hi = 0;   // (numerically lower = higher priority)
+  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   for (int t = 0; t < T; t++) {
-    HIPCHK(hipStreamCreateWithFlags(&ctx->stage_stream[t], hipStreamNonBlocking));
+    // copies queued while kernels hold the chip should not wait behind them: highest priority the device offers
+    HIPCHK(hipStreamCreateWithPriority(&ctx->stage_stream[t], hipStreamNonBlocking, prio_hi));
     for (int q = 0; q <= S; q++) HIPCHK(hipEventCreateWithFlags(&ctx->stage_ev[t][q], hipEventDisableTiming));
     for (int q = 0; q < msm_ctx::MAX_PIECES; q++) HIPCHK(hipEventCreateWithFlags(&ctx->piece_ev[q][t], hipEventDisableTiming));
   }
@@ -1111,6 +1115,8 @@ class PieceUpload {
   PieceUpload(msm_ctx* ctx, void* dst, const void* src, size_t bytes, const std::vector<size_t>& piece_end_bytes)
       : ctx_(ctx), dst_((char*)dst), src_((const char*)src), bytes_(bytes), ends_(piece_end_bytes), enq_(piece_end_bytes.size(), 0) {
     ensure_staging(ctx);
+    MSM_KNOB(n_streams_, "MSM_UPLOAD_STREAMS", 1);
+    n_streams_ = std::min<long long>(n_streams_, T);
     HIPCHK(hipStreamSynchronize(ctx->stream));   // dst may still be in use by what the stream holds
     for (int t = 0; t < T; t++) HIPCHK(hipStreamSynchronize(ctx->stage_stream[t]));
     for (int t = 0; t < T; t++) rc_[t] = hipSuccess;
@@ -1135,7 +1141,7 @@ class PieceUpload {
   float finish() {
     join();
     for (int t = 0; t < T; t++) HIPCHK(rc_[t]);
-    for (int t = 0; t < T; t++) HIPCHK(hipStreamSynchronize(ctx_->stage_stream[t]));
+    for (int t = 0; t < T; t++) HIPCHK(hipStreamSynchronize(ctx_->stage_stream[t % n_streams_]));
     return ms_;
   }
 
@@ -1150,13 +1156,16 @@ class PieceUpload {
     int q = 0;
     auto mark = [&](int upto) {   // this thread has nothing more to send for the pieces below `upto`
       for (; q < upto; q++) {
-        if (e == hipSuccess) e = hipEventRecord(ctx_->piece_ev[q][t], ctx_->stage_stream[t]);
+        if (e == hipSuccess) e = hipEventRecord(ctx_->piece_ev[q][t], ctx_->stage_stream[t % n_streams_]);
         std::lock_guard<std::mutex> l(mu_);
         rc_[t] = e;
         enq_[q]++;
         cv_.notify_all();
       }
     };
+    double t_wait = 0, t_copy = 0, t_enq = 0;   // tuning builds: where the host side of the transfer spends its time
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(now() - a).count(); };
     for (size_t i = t; i < n_chunks && e == hipSuccess; i += T, turn++) {
       const size_t off = i * CH, len = std::min(CH, bytes_ - off);
       int upto = q;
@@ -1164,14 +1173,23 @@ class PieceUpload {
       mark(upto);
       const int slot = (int)(turn % S);
       char* pin = ctx_->stage_pin + ((size_t)t * S + slot) * CH;
+      auto a = now();
       if (turn >= (size_t)S) e = hipEventSynchronize(ctx_->stage_ev[t][slot]);
+      t_wait += since(a);
       if (e != hipSuccess) break;
+      a = now();
       memcpy(pin, src_ + off, len);
-      e = hipMemcpyAsync(dst_ + off, pin, len, hipMemcpyHostToDevice, ctx_->stage_stream[t]);
-      if (e == hipSuccess) e = hipEventRecord(ctx_->stage_ev[t][slot], ctx_->stage_stream[t]);
+      t_copy += since(a);
+      a = now();
+      e = hipMemcpyAsync(dst_ + off, pin, len, hipMemcpyHostToDevice, ctx_->stage_stream[t % n_streams_]);
+      if (e == hipSuccess) e = hipEventRecord(ctx_->stage_ev[t][slot], ctx_->stage_stream[t % n_streams_]);
+      t_enq += since(a);
     }
+    if (MSM_KNOB_SET("MSM_UPLOAD_TRACE"))
+      fprintf(stderr, "upload thread %d: slot wait %.1f ms, host copy %.1f ms, enqueue %.1f ms, total %.1f ms\n", t, t_wait, t_copy, t_enq,
+              since(t0_));
     mark((int)ends_.size());   // on an error too: nobody may wait for ever
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx_->stage_stream[t]);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx_->stage_stream[t % n_streams_]);
     std::lock_guard<std::mutex> l(mu_);
     rc_[t] = e;
     const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0_).count();
@@ -1189,6 +1207,7 @@ class PieceUpload {
   std::condition_variable cv_;
   std::chrono::steady_clock::time_point t0_;
   float ms_ = 0;
+  long long n_streams_ = 2;   // copy streams the staging threads queue their chunks on (measured: 1, 2, 4 alike; 2 steadiest)
 };
 
 int stage_scalars(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const uint32_t** d_out) {
@@ -1211,9 +1230,13 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   // else is staged before the window groups start.
   std::vector<uint64_t> piece_end;   // pipelined upload: point index where piece q ends (the last = n)
   if (!on_device && n >= (1ull << 24)) {
+    // The link moves scalars ~4x as fast as the GPU consumes them (2 GB in ~40 ms against ~154 ms of MSM at 2^26), so
+    // every range may be ~4x its predecessor and still arrive before the GPU is done with the one before: 1/16, 3/16, the
+    // rest from 2^25 points; 1/8, 3/8, the rest below.  The first range is what the GPU waits for (2-3 ms); few ranges keep
+    // the sub-MSMs near full-size efficiency.
     const uint64_t gran = msm_ctx::STAGE_CHUNK / 32;   // scalars per staging chunk
-    const int shifts[3] = {3, 2, 1};                    // 1/8, 1/4, 1/2 of the points, then the rest
-    for (int i = n >= (1ull << 25) ? 0 : 1; i < 3; i++) piece_end.push_back(((n >> shifts[i]) / gran) * gran);
+    const int big = n >= (1ull << 25);
+    for (int sh : {big ? 4 : 3, big ? 2 : 1}) piece_end.push_back(((n >> sh) / gran) * gran);
     piece_end.push_back(n);
   }
   std::unique_ptr<PieceUpload> pipe;

@@ -380,6 +380,13 @@ def test_reference_shaped_api(gpu_ctx):
     out = par.msmUnsafe(sp, pp, 50, True, {"c": 6})
     exp = O.msm_batched_affine(sc, pts, c=6)
     assert out["result"].as_tuple() == exp and out["log"]
+    # {result, log} with the reference's log shape (src/msm-common.ts:176-214): parameters, "label... x.xms" lines, total last
+    import re
+
+    log = out["log"]
+    assert log[0][0]["c"] == 6 and log[0][0]["K"] == -(-127 // 6) and len(log) >= 7
+    assert all(re.fullmatch(r"[a-z &()]+\.\.\. \d+\.\dms", l[0]) for l in log[1:]) and log[-1][0].startswith("msm total... ")
+    assert par.msm(sp, pp, 50)["log"] == []
     # the reference's own way from `result` to bigints (scripts/msm-weierstrass.ts:89-91)
     scratch, sAffinePtr = cv.Field.getPointers(20), cv.Field.getPointer(cv.Affine.size)
     cv.Projective.toAffine(scratch, sAffinePtr, out["result"])
