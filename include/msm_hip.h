@@ -65,7 +65,9 @@ typedef struct msm_opts {
   int32_t unsafe;       /* accepted for API parity with msmUnsafe; the GPU path always handles edge cases */
   int32_t k_lo, k_hi;   /* window shard [k_lo, k_hi) for msm_window_sums; 0,0 = all windows */
   int32_t serial;       /* != 0: run the window groups one after the other on one stream (no overlap): phase_ms then
-                           hold exclusive kernel times -- used for roofline measurements */
+                           hold exclusive kernel times -- used for roofline measurements.  Every tree launch then has the
+                           chip to itself and takes the launch geometry of a lone window (128 instead of 512 pairs per
+                           lane and batch), which is what such a launch would ship with */
   int32_t no_glv;       /* != 0 (Weierstrass curves): no endomorphism split -- digits of the full scalar, K = ceil((b + 1) / c)
                            with b = bit length of q: the window structure of msmProjective / msmBasic
                            (src/parallel.ts:69-87, src/msm-basic.ts:56-91).  Same group element, 2x the additions */

@@ -1341,7 +1341,9 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       const int ka = groups[gi].ka, kb = groups[gi].kb;
       std::vector<uint32_t> part((size_t)(kb - ka) * pw);
       Plan pg = pl;
-      pg.lone = groups.size() == 1 && kb - ka == 1;
+      // a launch that has the chip to itself -- the one-window shard, or every launch of a serialised call (msm_opts.serial,
+      // the exclusive timing of the roofline) -- walks its pairs in four short batches instead of one long one (round_geom)
+      pg.lone = (groups.size() == 1 && kb - ka == 1) || (opts && opts->serial);
       if (groups[gi].piece >= 0) pipe->wait_piece(groups[gi].piece, ctx->ws[slot].stream);
       run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, part.data(), sts[slot], p_off);
       if (split_points) split_part[gi] = part;
