@@ -338,3 +338,59 @@ def test_workspace_limit_runs_windows_over_point_ranges(curve):
     again, info2 = ctx.run_device(dev, n, c=c)
     assert again.as_tuple() == ref.as_tuple() and info2["rounds"] == info0["rounds"]
     ctx.close()
+
+
+def test_shard_exchange_over_rccl_on_one_rank():
+    """The sharded path with its REAL backend: torch.distributed "nccl" (= RCCL) with a world of one rank on the box's GPU --
+    process-group initialisation with a device id, the pinned row -> device copy, `all_gather_into_tensor` on device tensors,
+    the event-timed collective and the one blocking copy back, for both shardings.  (Two ranks cannot share one GPU under
+    RCCL; the multi-rank form runs over gloo above and on the driver's multi-GPU node.)  Fresh child process."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = textwrap.dedent(f"""
+        import json, os, sys
+        sys.path.insert(0, {root!r})
+        import torch, torch.distributed as dist
+        from montgomery_amd.api import MsmContext
+        from montgomery_amd.distributed import PARTIAL_BYTES, ShardExchange, sharded_msm, sharded_msm_points
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        n = 1 << 18
+        ctx = MsmContext(device=0)
+        ctx.generate_points(n, seed=5)
+        dev, _ = ctx.generate_scalars(n, seed=6)
+        want, info = ctx.run_device(dev, n)
+        c, K = info["c"], info["K"]
+        ex = ShardExchange(PARTIAL_BYTES * K, torch.device("cuda", 0))
+        out = {{}}
+        for name in ("windows", "points"):
+            tm = {{}}
+            if name == "windows":
+                r = sharded_msm(lambda lo, hi: ctx.window_sums(dev, n, lo, hi, c=c, on_device=True)[0], K, c, device="cuda:0",
+                                curve=ctx.curve, timing=tm, exchange=ex)
+            else:
+                r = sharded_msm_points(lambda first, cnt: ctx.window_sums(dev + 32 * first, cnt, 0, K, c=c, on_device=True, point_lo=first)[0],
+                                       n, K, c, device="cuda:0", curve=ctx.curve, timing=tm, exchange=ex)
+            out[name] = {{"ok": r[1] == want.as_tuple(), "all_gather_ms": tm["all_gather_ms"]}}
+        out["backend"] = dist.get_backend()
+        dist.barrier()
+        dist.destroy_process_group()
+        ctx.close()
+        print(json.dumps(out))
+    """)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["backend"] == "nccl" and d["windows"]["ok"] and d["points"]["ok"], d
+    assert d["windows"]["all_gather_ms"] >= 0 and d["points"]["all_gather_ms"] >= 0

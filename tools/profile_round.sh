@@ -2,7 +2,7 @@
 # Profiling recipe for one round (run on the GPU box through gpurun):  tools/profile_round.sh r02
 # Writes rocprofv3 summaries under gpurun_out/prof_<tag>/; tools/collect_profiles.py copies the ones to keep into profiles/.
 set -x
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$(dirname "$0")/.."
 REPO=$PWD
 export TMPDIR=/tmp
@@ -20,10 +20,11 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace26 -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-other-configs > $OUT/trace26.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace20 -- python3 $REPO/bench.py --steps 5 --warmup 1 --log2n 20 --no-cpu-baseline --no-verify --no-other-configs > $OUT/trace20.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ed20 -- python3 $REPO/bench.py --curve ed377 --steps 5 --warmup 1 --log2n 20 > $OUT/trace_ed20.log 2>&1
-PM="python3 $REPO/bench.py --steps 1 --warmup 0 --log2n 24 --no-cpu-baseline --no-verify --no-other-configs"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PM > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PM > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pmc_sq -- $PM > $OUT/pmc_sq.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- $PM > $OUT/pmc_grbm.log 2>&1
+cd $REPO
+# the sharded path as the driver runs it, here with both ranks on the one GPU of the box (gloo): self-launched, both splits
+python bench.py --gpus 2 --dist-backend gloo --log2n 22 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_2rank_gloo_2p22.json 2> $OUT/bench_2rank.err
+[ -f montgomery_amd/msm_hip.node ] && node js/bench-msm.js 20 > $OUT/js_bench_2p20.txt 2>&1
+# PMC passes at the headline size (own runs, --pmc only): profiles/<tag>_pmc_2p26.json through tools/collect_pmc.py
+tools/pmc_headline.sh $TAG 26 > $OUT/pmc_headline.log 2>&1
 find $OUT -name "*.csv" -size +20M -delete
 ls -laR $OUT | head -80
