@@ -328,7 +328,7 @@ def main():
         torch.cuda.set_device(0)
 
     from montgomery_amd.api import AffineResult, MsmContext
-    from montgomery_amd.distributed import choose_split, point_shards, sharded_msm, sharded_msm_points, window_shards
+    from montgomery_amd.distributed import choose_split, choose_window, point_shards, sharded_msm, sharded_msm_points, window_shards
 
     n = 1 << args.log2n
     if args.curve == "ed377":
@@ -341,8 +341,18 @@ def main():
     # identical points on every rank; rank 0 keeps their discrete logs for the check of the result
     a_host = ctx.generate_points(n, seed=20261002, want_scalars=(verify and rank == 0), raw=True)
     c, K = ctx.plan(n, args.c or None)
-    shards = window_shards(K, world)
     split = "none" if world == 1 else (choose_split(n, world, K) if args.split == "auto" else args.split)
+
+    def plan_for(how):
+        """window size of one sharding (montgomery_amd.distributed.choose_window): the points split plans for a rank's share
+        of the points, the window split wants K divisible by the rank count; --c overrides both"""
+        if args.c or world == 1:
+            return ctx.plan(n, args.c or None)
+        return choose_window(lambda m, cc: ctx.plan(m, cc), n, world, how)
+
+    if world > 1:
+        c, K = plan_for(split)
+    shards = window_shards(K, world)
 
     dev = torch.device("cuda", local_rank)
     # fresh scalars per step, generated on the GPU before the timed region (resident in HBM); at most MAX_SCALAR_SETS
@@ -353,15 +363,16 @@ def main():
         ctx.generate_scalars(n, seed=1000 + i, into=t.data_ptr())
 
     ddev = dev if args.dist_backend == "nccl" else "cpu"
-    exchange = None
-    if world > 1:
+    exchanges = {}
+
+    def step(i, how, c=None, K=None):
+        if world == 1:
+            return ctx.run_device(scal[i % n_sets].data_ptr(), n, c=c_main)
         from montgomery_amd.distributed import PARTIAL_BYTES, ShardExchange
 
-        exchange = ShardExchange(PARTIAL_BYTES * K, ddev)   # one pinned row + device twin + gathered tensor for every step
-
-    def step(i, how):
-        if world == 1:
-            return ctx.run_device(scal[i % n_sets].data_ptr(), n, c=c)
+        if (how, K) not in exchanges:   # one pinned row + device twin + gathered tensor for every step of this sharding
+            exchanges[(how, K)] = ShardExchange(PARTIAL_BYTES * K, ddev)
+        exchange = exchanges[(how, K)]
         box = {}
 
         def my_window_sums(lo, hi):
@@ -391,11 +402,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_loop(how):
+    c_main = c
+
+    def timed_loop(how, c=None, K=None):
         """W untimed + K timed steps of one sharding, bracketed by barrier + device synchronisation; the time is the MAX over
         the ranks.  Returns (seconds, per-step ms, infos, last result, its scalar set, per-rank summaries)."""
+        shards = window_shards(K, world) if K else None
         for i in range(args.warmup):
-            step(i, how)
+            step(i, how, c, K)
         sync()
         t0 = time.perf_counter()
         infos, step_ms = [], []
@@ -403,7 +417,7 @@ def main():
         for i in range(args.steps):
             last_set = (args.warmup + i) % n_sets
             ts = time.perf_counter()
-            last, info = step(args.warmup + i, how)    # msm_run / the all-gather are synchronous: per-step wall time is meaningful
+            last, info = step(args.warmup + i, how, c, K)    # msm_run / the all-gather are synchronous: per-step wall time is meaningful
             step_ms.append((time.perf_counter() - ts) * 1e3)
             infos.append(info)
         sync()
@@ -434,13 +448,15 @@ def main():
         return bool(last is not None and last.as_tuple() == exp)
 
     failed = None
-    dt, step_ms, infos, last, last_set, ranks_info = timed_loop(split)
+    dt, step_ms, infos, last, last_set, ranks_info = timed_loop(split, c, K)
     other_splits = None
     if world > 1 and not args.no_other_splits:
         other = "points" if split == "windows" else "windows"
-        o_dt, o_step_ms, _, o_last, o_set, o_ranks = timed_loop(other)
+        o_c, o_K = plan_for(other)
+        o_dt, o_step_ms, _, o_last, o_set, o_ranks = timed_loop(other, o_c, o_K)
         if rank == 0:
-            other_splits = [{"split": other, "value": n * args.steps / o_dt, "unit": "points/s", "ms_per_step": o_dt / args.steps * 1e3,
+            other_splits = [{"split": other, "window_bits": o_c, "windows": o_K,
+                             "value": n * args.steps / o_dt, "unit": "points/s", "ms_per_step": o_dt / args.steps * 1e3,
                              **step_stats(o_step_ms), "verified": check(o_last, o_set) if verify else None, "ranks": o_ranks}]
 
     if rank == 0:
@@ -460,10 +476,23 @@ def main():
         excl = None
         pcie = None
         if world == 1:
+            # the same kernel under the round-3 plan (c = 16, K = 8: a third more pair additions, none of them through the
+            # chunk-ordered or descriptor paths) when the library picks a bigger window: the per-pair rate of the tree kernel
+            # where nothing but the kernel itself is in the way
+            c16 = None
+            if c > 16 and not args.c:
+                _, yi = ctx.run_device(scal[0].data_ptr(), n, c=16, serial=True)
+                y_ms, yp = yi["phase_ms"]["accumulate"], yi["n_pairs_algo"]
+                c16 = {"window_bits": 16, "windows": yi["K"], "accumulate_ms": y_ms, "pair_adds": yp,
+                       "int_mad_frac": yp * PAIR_MADS / (y_ms * 1e-3) / INT_MAD_PEAK, "ns_per_pair_add": y_ms * 1e6 / yp,
+                       "note": "one serialised step at c = 16 (the plan of rounds 1-3): more pair additions, all of them in the "
+                               "index-free rounds the kernel is fastest in; the shipped plan trades per-pair rate for 25 % fewer"}
             _, xi = ctx.run_device(scal[0].data_ptr(), n, c=c, serial=True)
             x_ms = xi["phase_ms"]["accumulate"]
             xp = xi["n_pairs_algo"]
             excl = {
+                "same_kernel_at_c16": c16,
+                "ns_per_pair_add": x_ms * 1e6 / xp,
                 "accumulate_ms": x_ms,
                 "pair_adds": xp,
                 "pair_adds_issued": xi["n_pairs"],

@@ -293,18 +293,19 @@ int fail_hip(msm_ctx* ctx, const HipFail& f) {
   catch (...) { return fail(ctx, MSM_ERR_INTERNAL, "unexpected exception"); }
 
 // GPU-tuned window size (the reference's table, src/msm-common.ts:25-41, was tuned for 16 CPU threads and copies
-// points).  Weierstrass + GLV (b + 1 = 127 or 128 bits): measured over N = 2^4 .. 2^26 (tools/small_sizes.py), c = 16
-// (K = 8, no degenerate top window, one window's counters fit the LDS) wins from N = 2^12 up -- by 20 % over c = 13
-// at 2^14 .. 2^18, where a smaller window mostly buys more rounds of fixed latency -- and c = 8 below.  From 2^27 points
-// the big windows (K = 7 / 6: a quarter fewer pair additions) win with the three-pass sort and the chunk-ordered round 1:
-// c = 21 at 2^27 (303 against 314 ms), c = 22 from 2^28 (601 against 643 ms); at 2^26 they are level with c = 16
-// (153 / 154 ms, profiles/r03_experiments.txt items 5 and 12) and c = 16 stays.
+// points).  Weierstrass + GLV (b + 1 = 127 or 128 bits): measured over N = 2^4 .. 2^28 (tools/small_sizes.py,
+// tools/knob_matrix.py), c = 16 (K = 8, no degenerate top window, one window's counters fit the LDS) wins from N = 2^12 to
+// 2^25 -- by 20 % over c = 13 at 2^14 .. 2^18, where a smaller window mostly buys more rounds of fixed latency -- and c = 8
+// below.  From 2^26 points the big windows (K = 7 / 6: a quarter fewer pair additions) win with the three-pass sort, the
+// chunk-ordered round 1 and, since round 4, the last descriptor rounds left to k_bucket_finish: 2^26 c = 22 149.2 against
+// 155.6 ms (2^25: 83.0 against 80.4, so c = 16 stays there), 2^27 c = 21 296 against 300 (c = 22) and 314 (c = 16), 2^28
+// c = 22 584 against 643 (profiles/r03_experiments.txt items 5 and 12, profiles/r04_experiments.txt item 8).
 // Twisted Edwards (b + 1 = 252, no inversion per round): a cost model over the window sizes whose top window is not
 // degenerate, ~9 multiplications per pair addition against ~64 per bucket; its picks are within 3 % of the best
 // measured ones.
 int pick_window(bool te, uint64_t n, int glv_max_bits) {
   // measured (profiles/r03_experiments.txt item 5): the mean bucket of the big windows wants ~128 entries
-  if (!te) return n >= (1ull << 28) ? 22 : n >= (1ull << 27) ? 21 : n >= 4096 ? 16 : 8;
+  if (!te) return n >= (1ull << 28) ? 22 : n >= (1ull << 27) ? 21 : n >= (1ull << 26) ? 22 : n >= 4096 ? 16 : 8;
   static const int cand_te[] = {4, 6, 7, 9, 12, 14, 16};
   const int b1 = 252;
   (void)glv_max_bits;
@@ -547,10 +548,43 @@ void reduce_buckets(msm_ctx* ctx, msm_ctx::Workspace& w, const uint4* fin, uint6
 }
 
 
+// Two window groups that run side by side on the two streams meet here between their sorts and their trees: neither tree
+// starts before BOTH sorts are done.  A tree kernel holds 2 x 226 of a SIMD's 512 VGPRs for the 512 steps of a workgroup, so a
+// sort still running when the other group's tree arrives finds no room for its workgroups and takes three to four times as
+// long (profiles/r04_experiments.txt items 1 and 8).  Groups with equal work (c = 16: 4 + 4 windows) reach this point together
+// anyway; groups with unequal sorts (c = 22: the top window holds 17 bits) do not.
+// Host side: both workers arrive after queueing their sorts and recording their event, then each makes its stream wait for the
+// other's event.  A worker that fails releases its partner (abort).
+class PairSync {
+ public:
+  // returns false if the partner will never arrive (it failed, or there is none)
+  bool arrive_and_wait(int pair, int n_pairs_expected) {
+    std::unique_lock<std::mutex> l(mu_);
+    if ((int)count_.size() < n_pairs_expected) count_.resize(n_pairs_expected, 0);
+    count_[pair]++;
+    cv_.notify_all();
+    cv_.wait(l, [&] { return count_[pair] >= 2 || aborted_; });
+    return count_[pair] >= 2;
+  }
+  void abort() {
+    std::lock_guard<std::mutex> l(mu_);
+    aborted_ = true;
+    cv_.notify_all();
+  }
+
+ private:
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<int> count_;
+  bool aborted_ = false;
+};
+
 // Partition sums P_k for windows [k_lo, k_hi) over the points [p_lo, p_lo + n) -> w.h_part[(k - k_lo) * 36 ...]
 // scalars: device pointer, n x 8 words.
+// before_tree: called once with the group's stream when everything up to the scatter has been queued (see PairSync).
 void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars_all, uint64_t p_lo, uint64_t n, const Plan& pl,
-                      int k_lo, int k_hi, uint32_t* h_partials_out, GroupStats& st, uint64_t p_off = 0) {
+                      int k_lo, int k_hi, uint32_t* h_partials_out, GroupStats& st, uint64_t p_off = 0,
+                      const std::function<void(hipStream_t)>* before_tree = nullptr) {
   hipStream_t s = w.stream;
   const uint32_t* d_scalars = d_scalars_all + p_lo * 8;   // scalar i of the call <-> resident point p_off + i
   p_lo += p_off;
@@ -761,12 +795,17 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     }
   }
   HIPCHK(hipEventRecord(w.ev[2], s));
+  if (before_tree) (*before_tree)(s);
+  HIPCHK(hipEventRecord(w.ev[5], s));   // the tree starts here (behind the partner group's sort, if there is one)
 
   // accumulation tree
   // Weierstrass: tail rounds run only until no bucket holds more than FINISH_MAX elements; k_bucket_finish ends it
   uint32_t FINISH_MAX = 32;
   MSM_KNOB(FINISH_MAX, "MSM_FINISH_MAX", 1);
-  uint32_t tail_min_pairs = 1u << 21;
+  // big windows (millions of small buckets per group): the last descriptor rounds pay a binary search over all buckets per
+  // pair and a launch each for a few million pair additions -- k_bucket_finish takes the last two or four elements of every
+  // bucket cheaper (2^26, c = 22: 154.3 -> 150.8 ms; profiles/r04_experiments.txt item 8)
+  uint32_t tail_min_pairs = pl.c >= 18 ? 1u << 23 : 1u << 21;
   MSM_KNOB(tail_min_pairs, "MSM_TAIL_MIN", 1);
   const bool use_finish = true;
   int r_stop = RT;
@@ -915,8 +954,8 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   float ms;
   HIPCHK(hipEventElapsedTime(&ms, w.ev[0], w.ev[1])); st.ms_digits += ms;
   HIPCHK(hipEventElapsedTime(&ms, w.ev[1], w.ev[2])); st.ms_sort += ms;
-  HIPCHK(hipEventElapsedTime(&ms, w.ev[2], w.ev[3])); st.ms_acc += ms;
-  HIPCHK(hipEventElapsedTime(&ms, w.ev[2], w.ev[6])); st.ms_r1 += ms;
+  HIPCHK(hipEventElapsedTime(&ms, w.ev[5], w.ev[3])); st.ms_acc += ms;
+  HIPCHK(hipEventElapsedTime(&ms, w.ev[5], w.ev[6])); st.ms_r1 += ms;
   HIPCHK(hipEventElapsedTime(&ms, w.ev[3], w.ev[4])); st.ms_red += ms;
 }
 
@@ -1276,6 +1315,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     int ka, kb;
     uint64_t p_lo, p_n;
     int piece;   // pipelined upload: the piece whose arrival the group waits for (-1: the scalars are in place)
+    int pair;    // the two groups with the same pair id run side by side and start their trees together (PairSync); -1: none
   };
   std::vector<Group> groups;
   // A single window (the 8-GPU shard) has no second window group to hide its sort and tails under: split it by
@@ -1301,24 +1341,27 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       const uint64_t cnt = piece_end[q] - lo;
       const int g = (nwin >= 2 && cnt >= (1ull << 22)) ? 2 : 1;
       const int per = std::max(1, std::min(wpg, (nwin + g - 1) / g));
-      for (int k = k_lo; k < k_hi; k += per) groups.push_back({k, std::min(k_hi, k + per), lo, cnt, (int)q});
+      const size_t first = groups.size();
+      for (int k = k_lo; k < k_hi; k += per) groups.push_back({k, std::min(k_hi, k + per), lo, cnt, (int)q, -1});
+      if (groups.size() - first == 2) groups[first].pair = groups[first + 1].pair = (int)q;
       lo = piece_end[q];
     }
   } else if (pieces > 1) {
     for (int k = k_lo; k < k_hi; k++)
       for (uint64_t q = 0; q < pieces; q++) {
         const uint64_t lo = n * q / pieces, hi = n * (q + 1) / pieces;
-        groups.push_back({k, k + 1, lo, hi - lo, -1});
+        groups.push_back({k, k + 1, lo, hi - lo, -1, -1});
       }
   } else {
     long long first_group = 0;   // experiment: windows in the first of two uneven groups
     MSM_KNOB(first_group, "MSM_WPG_A", 1);
     if (first_group > 0 && first_group < nwin) {
-      groups.push_back({k_lo, k_lo + (int)first_group, 0, n, -1});
-      groups.push_back({k_lo + (int)first_group, k_hi, 0, n, -1});
+      groups.push_back({k_lo, k_lo + (int)first_group, 0, n, -1, -1});
+      groups.push_back({k_lo + (int)first_group, k_hi, 0, n, -1, -1});
     } else {
-      for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg), 0, n, -1});
+      for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg), 0, n, -1, -1});
     }
+    if (groups.size() == 2) groups[0].pair = groups[1].pair = 0;
   }
   // does more than one group contribute to a window?  Then the sums of its ranges are added on the host below.
   bool split_points = false;
@@ -1333,6 +1376,13 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   }
   std::atomic<int> next{0};
   GroupStats sts[msm_ctx::N_WS];
+  const int nthreads = (opts && opts->serial) ? 1 : std::min<int>(msm_ctx::N_WS, (int)groups.size());
+  PairSync psync;
+  // Off: measured neutral where the groups' sorts differ (c = 22: 153.5 against 154.4 ms -- the stretched sort of one group
+  // was time the other group's tree had the chip to itself) and harmful where they are equal (c = 16: 159.9 against 157.3 --
+  // trees that start at the same instant walk their sweeps in step).  Kept as a knob of the tuning build.
+  long long want_pair_sync = 0;
+  MSM_KNOB(want_pair_sync, "MSM_PAIR_SYNC", 0);
   auto worker = [&](int slot) {
     HIPCHK(hipSetDevice(ctx->device));
     for (;;) {
@@ -1345,12 +1395,22 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       // the exclusive timing of the roofline) -- walks its pairs in four short batches instead of one long one (round_geom)
       pg.lone = (groups.size() == 1 && kb - ka == 1) || (opts && opts->serial);
       if (groups[gi].piece >= 0) pipe->wait_piece(groups[gi].piece, ctx->ws[slot].stream);
-      run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, part.data(), sts[slot], p_off);
+      // the partner group runs on the other workspace; its ev[2] closes its sort
+      const int pair = (nthreads == 2 && want_pair_sync) ? groups[gi].pair : -1;
+      const std::function<void(hipStream_t)> meet = [&, slot, pair](hipStream_t s) {
+        if (psync.arrive_and_wait(pair, (int)groups.size())) HIPCHK(hipStreamWaitEvent(s, ctx->ws[1 - slot].ev[2], 0));
+      };
+      try {
+        run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, part.data(), sts[slot], p_off,
+                         pair >= 0 ? &meet : nullptr);
+      } catch (...) {
+        psync.abort();   // the partner must not wait for a group that will not arrive
+        throw;
+      }
       if (split_points) split_part[gi] = part;
       else memcpy(&words[(size_t)(ka - k_lo) * pw], part.data(), part.size() * 4);
     }
   };
-  const int nthreads = (opts && opts->serial) ? 1 : std::min<int>(msm_ctx::N_WS, (int)groups.size());
   {
     // Whatever either worker throws (HIP failure, bad_alloc, ...) is re-raised here only after BOTH have stopped and both
     // group streams are idle: no queued kernel of a failed call may still run when the context is used again.
@@ -1921,6 +1981,15 @@ static int run_impl(msm_ctx* ctx, const void* scalars, const void* const* placed
   if ((opts ? opts->point_lo : 0) + n > ctx->n_points)
     return fail(ctx, MSM_ERR_NO_POINTS, "%s: points [%llu, +%llu) but %llu resident points", who,
                 (unsigned long long)(opts ? opts->point_lo : 0), (unsigned long long)n, (unsigned long long)ctx->n_points);
+  // Host scalars of a big call arrive range by range of the points (PieceUpload) and every range runs with the call's window:
+  // the first ranges are a sixteenth and three sixteenths of the input, so the window is picked for half the input rather than
+  // for all of it (2^26: c = 16 for every range 164.8 ms, c = 22 180.6 -- a 2^22-point range under 2^21 buckets per window)
+  msm_opts piped;
+  if (!placed && !on_device && n >= (1ull << 24) && !(opts && opts->c) && !ctx->is_te()) {
+    if (opts) piped = *opts; else memset(&piped, 0, sizeof piped);
+    piped.c = pick_window(false, n / 2, 0);
+    opts = &piped;
+  }
   Plan pl;
   if (make_plan(ctx, n, opts, pl)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);
   pl.merged = true;

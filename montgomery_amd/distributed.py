@@ -51,6 +51,23 @@ def point_shards(n: int, world: int) -> List[Tuple[int, int]]:
     return [(n * r // world, n * (r + 1) // world - n * r // world) for r in range(world)]
 
 
+def choose_window(plan: Callable[[int, Optional[int]], Tuple[int, int]], n: int, world: int, split: str) -> Tuple[int, int]:
+    """(c, K) for one MSM of n points sharded over `world` ranks; plan(n, c) -> (c, K) is the library's `msm_plan`.
+    by points: every rank runs a whole MSM over n / world points, so the window is the one the library picks for THAT size
+      (all ranks must use the same one: their window sums are added slot by slot);
+    by windows: the K windows are dealt to the ranks in contiguous ranges, so K should divide evenly -- the single-GPU pick
+      (c = 22, K = 6 at 2^26) leaves two of eight ranks without work, c = 16 (K = 8) gives every rank of 2, 4 or 8 the same."""
+    if world <= 1:
+        return plan(n, None)
+    if split == "points":
+        return plan(max(n // world, 1), None)
+    c, K = plan(n, None)
+    if K % world == 0:
+        return c, K
+    c16, K16 = plan(n, 16)
+    return (c16, K16) if -(-K16 // world) * K < -(-K // world) * K16 else (c, K)   # smaller share of the work on the busiest rank
+
+
 def choose_split(n: int, world: int, K: int) -> str:
     """'points' or 'windows' for one MSM of n points over `world` GPUs.  Measured per-rank work on one MI355X (2^26, K = 8,
     tools/shard_time.py, profiles/r03_shard_proxy.txt): points shards 79.9 / 42.8 / 22.3 ms against window shards

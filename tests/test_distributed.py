@@ -195,3 +195,23 @@ def test_point_shards_partition_and_group_combine():
     for first, count in ((0, 5), (5, 0), (5, 6)):
         parts += b"".join(_oracle_window_sums(sc[first:first + count], pts[first:first + count], c, K))
     assert combine_groups_host(parts, 3, K, c) == O.msm_batched_affine(sc, pts, c=c)
+
+
+def test_choose_window_for_shards():
+    """The window of a sharded MSM: by points the pick for a rank's share of the points; by windows a K the ranks divide
+    (the single-GPU pick at 2^26, c = 22 / K = 6, would leave two of eight ranks idle)."""
+    from montgomery_amd.distributed import choose_window
+
+    def plan(m, c):   # msm_plan of the BLS12-377 context: b + 1 = 127 bits
+        c = c or (22 if m >= 1 << 26 else 16)
+        return c, -(-127 // c)
+
+    n = 1 << 26
+    assert choose_window(plan, n, 1, "windows") == (22, 6)
+    assert choose_window(plan, n, 2, "windows") == (22, 6)      # 3 + 3 windows
+    assert choose_window(plan, n, 4, "windows") == (16, 8)      # 2 of 8 beats 2 of 6
+    assert choose_window(plan, n, 8, "windows") == (16, 8)      # 1 of 8 beats 1 of 6
+    assert choose_window(plan, n, 3, "windows") == (22, 6)
+    for world in (2, 4, 8):
+        assert choose_window(plan, n, world, "points") == (16, 8)   # a share of 2^25 or fewer points
+    assert choose_window(plan, 1 << 20, 8, "windows") == (16, 8)
