@@ -166,13 +166,33 @@ __global__ void __launch_bounds__(PS_BLOCK) k_pscan_final(const uint32_t* counts
 // the latency-critical batch-add kernel.  desc[e] = (index of the first operand << 1) | second operand present.
 // ---------------------------------------------------------------------------------------------
 
+// Big windows have millions of buckets (23 dependent loads per output in a plain binary search, 1.4 ms per call at 2^26 /
+// c = 22): the 256 consecutive outputs of a block belong to a short run of buckets, so the block's first and last lane
+// search the whole table once, and every lane then searches only that run (a handful of steps on lines the block has just
+// touched).
 __global__ void __launch_bounds__(256) k_tail_desc(uint32_t* desc, const uint32_t* off_in, const uint32_t* off_out, uint32_t nb,
                                                    uint32_t n_out) {
-  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t run[2];
+  const uint32_t e0 = blockIdx.x * blockDim.x;
+  const uint32_t e = e0 + threadIdx.x;
+#ifdef MSM_X_FLAT_TAIL_DESC   // experiment: every lane searches the whole table (the kernel of rounds 1-3)
+  if (threadIdx.x == 0) { run[0] = 0; run[1] = nb - 1; }
+#else
+  if (threadIdx.x == 0 || threadIdx.x == blockDim.x - 1) {
+    const uint32_t ee = min(threadIdx.x == 0 ? e0 : e0 + blockDim.x - 1, n_out - 1);
+    uint32_t lo = 0, hi = nb;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (off_out[mid] <= ee) lo = mid; else hi = mid;
+    }
+    run[threadIdx.x == 0 ? 0 : 1] = lo;
+  }
+#endif
+  __syncthreads();
   if (e >= n_out) return;
-  uint32_t lo = 0, hi = nb;
+  uint32_t lo = run[0], hi = run[1] + 1;   // the bucket of e lies in [run[0], run[1]]: off_out[lo] <= e < off_out[hi]
   while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
+    const uint32_t mid = (lo + hi) >> 1;
     if (off_out[mid] <= e) lo = mid; else hi = mid;
   }
   uint32_t j = e - off_out[lo];
