@@ -285,6 +285,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the known-discrete-log check of the last timed result")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-scalar (PCIe-inclusive) leg")
+    ap.add_argument("--no-c16", action="store_true", help="skip the serialised step at c = 16 (same_kernel_at_c16): counter runs "
+                                                          "then hold MSMs of one plan only")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the in-process runs of BASELINE configs[1] (2^20 BLS12-377) and configs[3] (2^20 Ed-on-BLS12-377)")
     ap.add_argument("--split", choices=["auto", "windows", "points"], default="windows",
@@ -480,7 +482,7 @@ def main():
             # chunk-ordered or descriptor paths) when the library picks a bigger window: the per-pair rate of the tree kernel
             # where nothing but the kernel itself is in the way
             c16 = None
-            if c > 16 and not args.c:
+            if c > 16 and not args.c and not args.no_c16:
                 _, yi = ctx.run_device(scal[0].data_ptr(), n, c=16, serial=True)
                 y_ms, yp = yi["phase_ms"]["accumulate"], yi["n_pairs_algo"]
                 c16 = {"window_bits": 16, "windows": yi["K"], "accumulate_ms": y_ms, "pair_adds": yp,
@@ -526,7 +528,7 @@ def main():
             p_ms, p_up = [], []
             for i in range(15):
                 tp = time.perf_counter()
-                got, pi = ctx.run(s_host, c=c)
+                got, pi = ctx.run(s_host, c=args.c or None)   # the library plans a host-scalar call itself (ranges of the points)
                 if i >= 5:
                     p_ms.append((time.perf_counter() - tp) * 1e3)
                     p_up.append(pi["phase_ms"]["upload"])

@@ -33,12 +33,14 @@ for kind in ("fetch", "write", "sq", "grbm"):
 
 # the bench line of the fetch pass: pair additions of the MSMs the run held (timed step + serialised step)
 pairs_algo = pairs_issued = msms = None
+window_bits = None
 for line in open(f"{src}/pmc_fetch.log", errors="ignore"):
     if line.startswith("{"):
         b = json.loads(line)
         msms = b["steps"] + b["warmup"] + 1
         pairs_algo = b["roofline"]["pair_adds_per_step"] * msms
         pairs_issued = b["roofline"]["pair_adds_issued_per_step"] * msms
+        window_bits = b["config"]["window_bits"]
 per_pair = {}
 if pairs_algo:
     def tot(kind, ctr, key):
@@ -50,7 +52,12 @@ if pairs_algo:
     # pair additions per kind of round: the gather round does half of a bucket's additions (n - 1 of them for n entries split
     # as n/2 in round 1, the rest later), so the split comes from the issued counts of the bench line where available
     half = pairs_algo / 2
-    for name, denom in (("gather_round", half), ("regular_rounds", half), ("all_rounds", pairs_algo)):
+    # the half / half split holds for windows of up to 16 bits (round 1 gathers, every other big round is index-free); bigger
+    # windows run rounds 1 and 2 in the gather kernel and most later ones through descriptors: only the total is meaningful
+    kinds = (("gather_round", half), ("regular_rounds", half), ("all_rounds", pairs_algo)) if window_bits <= 16 else (("all_rounds", pairs_algo),)
+    if window_bits > 16:
+        per_pair = {"all_rounds": per_pair["all_rounds"], "raw_totals_by_kernel_mode": {k: v for k, v in per_pair.items() if k != "all_rounds"}}
+    for name, denom in kinds:
         p = per_pair[name]
         p["pair_adds_basis"] = denom
         p["hbm_bytes_per_pair_add"] = (p["fetch_bytes_x2"] + p["write_bytes"]) / denom
@@ -61,7 +68,7 @@ json.dump({"command": f"rocprofv3 --pmc <one counter group per run: FETCH_SIZE |
            "note": "FETCH_SIZE / WRITE_SIZE in KB as reported (x 1024 below); FETCH_SIZE is doubled for HBM bytes (gfx950 halves wide "
                    "coalesced reads, MI355X_MICROARCH.md); SQ_* cycle counters in quad-cycles; GRBM_GUI_ACTIVE summed over the 8 XCDs. "
                    "Per-pair figures divide by algorithmic pair additions (half of them in the gather round).",
-           "msms_in_run": msms, "pair_adds_algorithmic": pairs_algo, "pair_adds_issued": pairs_issued,
+           "window_bits": window_bits, "msms_in_run": msms, "pair_adds_algorithmic": pairs_algo, "pair_adds_issued": pairs_issued,
            "per_pair_addition": per_pair, "effective_clock_ghz": clocks, "counters": out},
           open(f"profiles/{tag}_pmc_2p{lg}.json", "w"), indent=1)
 print("collected", tag, lg, json.dumps(per_pair.get("all_rounds", {})))

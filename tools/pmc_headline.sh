@@ -1,15 +1,15 @@
 #!/bin/bash
 # PMC passes over the HEADLINE configuration (2^26 by default), each counter group in its own rocprofv3 run (--pmc only, no
-# trace domains), as MI355X_MICROARCH.md prescribes.  usage: tools/pmc_headline.sh TAG [LOG2N]
+# trace domains), as MI355X_MICROARCH.md prescribes.  usage: tools/pmc_headline.sh TAG [LOG2N] [extra bench.py arguments, e.g. --c 16]
 # Every run holds two MSMs (the timed step and the serialised "exclusive" one); tools/collect_pmc.py TAG LOG2N turns the
 # counter files into profiles/<TAG>_pmc_2p<LOG2N>.json with per-pair-addition figures.
-TAG=${1:-r04}; LG=${2:-26}
+TAG=${1:-r04}; LG=${2:-26}; EXTRA="${@:3}"
 cd "$(dirname "$0")/.."
 REPO=$PWD
 export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/pmc_${TAG}_2p$LG
 rm -rf $OUT; mkdir -p $OUT
-PM="python3 $REPO/bench.py --steps 1 --warmup 0 --log2n $LG --no-cpu-baseline --no-verify --no-other-configs --no-pcie"
+PM="python3 $REPO/bench.py --steps 1 --warmup 0 --log2n $LG --no-cpu-baseline --no-verify --no-other-configs --no-pcie --no-c16 $EXTRA"
 cd /tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PM > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PM > $OUT/pmc_write.log 2>&1
