@@ -1304,7 +1304,13 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   int wpg = std::min(windows_per_group(ctx, n, pl), 128);
   // the radix-split and three-pass sorts describe their windows in a WinSplit of 16 entries (sort_kernels.h): a group that
   // may take one of them holds at most 16 windows (msmProjective with a small explicit window: K = 17 .. 29 at c = 15 .. 9)
-  if (pl.c - 1 > (int)RX_FINE_BITS) wpg = std::min(wpg, 16);
+  // (the one-level sort of small inputs -- a window's counters fit the LDS and fewer than 2^22 entries per window -- has no
+  // such table: Ed-on-BLS12-377 at 2^20 keeps its 18 windows in one group)
+  {
+    const uint64_t entries = ctx->is_te() ? n : 2 * n;
+    const bool fits_lds = ((size_t)pl.L * 4 <= 128 * 1024);
+    if (pl.c - 1 > (int)RX_FINE_BITS && (!fits_lds || entries >= (1ull << 22))) wpg = std::min(wpg, 16);
+  }
   const int nwin = k_hi - k_lo;
   // measured on MI355X: two groups win 14 % at 2^23 / 2^24, 3 % at 2^22, nothing at 2^21 -- below that the fixed
   // per-group latencies (read-backs, bucket reduction depth) cost more than the overlap returns
