@@ -214,9 +214,9 @@ struct msm_ctx {
   Workspace ws[N_WS];
 
   msm_host::Curve6 hc;
-  msm_host::Fe6 k_dev_to_host;  // 2^(768 - 30 NL): device Montgomery (radix 2^(30 NL)) -> host Montgomery (2^384)
+  msm_host::Fe6 k_dev_to_host;  // 2^(2 * 64 nl_host - 30 NL): device Montgomery (radix 2^(30 NL)) -> host Montgomery (2^384 or 2^256)
   msm_host::TeCurve6 hte;       // Ed-on-BLS12-377 over the 253-bit field (same 6-limb host field code)
-  msm_host::Fe6 k_te_to_host;   // 2^498: device Montgomery (2^270) -> host Montgomery (2^384)
+  msm_host::Fe6 k_te_to_host;   // 2^(512 - 270): device Montgomery (2^270) -> host Montgomery (2^256: four active limbs)
   bool is_te() const { return curve == MSM_CURVE_ED_ON_BLS12_377; }
   // per-field sizes (the reference sizes limbs per field, src/parallel.ts:53-57): 30-bit limbs in registers, packed words
   // per coordinate in memory, and the coordinate bytes at the ABI (wire points, results, test operands)
@@ -1707,12 +1707,12 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     return MSM_ERR_INTERNAL;
   }
   ctx->hc.F.init(curve == MSM_CURVE_ED_ON_BLS12_377 ? Fp377::PW : curve_info(curve).pw);   // (the Edwards context uses hte)
-  ctx->k_dev_to_host = ctx->hc.F.pow2(768 - 30 * ctx->nl());   // device radix 2^(30 NL): 2^378 for 13 limbs, 2^498 for 9
+  ctx->k_dev_to_host = ctx->hc.F.pow2(2 * ctx->hc.F.radix_bits() - 30 * ctx->nl());   // device radix 2^(30 NL); host radix 2^384 or 2^256
   {
     uint32_t pw[12] = {0};
     for (int i = 0; i < 8; i++) pw[i] = Fp253::PW[i];
     ctx->hte.init(pw, 3021);
-    ctx->k_te_to_host = ctx->hte.F.pow2(498);
+    ctx->k_te_to_host = ctx->hte.F.pow2(2 * ctx->hte.F.radix_bits() - 270);
   }
   *out = ctx;
   return MSM_OK;
