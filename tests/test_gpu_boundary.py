@@ -394,3 +394,41 @@ def test_shard_exchange_over_rccl_on_one_rank():
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert d["backend"] == "nccl" and d["windows"]["ok"] and d["points"]["ok"], d
     assert d["windows"]["all_gather_ms"] >= 0 and d["points"]["all_gather_ms"] >= 0
+
+
+def test_pipelined_host_scalars_error_paths():
+    """Failures while host scalars are still crossing PCIe behind the computation: a scalar >= q under msm_opts.strict in the
+    LAST range of the points (the call fails with MSM_ERR_SCALAR after all ranges ran), and a workspace limit that forces the
+    plain staged upload instead.  The context stays usable and the next call gives the right element."""
+    import ctypes as CT
+
+    from montgomery_amd import _lib
+    from montgomery_amd._lib import MsmOpts, MsmResult
+    from montgomery_amd.api import MsmContext
+
+    n = 1 << 24
+    ctx = MsmContext()
+    ctx.generate_points(n, seed=91)
+    dev, host = ctx.generate_scalars(n, seed=92, to_host=True, raw=True)
+    want, _ = ctx.run_device(dev, n)
+    bad = (CT.c_uint8 * (32 * n)).from_buffer_copy(host)
+    for j in range(32):
+        bad[32 * (n - 5) + j] = 0xFF     # 2^256 - 1 >= q, in the last range
+    out = MsmResult()
+    rc = ctx._lib.msm_run(ctx._h, bad, n, 0, CT.byref(MsmOpts(strict=1)), CT.byref(out))
+    assert rc == _lib.MSM_ERR_SCALAR
+    got, _ = ctx.run(host)             # the same context, the clean buffer: pipelined again
+    assert got.as_tuple() == want.as_tuple()
+    # without strict the bad scalar is reduced mod q: same element as the reduced value resident in HBM
+    rc = ctx._lib.msm_run(ctx._h, bad, n, 0, CT.byref(MsmOpts()), CT.byref(out))
+    assert rc == _lib.MSM_OK
+    dev2 = ctx.device_alloc(32 * n)
+    ctx.device_upload(dev2, bytes(bad))
+    ref, _ = ctx.run_device(dev2, n)
+    assert int.from_bytes(bytes(out.x), "little") == ref.x and int.from_bytes(bytes(out.y), "little") == ref.y
+    # a tight workspace makes the windows run over ranges of the points of their own: plain staged upload, same result
+    ctx.set_workspace_limit(3 << 30)
+    got, _ = ctx.run(host)
+    assert got.as_tuple() == want.as_tuple()
+    ctx.set_workspace_limit(0)
+    ctx.close()
