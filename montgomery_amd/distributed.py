@@ -140,6 +140,8 @@ class ShardExchange:
         elif timing is not None:
             timing["all_gather_ms"] = (time.perf_counter() - t0) * 1e3
         out = self.gathered.cpu().numpy().tobytes() if self.rank == 0 else None   # rank 0: the step's one blocking copy
+        if self.on_gpu and self.rank != 0:
+            torch.cuda.current_stream(self.device).synchronize()   # the pinned row is rewritten by the next step: its copy must be done
         if ev:
             ev[1].synchronize()
             timing["all_gather_ms"] = ev[0].elapsed_time(ev[1])
