@@ -53,16 +53,17 @@ def point_shards(n: int, world: int) -> List[Tuple[int, int]]:
 
 def choose_window(plan: Callable[[int, Optional[int]], Tuple[int, int]], n: int, world: int, split: str) -> Tuple[int, int]:
     """(c, K) for one MSM of n points sharded over `world` ranks; plan(n, c) -> (c, K) is the library's `msm_plan`.
-    by points: every rank runs a whole MSM over n / world points, so the window is the one the library picks for THAT size
-      (all ranks must use the same one: their window sums are added slot by slot);
-    by windows: the K windows are dealt to the ranks in contiguous ranges, so K should divide evenly -- the single-GPU pick
-      (c = 22, K = 6 at 2^26) leaves two of eight ranks without work, c = 16 (K = 8) gives every rank of 2, 4 or 8 the same."""
+    Either way a rank does 1 / world of the work of the whole MSM, so the window is the one the library picks for an input
+    of n / world points (all ranks must use the same one: their window sums meet slot by slot):
+    by points that IS the rank's input; by windows the rank runs K / world windows over all points, and the big windows a
+    single GPU takes from 2^26 points (c = 22, K = 6) neither divide among 4 or 8 ranks nor pay for a group of three
+    (tools/shard_time.py at 2^26, 2 ranks: 84.1 ms against 81 with c = 16).  If that K does not divide and c = 16 (K = 8)
+    does, c = 16 is taken when it leaves the busiest rank a smaller share."""
     if world <= 1:
         return plan(n, None)
-    if split == "points":
-        return plan(max(n // world, 1), None)
-    c, K = plan(n, None)
-    if K % world == 0:
+    c, K = plan(max(n // world, 1), None)
+    c, K = plan(n, c)   # (K for the call the ranks actually make)
+    if split == "points" or K % world == 0:
         return c, K
     c16, K16 = plan(n, 16)
     return (c16, K16) if -(-K16 // world) * K < -(-K // world) * K16 else (c, K)   # smaller share of the work on the busiest rank

@@ -208,10 +208,10 @@ def test_choose_window_for_shards():
 
     n = 1 << 26
     assert choose_window(plan, n, 1, "windows") == (22, 6)
-    assert choose_window(plan, n, 2, "windows") == (22, 6)      # 3 + 3 windows
-    assert choose_window(plan, n, 4, "windows") == (16, 8)      # 2 of 8 beats 2 of 6
-    assert choose_window(plan, n, 8, "windows") == (16, 8)      # 1 of 8 beats 1 of 6
-    assert choose_window(plan, n, 3, "windows") == (22, 6)
-    for world in (2, 4, 8):
-        assert choose_window(plan, n, world, "points") == (16, 8)   # a share of 2^25 or fewer points
+    for world in (2, 4, 8):                                     # a rank's share is 2^25 points or fewer: c = 16, K = 8 divides
+        assert choose_window(plan, n, world, "windows") == (16, 8)
+        assert choose_window(plan, n, world, "points") == (16, 8)
+    assert choose_window(plan, n, 3, "windows") == (16, 8)      # 3 of 8 windows on the busiest rank either way: keep the pick
+    assert choose_window(plan, 1 << 28, 2, "windows") == (22, 6)    # 2^27 points per rank: the big window, 3 + 3
+    assert choose_window(plan, 1 << 28, 4, "windows") == (16, 8)    # K = 6 leaves ranks with 2 of 6; 2 of 8 is less
     assert choose_window(plan, 1 << 20, 8, "windows") == (16, 8)

@@ -4,6 +4,7 @@ usage: python tools/shard_time.py [LOG2N]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from montgomery_amd.api import MsmContext
+from montgomery_amd.distributed import choose_window
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 26
 n = 1 << lg
 ctx = MsmContext()
@@ -18,19 +19,21 @@ def best_of(f, reps=3):
         t = time.perf_counter(); _, info = f(); best = min(best, time.perf_counter() - t)
     return best * 1e3, info
 
-full, _ = best_of(lambda: ctx.window_sums(dev, n, 0, K, c=c, on_device=True))
-print(f"2^{lg}, c = {c}, K = {K}: all windows, all points {full:.1f} ms")
+full, _ = best_of(lambda: ctx.run_device(dev, n))
+print(f"2^{lg}, c = {c}, K = {K}: full MSM {full:.1f} ms")
+plan = lambda m, cc: ctx.plan(m, cc)
 for G in (2, 4, 8):
-    if K % G == 0:
-        w = K // G
-        # the slowest window shard: the lowest windows are full, the top one is lighter
-        tw, iw = best_of(lambda: ctx.window_sums(dev, n, 0, w, c=c, on_device=True))
-        tt, _ = best_of(lambda: ctx.window_sums(dev, n, K - w, K, c=c, on_device=True))
-    else:
-        tw = tt = float("nan"); iw = None
+    # the windows each sharding runs with (choose_window: K the ranks divide / the pick for a rank's share of the points)
+    cw, Kw = choose_window(plan, n, G, "windows")
+    cp, Kp = choose_window(plan, n, G, "points")
+    w = -(-Kw // G)
+    # the slowest window shard: the lowest windows are full, the top one is lighter
+    tw, iw = best_of(lambda: ctx.window_sums(dev, n, 0, w, c=cw, on_device=True))
+    tt, _ = best_of(lambda: ctx.window_sums(dev, n, Kw - w, Kw, c=cw, on_device=True))
     m = n // G
     first = (G - 1) * m
-    tp, ip = best_of(lambda: ctx.window_sums(dev + 32 * first, m, 0, K, c=c, on_device=True, point_lo=first))
-    print(f"G = {G}: window shard {tw:.1f} ms (top windows {tt:.1f})  -> x{full / tw:.2f}   points shard {tp:.1f} ms -> x{full / tp:.2f}")
+    tp, ip = best_of(lambda: ctx.window_sums(dev + 32 * first, m, 0, Kp, c=cp, on_device=True, point_lo=first))
+    print(f"G = {G}: window shard (c = {cw}, {w} of {Kw} windows) {tw:.1f} ms (top windows {tt:.1f})  -> x{full / tw:.2f}   "
+          f"points shard (c = {cp}) {tp:.1f} ms -> x{full / tp:.2f}")
     print("   window phases", {k: round(v, 1) for k, v in (iw or {"phase_ms": {}})["phase_ms"].items()})
     print("   points phases", {k: round(v, 1) for k, v in ip["phase_ms"].items()})
