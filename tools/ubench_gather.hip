@@ -18,7 +18,9 @@ __device__ __forceinline__ uint64_t mix(uint64_t z) {
   return z ^ (z >> 31);
 }
 
-template <int PATTERN>
+// PIECES: 16-byte pieces read of every line -- 6 = x and y (both 64-byte sectors: the backward sweep), 3 = x alone (the first
+// sector: the forward sweep)
+template <int PATTERN, int PIECES = 6>
 __global__ void __launch_bounds__(256, 2) k_gather(const char* table, uint64_t lines, uint64_t win_lines, int steps, uint32_t* out) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   const uint32_t wave = t >> 6, lane = t & 63;
@@ -42,11 +44,11 @@ __global__ void __launch_bounds__(256, 2) k_gather(const char* table, uint64_t l
     }
     const uint4* pa = reinterpret_cast<const uint4*>(table + la * 128);
     const uint4* pb = reinterpret_cast<const uint4*>(table + lb * 128);
-    uint4 v[12];
+    uint4 v[2 * PIECES];
 #pragma unroll
-    for (int j = 0; j < 6; j++) { v[j] = pa[j]; v[6 + j] = pb[j]; }
+    for (int j = 0; j < PIECES; j++) { v[j] = pa[j]; v[PIECES + j] = pb[j]; }
 #pragma unroll
-    for (int j = 0; j < 12; j++) { acc.x ^= v[j].x; acc.y += v[j].y; acc.z ^= v[j].z; acc.w += v[j].w; }
+    for (int j = 0; j < 2 * PIECES; j++) { acc.x ^= v[j].x; acc.y += v[j].y; acc.z ^= v[j].z; acc.w += v[j].w; }
   }
   out[t] = acc.x ^ acc.y ^ acc.z ^ acc.w;
 }
@@ -75,6 +77,21 @@ int main(int argc, char** argv) {
     printf("pattern %d  range %8.0f MB  wave window %8.0f MB : %7.3f ms  %6.0f GB/s useful (192 B per lane-step)  %5.2f G lines/s\n", pattern,
            range_bytes / 1048576.0, win_bytes / 1048576.0, ms, useful / ms / 1e6, (double)blocks * 256 * steps * 2 / ms / 1e6);
   };
+  if (argc > 3) {   // x alone: three pieces of the first sector of every line
+    for (uint64_t wmb : {256ull, 1024ull}) {
+      float ms = 0;
+      const uint64_t wl = (wmb << 20) / 128;
+      for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(e0);
+        k_gather<1, 3><<<blocks, 256>>>(table, lines, wl, steps, out);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+      }
+      printf("pattern 1, first sector only (48 B per line)  wave window %8.0f MB : %7.3f ms  %5.2f G lines/s\n", wmb * 1.0, ms,
+             (double)blocks * 256 * steps * 2 / ms / 1e6);
+    }
+    return 0;
+  }
   for (uint64_t mb : {64ull, 256ull, 1024ull, 4096ull, (unsigned long long)(table_gb * 1024)}) run(0, mb << 20, 0);
   for (uint64_t wmb : {2ull, 32ull, 256ull, 1024ull, 4096ull}) run(1, bytes, wmb << 20);
   for (uint64_t wmb : {32ull, 256ull, 1024ull, 4096ull, (unsigned long long)(table_gb * 1024)}) run(2, bytes, wmb << 20);
