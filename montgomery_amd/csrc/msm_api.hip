@@ -445,8 +445,10 @@ void reduce_buckets(msm_ctx* ctx, msm_ctx::Workspace& w, const uint4* fin, uint6
   const uint64_t nb = (uint64_t)kc * L;
   const int part_words = te ? 32 : 36;
   // buckets per lane: enough lanes to fill the chip, but never more than 16 buckets deep (2 additions each)
+  // (millions of buckets -- the big windows -- go 32 deep: 2^26 at c = 22, with the two policies below, 150.6 -> 149.3 ms)
   uint32_t TC = 2;
-  while (TC < 16 && nb / TC > 65536) TC *= 2;
+  const uint32_t tc_cap = nb >= (1ull << 22) ? 32 : 16;
+  while (TC < tc_cap && nb / TC > 65536) TC *= 2;
   MSM_KNOB(TC, "MSM_TC", 1);
   TC = std::min<uint32_t>(TC, L);
   uint32_t nchunks = (L + TC - 1) / TC;
@@ -655,6 +657,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     // big inputs: finer slices also keep the round-1 gathers of neighbouring lanes inside one Infinity-Cache-sized
     // range of point rows (measured: 193 -> 183 ms at 2^26); small inputs: fewer, larger blocks (less fixed cost)
     uint64_t mult = two_n >= (1ull << 27) ? 8 : two_n >= (1ull << 24) ? 4 : 2;   // measured 2^21 .. 2^26
+    if (three_pass) mult = std::min<uint64_t>(mult, 4);   // the chunk-ordered round 1 makes its own locality: fewer, larger slices
     MSM_KNOB(mult, "MSM_SORTB_MULT", 1);
     uint64_t want = std::max<uint64_t>(1, (mult * ctx->n_cu + kc - 1) / kc);
     uint64_t maxb = std::max<uint64_t>(1, two_n / 8192);
@@ -800,7 +803,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
 
   // accumulation tree
   // Weierstrass: tail rounds run only until no bucket holds more than FINISH_MAX elements; k_bucket_finish ends it
-  uint32_t FINISH_MAX = 32;
+  uint32_t FINISH_MAX = pl.c >= 18 ? 64 : 32;
   MSM_KNOB(FINISH_MAX, "MSM_FINISH_MAX", 1);
   // big windows (millions of small buckets per group): the last descriptor rounds pay a binary search over all buckets per
   // pair and a launch each for a few million pair additions -- k_bucket_finish takes the last two or four elements of every
