@@ -305,10 +305,14 @@ int fail_hip(msm_ctx* ctx, const HipFail& f) {
 // measured ones.
 int pick_window(bool te, uint64_t n, int glv_max_bits) {
   // measured (profiles/r03_experiments.txt item 5): the mean bucket of the big windows wants ~128 entries
-  if (!te) return n >= (1ull << 28) ? 22 : n >= (1ull << 27) ? 21 : n >= (1ull << 26) ? 22 : n >= 4096 ? 16 : 8;
+  // b = 126 (BLS12-377 after GLV): 127 = 6 * 21 + 1, so 21-bit windows fold the carry bit into the sixth window (make_plan) --
+  // K = 6 with half the buckets of the 22-bit plan: 2^24 43.6 against 44.3 (c = 16), 2^25 79.7 against 80.7, 2^26 148.9 against
+  // 151.5 (c = 22) and 158.3 (c = 16), 2^27 302.8 against 311.5 (c = 22) on one box (profiles/r04_experiments.txt item 13).
+  // b = 127 (BLS12-381, Pallas): 128 = 5 * 22 + 18, the 22-bit plan has six whole windows from 2^26 points up.
+  if (!te && glv_max_bits == 126) return n >= (1ull << 24) ? 21 : n >= 4096 ? 16 : 8;
+  if (!te) return n >= (1ull << 26) ? 22 : n >= 4096 ? 16 : 8;
   static const int cand_te[] = {4, 6, 7, 9, 12, 14, 16};
   const int b1 = 252;
-  (void)glv_max_bits;
   int best = 4;
   double best_cost = 1e300;
   for (int i = 0; i < 7; i++) {
@@ -321,9 +325,10 @@ int pick_window(bool te, uint64_t n, int glv_max_bits) {
 }
 
 struct Plan {
-  int c, K, L_log;
+  int c, K, L_log;       // c: bits a window advances by (the weight of window k is 2^(c k)); L_log: bits of a bucket index
   int bits = 0;          // b + 1: scalar bits the windows cover (the top window holds bits - (K - 1) c of them)
-  uint32_t L;
+  bool fold = false;     // the top window is c + 1 bits wide (see make_plan)
+  uint32_t L;            // buckets per window = 2^L_log
   bool no_glv;
   bool strict = false;   // msm_opts.strict: scalars >= q fail the call instead of being reduced
   bool lone = false;   // one window, one group: nothing else shares the GPU (see round_geom)
@@ -334,7 +339,7 @@ struct Plan {
 int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
   const bool te = ctx && ctx->is_te();
   const int glv_bits = curve_info(ctx ? ctx->curve : MSM_CURVE_BLS12_377_G1).glv_max_bits;
-  int c = (opts && opts->c > 0) ? opts->c : pick_window(te, n, glv_bits);
+  int c = (opts && opts->c > 0) ? opts->c : pick_window(te, n, (opts && opts->no_glv) ? 0 : glv_bits);
   if (c < 2 || c > 24) return MSM_ERR_ARG;
   // b = Scalar.maxBits (126 after GLV, src/wasm/glv.ts:216-226) or Scalar.sizeInBits (251, src/msm-basic.ts:56)
   // b = Scalar.maxBits after GLV (src/wasm/glv.ts:216-226), or the bit length of q without it (src/msm-basic.ts:56)
@@ -346,7 +351,20 @@ int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
   pl.K = (b + 1 + c - 1) / c;  // K = ceil((b + 1) / c), src/msm-batched-affine.ts:90, src/msm-basic.ts:59
   pl.bits = b + 1;
   pl.L_log = c - 1;
-  pl.L = 1u << (c - 1);
+  // K c >= b + 1 keeps the carry of the signed recoding inside the top window (src/msm-batched-affine.ts:183-193).  When
+  // b + 1 = (K - 1) c + 1 -- BLS12-377 after GLV: 127 = 7 * 18 + 1 = 6 * 21 + 1 -- that top window holds the carry bit and
+  // nothing else: every entry with a carry lands in its bucket 1, a full window's worth of tree work for one bit (c = 21 at
+  // 2^26: seven windows in 155 ms, six of 22 bits in 149).  The big-window plans fold that bit into the window below instead:
+  // K - 1 windows, the top one c + 1 bits wide and not recoded (its magnitude is at most 2^c, it cannot carry out), the
+  // others as before.  Every window gets 2^c buckets (the lower ones fill the lower half); window k still weighs 2^(c k),
+  // so sums, shards and msm_combine are unchanged.  Only for c >= 18: those windows sort with per-window effective bits
+  // (WinSplit) already.
+  pl.fold = !te && c >= 18 && pl.K > 1 && (b + 1) - (pl.K - 1) * c == 1;
+  if (pl.fold) {
+    pl.K -= 1;
+    pl.L_log = c;
+  }
+  pl.L = 1u << pl.L_log;
   return MSM_OK;
 }
 
@@ -438,8 +456,9 @@ void host_to_partial(const msm_ctx*, const msm_host::Proj6& P, uint32_t* out36) 
 // sums, src/msm-batched-affine.ts:556-583, :312-319) -> h_partials_out, kc x 36 (32 on the Edwards path) words.  The bucket
 // sums come as projective points from k_bucket_finish (`bucket_proj`) or as the first element of every bucket in the tree
 // buffer (`fin`, `off_fin`).  Runs on w.stream, records w.ev[4] behind its last kernel and returns when the sums are on the host.
+// stride: bits a window advances by (Plan::c); 0 = log2(L) + 1, the plain plan's c.
 void reduce_buckets(msm_ctx* ctx, msm_ctx::Workspace& w, const uint4* fin, uint64_t fin_cap, const uint32_t* off_fin,
-                    const uint32_t* bucket_proj, uint32_t L, int kc, uint32_t* h_partials_out, bool merged = false) {
+                    const uint32_t* bucket_proj, uint32_t L, int kc, uint32_t* h_partials_out, bool merged = false, int stride = 0) {
   hipStream_t s = w.stream;
   const bool te = ctx->is_te();
   const uint64_t nb = (uint64_t)kc * L;
@@ -512,14 +531,20 @@ void reduce_buckets(msm_ctx* ctx, msm_ctx::Workspace& w, const uint4* fin, uint6
       // kk the sum S_b sits at bit log2(TC) + b, the triangle sum at bit 0 -- with c kc doublings instead of (c - 1) kc for
       // the windows plus c (kc - 1) for their combination.  S_g goes into the slot of the group's first window, the identity
       // into the others: sum_k 2^(c k) (slot k) is the same group element as with one P_k per slot.
+      // With a folded top window (Plan::fold) a window has one bit position more than it advances by: position `stride` of
+      // window kk coincides with position 0 of window kk + 1, so the pass walks GLOBAL bit positions and adds what every
+      // window has there.
       uint32_t lt = 0, cbits = 1;
       while ((1u << lt) < TC) lt++;
       while ((1u << (cbits - 1)) < L) cbits++;
+      const int adv = stride ? stride : (int)cbits;
       msm_host::Proj6 acc = C.zero();
-      for (int kk = kc - 1; kk >= 0; kk--) {
-        const uint32_t* base = w.h_part + (size_t)kk * (nbits + 1) * 36;
-        for (int pos = (int)cbits - 1; pos >= 0; pos--) {
-          acc = C.dbl(acc);
+      for (int gpos = (kc - 1) * adv + (int)cbits - 1; gpos >= 0; gpos--) {
+        acc = C.dbl(acc);
+        for (int kk = kc - 1; kk >= 0; kk--) {
+          const int pos = gpos - kk * adv;
+          if (pos < 0 || pos >= (int)cbits) continue;
+          const uint32_t* base = w.h_part + (size_t)kk * (nbits + 1) * 36;
           const int b = pos - (int)lt;
           if (b >= 0 && b < (int)nbits) acc = C.add(acc, partial_to_host(ctx, base + (size_t)b * 36));
           if (pos == 0) acc = C.add(acc, partial_to_host(ctx, base + (size_t)nbits * 36));
@@ -605,7 +630,8 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   // Big buckets (>= 1024 entries) take G = mean / 32: a quarter of the pads (1/64 instead of 1/16 of all slots are identity
   // pairs that occupy a lane for nothing) for more k_bucket_finish work, which is negligible there (2^26: 152.7 -> 152.1 ms
   // from 16 to 32, no further gain at 64; profiles/r04_experiments.txt item 6).
-  uint64_t mean = std::max<uint64_t>(1, two_n / L);
+  // (a folded plan allocates 2^c buckets per window and its lower windows fill half of them)
+  uint64_t mean = std::max<uint64_t>(1, two_n / (pl.fold ? L / 2 : L));
   uint64_t per_bucket_left = mean >= 1024 ? 32 : 8;
   MSM_KNOB(per_bucket_left, "MSM_PBL", 1);
   uint32_t logG = 1;
@@ -622,7 +648,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   //   one level  : a window's counters fit the LDS (c <= 16) and the input is small
   //   two passes : c <= 16, big inputs -- 2^(c-8) coarse bins x 128 buckets
   //   three passes: c > 16 (up to c = 24, the largest window make_plan accepts) -- coarse bins x mid bins x 128 (256) buckets
-  const int cbits = pl.c - 1;   // bits of a bucket index
+  const int cbits = pl.L_log;   // bits of a bucket index
   const bool fits_lds = (size_t)L * 4 <= 128 * 1024;
   long long want_radix = (fits_lds && cbits > (int)RX_FINE_BITS && two_n >= (1ull << 22)) ? 1 : 0;   // measured: wins from N = 2^21 up
   MSM_KNOB(want_radix, "MSM_RADIX", 0);
@@ -640,7 +666,9 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
     const int lp_log = cbits - (int)fb;
     for (int kk = 0; kk < kc; kk++) {
       // bits the digits of this window really have: the top window of a scalar is usually short (sort_kernels.h, WinSplit)
-      const int eff = std::max(1, std::min(cbits, pl.bits - (k_lo + kk) * pl.c));
+      // (a window below the top one holds signed digits of magnitude <= 2^(c - 1); the top one what is left of the scalar)
+      const bool top = k_lo + kk == pl.K - 1;
+      const int eff = std::max(1, top ? std::min(cbits, pl.bits - (k_lo + kk) * pl.c) : std::min(cbits, pl.c - 1));
       const int fbk = std::max(0, eff - lp_log);
       const int hi = eff - fbk;
       ws.fb[kk] = (uint8_t)fbk;
@@ -677,7 +705,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
                          k_lo, kc, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p);
     else
       W_LAUNCH(ctx, k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K, k_lo, kc,
-                         pl.no_glv ? 0 : 1, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p);
+                         (pl.no_glv ? 0 : 1) | (pl.fold ? 2 : 0), pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p);
   }
   HIPCHK(hipEventRecord(w.ev[1], s));
   if (!three_pass) {
@@ -953,7 +981,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   if (total_slots == 0) HIPCHK(hipEventRecord(w.ev[6], s));
   HIPCHK(hipEventRecord(w.ev[3], s));
 
-  reduce_buckets(ctx, w, fin, fin_cap, off_fin, bucket_proj, L, kc, h_partials_out, pl.merged);
+  reduce_buckets(ctx, w, fin, fin_cap, off_fin, bucket_proj, L, kc, h_partials_out, pl.merged, pl.c);
   float ms;
   HIPCHK(hipEventElapsedTime(&ms, w.ev[0], w.ev[1])); st.ms_digits += ms;
   HIPCHK(hipEventElapsedTime(&ms, w.ev[1], w.ev[2])); st.ms_sort += ms;
@@ -1991,12 +2019,13 @@ static int run_impl(msm_ctx* ctx, const void* scalars, const void* const* placed
     return fail(ctx, MSM_ERR_NO_POINTS, "%s: points [%llu, +%llu) but %llu resident points", who,
                 (unsigned long long)(opts ? opts->point_lo : 0), (unsigned long long)n, (unsigned long long)ctx->n_points);
   // Host scalars of a big call arrive range by range of the points (PieceUpload) and every range runs with the call's window:
-  // the first ranges are a sixteenth and three sixteenths of the input, so the window is picked for half the input rather than
-  // for all of it (2^26: c = 16 for every range 164.8 ms, c = 22 180.6 -- a 2^22-point range under 2^21 buckets per window)
+  // the first ranges are a sixteenth and three sixteenths of the input, so the window is picked for an eighth of the input
+  // rather than for all of it (2^26: c = 16 for every range 164.8 ms, c = 22 180.6 -- a 2^22-point range under 2^21 buckets
+  // per window)
   msm_opts piped;
   if (!placed && !on_device && n >= (1ull << 24) && !(opts && opts->c) && !ctx->is_te()) {
     if (opts) piped = *opts; else memset(&piped, 0, sizeof piped);
-    piped.c = pick_window(false, n / 2, 0);
+    piped.c = pick_window(false, n / 8, (opts && opts->no_glv) ? 0 : curve_info(ctx->curve).glv_max_bits);
     opts = &piped;
   }
   Plan pl;

@@ -192,9 +192,13 @@ MSM_DEV bool words8_ge(const uint32_t (&a)[8], const uint32_t* q) {
 }
 
 // windows [k_lo, k_lo + k_cnt) of K_total are emitted (window groups / multi-GPU window shards)
+// glv: bit 0 = endomorphism split, bit 1 = folded top window (Plan::fold, msm_api.hip): window K_total - 1 is c + 1 bits wide
+// and keeps its value as it is -- at most 2^c, it cannot carry out.
 template <class CV>
 __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, const uint32_t* scalars, uint32_t n, int c, int k_total,
-                                                int k_lo, int k_cnt, int glv, int strict, uint32_t* err) {
+                                                int k_lo, int k_cnt, int glv_flags, int strict, uint32_t* err) {
+  const int glv = glv_flags & 1;
+  const bool fold = glv_flags & 2;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -220,8 +224,9 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, const uint32_t* s
     // first entry of the point; the endomorphism entry stays empty (digit 0 is never sorted)
     uint32_t carry = 0;
     for (int k = 0; k < k_total; k++) {
-      uint32_t l = bn_bits<8>(s, k * c, c) + carry;
-      if (l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
+      const bool top = fold && k == k_total - 1;
+      uint32_t l = bn_bits<8>(s, k * c, top ? c + 1 : c) + carry;
+      if (!top && l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
       int kk = k - k_lo;
       if (kk >= 0 && kk < k_cnt) {
         dig[(uint64_t)kk * two_n + 2ull * i] = l | (carry << 31);
@@ -236,8 +241,9 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, const uint32_t* s
   for (int hh = 0; hh < 2; hh++) {
     uint32_t carry = 0;
     for (int k = 0; k < k_total; k++) {
-      uint32_t l = bn_bits<4>(h[hh].mag, k * c, c) + carry;
-      if (l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
+      const bool top = fold && k == k_total - 1;
+      uint32_t l = bn_bits<4>(h[hh].mag, k * c, top ? c + 1 : c) + carry;
+      if (!top && l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
       int kk = k - k_lo;
       if (kk >= 0 && kk < k_cnt) {
         uint32_t neg = carry ^ (h[hh].neg ? 1u : 0u);

@@ -53,20 +53,20 @@ def point_shards(n: int, world: int) -> List[Tuple[int, int]]:
 
 def choose_window(plan: Callable[[int, Optional[int]], Tuple[int, int]], n: int, world: int, split: str) -> Tuple[int, int]:
     """(c, K) for one MSM of n points sharded over `world` ranks; plan(n, c) -> (c, K) is the library's `msm_plan`.
-    Either way a rank does 1 / world of the work of the whole MSM, so the window is the one the library picks for an input
-    of n / world points (all ranks must use the same one: their window sums meet slot by slot):
-    by points that IS the rank's input; by windows the rank runs K / world windows over all points, and the big windows a
-    single GPU takes from 2^26 points (c = 22, K = 6) neither divide among 4 or 8 ranks nor pay for a group of three
-    (tools/shard_time.py at 2^26, 2 ranks: 84.1 ms against 81 with c = 16).  If that K does not divide and c = 16 (K = 8)
-    does, c = 16 is taken when it leaves the busiest rank a smaller share."""
+    All ranks must use the same window: their window sums meet slot by slot.
+    by points: every rank runs a whole MSM over n / world points -- the window the library picks for THAT size;
+    by windows: a rank runs K / world windows over all points.  The big windows a single GPU takes from 2^24 points (K = 6)
+      neither divide among 4 or 8 ranks nor pay for a shard of three windows, which has no second window group of its own
+      size beside it (tools/shard_time.py at 2^26, 2 ranks: 84.1 ms with three 22-bit windows against 81 with four 16-bit
+      ones): c = 16 (K = 8) whenever the ranks divide its windows, else the pick for a rank's share of the points."""
     if world <= 1:
         return plan(n, None)
-    c, K = plan(max(n // world, 1), None)
-    c, K = plan(n, c)   # (K for the call the ranks actually make)
-    if split == "points" or K % world == 0:
-        return c, K
-    c16, K16 = plan(n, 16)
-    return (c16, K16) if -(-K16 // world) * K < -(-K // world) * K16 else (c, K)   # smaller share of the work on the busiest rank
+    if split != "points":
+        c16, K16 = plan(n, 16)
+        if K16 % world == 0:
+            return c16, K16
+    c, _ = plan(max(n // world, 1), None)
+    return plan(n, c)   # (K for the call the ranks actually make)
 
 
 def choose_split(n: int, world: int, K: int) -> str:

@@ -202,16 +202,16 @@ def test_choose_window_for_shards():
     (the single-GPU pick at 2^26, c = 22 / K = 6, would leave two of eight ranks idle)."""
     from montgomery_amd.distributed import choose_window
 
-    def plan(m, c):   # msm_plan of the BLS12-377 context: b + 1 = 127 bits
-        c = c or (22 if m >= 1 << 26 else 16)
-        return c, -(-127 // c)
+    def plan(m, c):   # msm_plan of the BLS12-377 context: b + 1 = 127 bits, the carry bit folded for c = 18 and 21
+        c = c or (21 if m >= 1 << 24 else 16)
+        return c, -(-127 // c) - (1 if c in (18, 21) else 0)
 
     n = 1 << 26
-    assert choose_window(plan, n, 1, "windows") == (22, 6)
-    for world in (2, 4, 8):                                     # a rank's share is 2^25 points or fewer: c = 16, K = 8 divides
-        assert choose_window(plan, n, world, "windows") == (16, 8)
-        assert choose_window(plan, n, world, "points") == (16, 8)
-    assert choose_window(plan, n, 3, "windows") == (16, 8)      # 3 of 8 windows on the busiest rank either way: keep the pick
-    assert choose_window(plan, 1 << 28, 2, "windows") == (22, 6)    # 2^27 points per rank: the big window, 3 + 3
-    assert choose_window(plan, 1 << 28, 4, "windows") == (16, 8)    # K = 6 leaves ranks with 2 of 6; 2 of 8 is less
+    assert choose_window(plan, n, 1, "windows") == (21, 6)
+    for world in (2, 4, 8):
+        assert choose_window(plan, n, world, "windows") == (16, 8)      # K = 8 divides: every rank the same number of windows
+    assert choose_window(plan, n, 2, "points") == (21, 6)               # a share of 2^25 points: the library's pick for it
+    assert choose_window(plan, n, 4, "points") == (21, 6)
+    assert choose_window(plan, n, 8, "points") == (16, 8)               # 2^23 points per rank
+    assert choose_window(plan, n, 3, "windows") == (21, 6)              # 8 does not divide by 3: the pick for a rank's share
     assert choose_window(plan, 1 << 20, 8, "windows") == (16, 8)
