@@ -627,12 +627,13 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
 
   // padding granule G = 2^g: about 1/8 of the mean bucket population (pads cost G/2 slots per bucket; what is
   // left after g regular rounds, ~8 elements per bucket, is finished without inversions by k_bucket_finish)
-  // Big buckets (>= 1024 entries) take G = mean / 32: a quarter of the pads (1/64 instead of 1/16 of all slots are identity
-  // pairs that occupy a lane for nothing) for more k_bucket_finish work, which is negligible there (2^26: 152.7 -> 152.1 ms
-  // from 16 to 32, no further gain at 64; profiles/r04_experiments.txt item 6).
-  // (a folded plan allocates 2^c buckets per window and its lower windows fill half of them)
-  uint64_t mean = std::max<uint64_t>(1, two_n / (pl.fold ? L / 2 : L));
-  uint64_t per_bucket_left = mean >= 1024 ? 32 : 8;
+  // Bigger buckets leave more: pads are identity pairs that occupy a lane for nothing (mean / (2 * left) of all slots), and
+  // k_bucket_finish is cheap next to them.  Measured (profiles/r04_experiments.txt items 6 and 14, best `left` per mean bucket):
+  // 64 entries 8 with 16-bit windows (2^20: 3.89 against 3.93 ms) but 16 with the big ones (2^25: 81.5 -> 79.9);
+  // 128 .. 256: 16 (2^21 6.92 -> 6.88, 2^22 12.45 -> 12.17, Ed-377 2^20 2.64 -> 2.59, 2^26 145.7 -> 142.5, 2^27 304.9 -> 301.8);
+  // from 512: 32 (2^23 22.65 -> 22.18, 2^26 at c = 16 152.7 -> 152.1); 32 entries: 8 (2^24: 16 costs 8 %).
+  uint64_t mean = std::max<uint64_t>(1, two_n / (pl.fold ? L / 2 : L));   // (a folded plan's lower windows fill half their buckets)
+  uint64_t per_bucket_left = mean >= 512 ? 32 : (mean >= 128 || (mean >= 64 && pl.c >= 18)) ? 16 : 8;
   MSM_KNOB(per_bucket_left, "MSM_PBL", 1);
   uint32_t logG = 1;
   while (logG < 10 && (1ull << (logG + 1)) * per_bucket_left <= mean) logG++;
