@@ -191,6 +191,7 @@ struct msm_ctx {
   static constexpr int STAGE_THREADS = 4, STAGE_SLOTS = 2;
   static constexpr size_t STAGE_CHUNK = (size_t)16 << 20;
   char* stage_pin = nullptr;
+  bool staging_ready = false;      // pinned slots, copy streams and events all exist (ensure_staging)
   hipStream_t stage_stream[STAGE_THREADS] = {};
   hipEvent_t stage_ev[STAGE_THREADS][STAGE_SLOTS + 1] = {};
   static constexpr int MAX_PIECES = 4;   // ranges of the points a host-scalar MSM is pipelined over (PieceUpload)
@@ -1119,16 +1120,20 @@ void te_horner_to_affine(const msm_ctx* ctx, const std::vector<uint32_t>& words,
 // Ordered into ctx->stream: work queued there afterwards sees the whole buffer.
 void ensure_staging(msm_ctx* ctx) {
   constexpr int T = msm_ctx::STAGE_THREADS, S = msm_ctx::STAGE_SLOTS;
-  if (ctx->stage_pin) return;
-  HIPCHK(hipHostMalloc((void**)&ctx->stage_pin, (size_t)T * S * msm_ctx::STAGE_CHUNK, hipHostMallocDefault));
-  int prio_lo = 0, prio_hi = 0;   // (numerically lower = higher priority)
+  if (ctx->staging_ready) return;
+  // (a failure half way leaves what exists in place: the next call creates only what is still missing)
+  if (!ctx->stage_pin) HIPCHK(hipHostMalloc((void**)&ctx->stage_pin, (size_t)T * S * msm_ctx::STAGE_CHUNK, hipHostMallocDefault));
+  int prio_lo = 0, prio_hi = 0;   // least and greatest priority (numerically lower = higher)
   HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   for (int t = 0; t < T; t++) {
-    // copies queued while kernels hold the chip should not wait behind them: highest priority the device offers
-    HIPCHK(hipStreamCreateWithPriority(&ctx->stage_stream[t], hipStreamNonBlocking, prio_hi));
-    for (int q = 0; q <= S; q++) HIPCHK(hipEventCreateWithFlags(&ctx->stage_ev[t][q], hipEventDisableTiming));
-    for (int q = 0; q < msm_ctx::MAX_PIECES; q++) HIPCHK(hipEventCreateWithFlags(&ctx->piece_ev[q][t], hipEventDisableTiming));
+    // copies queued while kernels hold the chip must not wait behind them: highest priority the device offers
+    if (!ctx->stage_stream[t]) HIPCHK(hipStreamCreateWithPriority(&ctx->stage_stream[t], hipStreamNonBlocking, prio_hi));
+    for (int q = 0; q <= S; q++)
+      if (!ctx->stage_ev[t][q]) HIPCHK(hipEventCreateWithFlags(&ctx->stage_ev[t][q], hipEventDisableTiming));
+    for (int q = 0; q < msm_ctx::MAX_PIECES; q++)
+      if (!ctx->piece_ev[q][t]) HIPCHK(hipEventCreateWithFlags(&ctx->piece_ev[q][t], hipEventDisableTiming));
   }
+  ctx->staging_ready = true;
 }
 
 void upload_staged(msm_ctx* ctx, void* dst, const void* src, size_t bytes) {
