@@ -532,3 +532,42 @@ def test_single_window_shards_split_by_points(gpu_ctx):
     # two-window shards (4-GPU case) take the ordinary path
     parts2 = b"".join(gpu_ctx.window_sums(dev, n, k, k + 2, c=16, on_device=True)[0] for k in range(0, K, 2))
     assert parts2 == parts or gpu_ctx.combine(parts2, K, 16).as_tuple() == full.as_tuple()
+
+
+def test_folded_top_window(gpu_ctx):
+    """Windows of 18 and 21 bits on BLS12-377 (127 = 7 * 18 + 1 = 6 * 21 + 1; `msmProjective`: 254 = 11 * 23 + 1): the top window
+    would hold the carry bit of the signed recoding alone, so the plan folds it into the window below -- one window less, the
+    top one c + 1 bits wide and not recoded, weights 2^(c k) unchanged.  Same group element as the oracle and as the plain plan,
+    through full MSMs, one-window shards + msm_combine, and scalars whose halves sit at the edges of the recoding."""
+    from montgomery_amd.distributed import combine_host
+
+    pts, _ = O.random_points_bls377("gpu/fold", 300)
+    sc = O.prng_ints("gpu/fold/s", 300, C.q)
+    gpu_ctx.set_points(O.points_to_bytes(pts, 48))
+    exp = O.msm_batched_affine(sc, pts, c=16)
+    for c, K in ((18, 7), (21, 6)):
+        res, info = gpu_ctx.run(O.scalars_to_bytes(sc), c=c)
+        assert (info["c"], info["K"]) == (c, K) and res.as_tuple() == exp, info
+    for lg in (12, 18, 21):
+        n = 1 << lg
+        gpu_ctx.generate_points(n, seed=700 + lg)
+        dev, _ = gpu_ctx.generate_scalars(n, seed=800 + lg)
+        want, _ = gpu_ctx.run_device(dev, n, c=16)
+        for c in (18, 21):
+            got, info = gpu_ctx.run_device(dev, n, c=c)
+            assert got.as_tuple() == want.as_tuple(), (lg, c, info)
+            K = info["K"]
+            parts = b"".join(gpu_ctx.window_sums(dev, n, k, k + 1, c=c, on_device=True)[0] for k in range(K))
+            assert combine_host(parts, K, c) == want.as_tuple(), (lg, c)
+    # every scalar the same: all entries of a window in one bucket; q - 1 and 2^252 - 1 drive the top window to its largest values
+    n = 1 << 12
+    gpu_ctx.generate_points(n, seed=99)
+    for val in (C.q - 1, C.q - 2, 1, (1 << 252) - 1):
+        sb = O.scalars_to_bytes([val] * n)
+        want, _ = gpu_ctx.run(sb, c=16)
+        for c in (18, 21):
+            assert gpu_ctx.run(sb, c=c)[0].as_tuple() == want.as_tuple(), (hex(val), c)
+    dev, _ = gpu_ctx.generate_scalars(n, seed=6)
+    want, _ = gpu_ctx.run_device(dev, n)
+    got, info = gpu_ctx.run_device(dev, n, c=23, no_glv=True)
+    assert info["K"] == 11 and got.as_tuple() == want.as_tuple()
