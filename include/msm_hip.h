@@ -61,7 +61,12 @@ typedef struct msm_ctx msm_ctx;
 /* Options of one msm call; mirrors `{c, useSafeAdditions}` of src/msm-batched-affine.ts:74-77.
  * Zero-initialise for defaults. */
 typedef struct msm_opts {
-  int32_t c;            /* window size in bits, 0 = pick from N (windowSize, src/msm-common.ts:8-41, retuned) */
+  int32_t c;            /* window size in bits, 0 = pick from N (windowSize, src/msm-common.ts:8-41, retuned).  The number of
+                           windows is the reference's K = ceil((b + 1) / c) (src/msm-batched-affine.ts:90) with one exception:
+                           for c >= 18, a top window that would hold the carry bit of the signed recoding alone
+                           (b + 1 = (K - 1) c + 1; BLS12-377: c = 18, 21) is folded into the window below -- K - 1 windows,
+                           window k still weighs 2^(c k).  msm_plan / msm_result.K report the K in use; every rank of a
+                           sharded run gets the same one from the same c */
   int32_t unsafe;       /* accepted for API parity with msmUnsafe; the GPU path always handles edge cases */
   int32_t k_lo, k_hi;   /* window shard [k_lo, k_hi) for msm_window_sums; 0,0 = all windows */
   int32_t serial;       /* != 0: run the window groups one after the other on one stream (no overlap): phase_ms then
@@ -170,7 +175,7 @@ int msm_combine_curve(int curve, const uint8_t* partials, int32_t K, int32_t c, 
  * msm_window_sums wrote them); P_k = sum over the groups, then as msm_combine_curve. */
 int msm_combine_groups(int curve, const uint8_t* partials, int32_t G, int32_t K, int32_t c, msm_result* out);
 
-/* Window plan for n points: the c the library would pick and the resulting K. */
+/* Window plan for n points: the c the library would pick (opts->c forces one) and the resulting K (see msm_opts.c). */
 int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_out, int32_t* K_out);
 
 /* Synthetic inputs generated on the GPU (randomPointsFast / randomScalars, src/curve-random.ts):
