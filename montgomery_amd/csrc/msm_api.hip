@@ -1442,6 +1442,12 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       const int pair = (nthreads == 2 && want_pair_sync) ? groups[gi].pair : -1;
       const std::function<void(hipStream_t)> meet = [&, slot, pair](hipStream_t s) {
         if (psync.arrive_and_wait(pair, (int)groups.size())) HIPCHK(hipStreamWaitEvent(s, ctx->ws[1 - slot].ev[2], 0));
+        long long tree_delay_us = 0;   // experiment: the second group's tree starts this much after the first one's
+        MSM_KNOB(tree_delay_us, "MSM_TREE_DELAY_US", 0);
+        if (tree_delay_us && slot == 1) {
+          HIPCHK(hipStreamSynchronize(s));
+          std::this_thread::sleep_for(std::chrono::microseconds(tree_delay_us));
+        }
       };
       try {
         run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, part.data(), sts[slot], p_off,
