@@ -293,6 +293,9 @@ def main():
                     help="N > 1: the headline sharding -- by scalar window (default: BASELINE configs[4]) or by points; "
                          "auto = montgomery_amd.distributed.choose_split.  The other one is timed too (other_splits)")
     ap.add_argument("--no-other-splits", action="store_true", help="N > 1: time the headline split only")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1 only: take the SHARDED code path with a process group of one rank (RCCL initialisation with a "
+                         "device id, device all-reduce / all-gather, both splits) -- what a one-GPU box can exercise of the N > 1 path")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (functional check of the sharded path on one GPU)")
     ap.add_argument("--curve", choices=["bls12-377", "bls12-381", "ed377"], default="bls12-377",
                     help="ed377 = BASELINE configs[3]: twisted Edwards msmBasic path (single GPU, use --log2n 20); "
@@ -312,10 +315,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    sharded = world > 1 or (args.force_dist and args.gpus == 1)
+    if sharded:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # --force-dist without a launcher: a rendezvous of one
+            import socket
+
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+            s_.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if local_rank >= torch.cuda.device_count():   # several ranks on one GPU: a functional check only, and only over gloo
             if args.dist_backend == "nccl":
                 sys.exit(f"bench: rank {rank} has no GPU of its own ({torch.cuda.device_count()} visible, {world} ranks): RCCL "
@@ -343,16 +356,16 @@ def main():
     # identical points on every rank; rank 0 keeps their discrete logs for the check of the result
     a_host = ctx.generate_points(n, seed=20261002, want_scalars=(verify and rank == 0), raw=True)
     c, K = ctx.plan(n, args.c or None)
-    split = "none" if world == 1 else (choose_split(n, world, K) if args.split == "auto" else args.split)
+    split = "none" if not sharded else (choose_split(n, world, K) if args.split == "auto" else args.split)
 
     def plan_for(how):
         """window size of one sharding (montgomery_amd.distributed.choose_window): the points split plans for a rank's share
         of the points, the window split wants K divisible by the rank count; --c overrides both"""
-        if args.c or world == 1:
+        if args.c or not sharded:
             return ctx.plan(n, args.c or None)
         return choose_window(lambda m, cc: ctx.plan(m, cc), n, world, how)
 
-    if world > 1:
+    if sharded:
         c, K = plan_for(split)
     shards = window_shards(K, world)
 
@@ -368,7 +381,7 @@ def main():
     exchanges = {}
 
     def step(i, how, c=None, K=None):
-        if world == 1:
+        if not sharded:
             return ctx.run_device(scal[i % n_sets].data_ptr(), n, c=c_main)
         from montgomery_amd.distributed import PARTIAL_BYTES, ShardExchange
 
@@ -400,7 +413,7 @@ def main():
         return res, box.get("info")
 
     def sync():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -425,7 +438,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         ranks_info = None
-        if world > 1:
+        if sharded:
             tmax = torch.tensor([dt], dtype=torch.float64, device=ddev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -452,7 +465,7 @@ def main():
     failed = None
     dt, step_ms, infos, last, last_set, ranks_info = timed_loop(split, c, K)
     other_splits = None
-    if world > 1 and not args.no_other_splits:
+    if sharded and not args.no_other_splits:
         other = "points" if split == "windows" else "windows"
         o_c, o_K = plan_for(other)
         o_dt, o_step_ms, _, o_last, o_set, o_ranks = timed_loop(other, o_c, o_K)
@@ -477,7 +490,7 @@ def main():
         # kernels SHARING the GPU.  One extra, untimed step with the groups serialised gives the exclusive figures.
         excl = None
         pcie = None
-        if world == 1:
+        if not sharded:
             # the same kernel under the round-3 plan (c = 16, K = 8: a third more pair additions, none of them through the
             # chunk-ordered or descriptor paths) when the library picks a bigger window: the per-pair rate of the tree kernel
             # where nothing but the kernel itself is in the way
@@ -520,7 +533,7 @@ def main():
                     "frac": 2 * n * K * SORT_ALGO_BYTES / (xi["phase_ms"]["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 },
             }
-        if world == 1 and not args.no_pcie:
+        if not sharded and not args.no_pcie:
             # The same MSM with the scalars handed over as a HOST buffer (pageable memory; 2^n x 32 bytes cross PCIe inside the
             # call, behind the computation from 2^24 points up): never `value`.  Same protocol as the headline: 15 calls, the
             # first 5 discarded, median and sample standard deviation; every result must equal the device-resident one.
@@ -560,7 +573,7 @@ def main():
                 "log2_n": args.log2n,
                 "window_bits": c,
                 "windows": K,
-                "parallelism": "single-gpu" if world == 1 else (
+                "parallelism": "single-gpu" if not sharded else (
                     f"window-shard x{world}, one RCCL all-gather of {K}x144 B" if split == "windows" else
                     f"points-shard x{world} (all {K} windows on n/{world} points per rank), one RCCL all-gather of {K}x144 B per rank"),
                 "points": "P_i = a_i*G generated on GPU (resident)",
@@ -618,15 +631,15 @@ def main():
             "pcie_inclusive": pcie,
             "result_is_infinity": bool(last.isZero) if last is not None else None,
         }
-        if world == 1 and not args.no_cpu_baseline and not is381:
+        if not sharded and not args.no_cpu_baseline and not is381:
             out["cpu_baseline"] = cpu_baseline(ctx, min(args.cpu_log2n, args.log2n), seed=777)
-        if world == 1 and not is381 and not args.no_other_configs and args.log2n != 20:
+        if not sharded and not is381 and not args.no_other_configs and args.log2n != 20:
             # the other size BASELINE.json's metric names and configs[3], timed by the same process (value stays the headline size)
             out["other_configs"] = [timed_config("bls12-377", 20, torch), timed_config("ed377", 20, torch)]
         print(json.dumps(out), flush=True)
         if verified is False or any(o["verified"] is False for o in (other_splits or [])):
             failed = "bench: the MSM result failed the known-discrete-log check"
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

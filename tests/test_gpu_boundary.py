@@ -432,3 +432,25 @@ def test_pipelined_host_scalars_error_paths():
     assert got.as_tuple() == want.as_tuple()
     ctx.set_workspace_limit(0)
     ctx.close()
+
+
+def test_bench_sharded_path_over_rccl_with_one_rank():
+    """`bench.py --gpus 1 --force-dist`: the N > 1 code path of the bench itself -- RCCL process group with a device id, barrier,
+    device all-reduce of the times, `all_gather_object`, the shard exchange on device tensors, both splits timed and verified --
+    with the one rank a one-GPU box can give it."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--log2n", "18",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["verified"] is True and d["split"] == "windows", d
+    assert "window-shard x1" in d["config"]["parallelism"] and len(d["ranks"]) == 1 and d["ranks"][0]["all_gather_ms"] is not None
+    assert d["other_splits"][0]["split"] == "points" and d["other_splits"][0]["verified"] is True
