@@ -8,12 +8,14 @@ HIPFLAGS := -O3 -pthread -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unus
 BUILD := build
 CURVES := CvBls377 CvBls381 CvPallas
 CURVE_OBJS := $(CURVES:%=$(BUILD)/kernels_%.o)
+HOST_TUS := msm_plan msm_sort msm_tree msm_reduce msm_upload msm_pipeline msm_abi msm_test_abi msm_gen sort_kernels te_kernels
+HOST_OBJS := $(HOST_TUS:%=$(BUILD)/%.o)
 KHDRS := $(CSRC)/msm_kernels.h $(CSRC)/batch_add.h $(CSRC)/msm_gen_kernels.h $(CSRC)/kernel_inst.h $(CSRC)/field.h $(CSRC)/packed.h $(CSRC)/curve.h \
          $(CSRC)/glv.h $(CSRC)/constants_gen.h
 
 # the curve-templated kernels compile once per curve, in parallel with the host pipeline
 all:
-	$(MAKE) -j4 $(LIB)
+	$(MAKE) -j8 $(LIB)
 
 $(CSRC)/constants_gen.h: $(CSRC)/gen_constants.py
 	python3 $(CSRC)/gen_constants.py
@@ -22,13 +24,14 @@ $(BUILD)/kernels_%.o: $(CSRC)/kernels_curve.hip $(KHDRS)
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -DMSM_CURVE_TU=$* -c $(CSRC)/kernels_curve.hip -o $@
 
-$(BUILD)/msm_api.o: $(CSRC)/msm_api.hip $(KHDRS) $(CSRC)/sort_kernels.h $(CSRC)/te_kernels.h $(CSRC)/msm_gen.h $(CSRC)/host_field.h \
-                    include/msm_hip.h
+# the host pipeline is one translation unit per concern (msm_internal.h lists them); the curve-independent kernels have two of their own
+HHDRS := $(KHDRS) $(CSRC)/msm_internal.h $(CSRC)/sort_kernels.h $(CSRC)/tree_kernels.h $(CSRC)/te_kernels.h $(CSRC)/host_field.h include/msm_hip.h
+$(BUILD)/%.o: $(CSRC)/%.hip $(HHDRS)
 	@mkdir -p $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -c $(CSRC)/msm_api.hip -o $@
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIB): $(BUILD)/msm_api.o $(CURVE_OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -pthread $(BUILD)/msm_api.o $(CURVE_OBJS) -o $(LIB)
+$(LIB): $(HOST_OBJS) $(CURVE_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -pthread $(HOST_OBJS) $(CURVE_OBJS) -o $(LIB)
 
 clean:
 	rm -rf $(LIB) $(BUILD)
@@ -58,7 +61,7 @@ examples/msm_demo: examples/msm_demo.c include/msm_hip.h $(LIB)
 ab:
 	@mkdir -p ab_builds/$(NAME)
 	for c in $(CURVES); do $(HIPCC) $(HIPFLAGS) $(EXTRA) -DMSM_CURVE_TU=$$c -c $(CSRC)/kernels_curve.hip -o ab_builds/$(NAME)/kernels_$$c.o & done; \
-	$(HIPCC) $(HIPFLAGS) $(EXTRA) -c $(CSRC)/msm_api.hip -o ab_builds/$(NAME)/msm_api.o; wait
+	for t in $(HOST_TUS); do $(HIPCC) $(HIPFLAGS) $(EXTRA) -c $(CSRC)/$$t.hip -o ab_builds/$(NAME)/$$t.o & done; wait
 	$(HIPCC) --offload-arch=$(ARCH) -shared -pthread ab_builds/$(NAME)/*.o -o ab_builds/libmsm_$(NAME).so
 	rm -rf ab_builds/$(NAME)
 

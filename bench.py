@@ -246,6 +246,7 @@ def bench_ed377(args, torch):
         "roofline": {"kernel": "k_te_add (bucket tree, unified extended additions)", "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_pair_add": algo_bytes,
+                     "pair_adds_per_step": pairs / len(infos), "pair_adds_issued_per_step": sum(x["n_pairs"] for x in infos) / len(infos),
                      "int_mad": {"achieved": pairs * mads / (acc_ms * 1e-3), "peak": INT_MAD_PEAK,
                                  "frac": pairs * mads / (acc_ms * 1e-3) / INT_MAD_PEAK}},
         "phase_ms": {k: sum(x["phase_ms"][k] for x in infos) / len(infos) for k in infos[0]["phase_ms"]},

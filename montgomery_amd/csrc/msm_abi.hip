@@ -1,0 +1,495 @@
+// The C ABI of include/msm_hip.h: contexts, resident point sets, msm_run / msm_window_sums / msm_combine, device buffers.
+// (reference interface replaced: Curve.Parallel.* of src/parallel.ts:135-145,251-259)
+#include "msm_internal.h"
+
+using namespace msm;
+using namespace msmi;
+
+extern "C" {
+
+uint32_t msm_abi_version(void) { return MSM_ABI_VERSION; }
+uint32_t msm_abi_struct_bytes(int which) { return which == 0 ? (uint32_t)sizeof(msm_opts) : which == 1 ? (uint32_t)sizeof(msm_result) : 0u; }
+
+int msm_ctx_create(msm_ctx** out, int curve, int device) {
+  if (!out) return MSM_ERR_ARG;
+  *out = nullptr;
+  if (curve != MSM_CURVE_BLS12_377_G1 && curve != MSM_CURVE_ED_ON_BLS12_377 && curve != MSM_CURVE_BLS12_381_G1 &&
+      curve != MSM_CURVE_PALLAS)
+    return MSM_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MSM_ERR_NO_DEVICE;
+  msm_ctx* ctx = new (std::nothrow) msm_ctx();
+  if (!ctx) return MSM_ERR_INTERNAL;
+  ctx->curve = curve;
+  ctx->device = device;
+  try {
+    ctx->helper.reset(new HelperThread());
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_info, 64 * 4, hipHostMallocDefault));
+    for (auto& w : ctx->ws) {
+      HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+      for (auto& e : w.ev) HIPCHK(hipEventCreate(&e));
+      HIPCHK(hipHostMalloc((void**)&w.h_info, 64 * 4, hipHostMallocDefault));
+      HIPCHK(hipHostMalloc((void**)&w.h_part, 128 * 20 * 36 * 4, hipHostMallocDefault));
+    }
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    // leave room for the resident points (144 B/point at 2^26 = 9.7 GB) and fragmentation
+    ctx->ws_budget = (uint64_t)(free_b * 0.55);
+    ctx->ensure(ctx->errflag, 16);
+    HIPCHK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  } catch (const HipFail& f) {
+    fprintf(stderr, "msm_ctx_create: HIP error %s at line %d\n", hipGetErrorString(f.e), f.line);
+    msm_ctx_destroy(ctx);
+    return MSM_ERR_HIP;
+  } catch (...) {
+    msm_ctx_destroy(ctx);
+    return MSM_ERR_INTERNAL;
+  }
+  ctx->hc.F.init(curve == MSM_CURVE_ED_ON_BLS12_377 ? Fp377::PW : curve_info(curve).pw);   // (the Edwards context uses hte)
+  ctx->k_dev_to_host = ctx->hc.F.pow2(2 * ctx->hc.F.radix_bits() - 30 * ctx->nl());   // device radix 2^(30 NL); host radix 2^384 or 2^256
+  {
+    uint32_t pw[12] = {0};
+    for (int i = 0; i < 8; i++) pw[i] = Fp253::PW[i];
+    ctx->hte.init(pw, 3021);
+    ctx->k_te_to_host = ctx->hte.F.pow2(2 * ctx->hte.F.radix_bits() - 270);
+  }
+  *out = ctx;
+  return MSM_OK;
+}
+
+void msm_ctx_destroy(msm_ctx* ctx) {
+  if (!ctx) return;
+  ctx->fan.clear();
+  for (msm_ctx* c : ctx->children) msm_ctx_destroy(c);
+  ctx->children.clear();
+  (void)hipSetDevice(ctx->device);
+  for (size_t i = 0; i < ctx->sets.size(); i++)
+    if ((int)i != ctx->cur_set) ctx->release(ctx->sets[i].rows);
+  for (void* p : ctx->allocs) (void)hipFree(p);
+  ctx->allocs.clear();
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->errflag, &ctx->misc}) ctx->release(*b);
+  for (auto& w : ctx->ws) {
+    if (w.stream) (void)hipStreamSynchronize(w.stream);
+    for (DevBuf* b : w.all) ctx->release(*b);
+    if (w.h_info) (void)hipHostFree(w.h_info);
+    if (w.h_part) (void)hipHostFree(w.h_part);
+    for (auto& e : w.ev) if (e) (void)hipEventDestroy(e);
+    if (w.stream) (void)hipStreamDestroy(w.stream);
+  }
+  if (ctx->h_info) (void)hipHostFree(ctx->h_info);
+  if (ctx->stage_pin) (void)hipHostFree(ctx->stage_pin);
+  for (auto& st : ctx->stage_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  for (auto& row : ctx->stage_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
+  for (auto& row : ctx->piece_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* msm_last_error(const msm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+static int set_points_one(msm_ctx* ctx, const void* points, uint64_t n, int on_device, int check_curve) {
+  if (!ctx || (!points && n)) return fail(ctx, MSM_ERR_ARG, "msm_set_points: null argument");
+  if (n >= (1ull << 30)) return fail(ctx, MSM_ERR_ARG, "msm_set_points: n must be < 2^30");
+  const bool te = ctx->is_te();
+  const size_t wire_bytes = 2 * ctx->coord_bytes();   // x || y, little-endian
+  const size_t row_words = te ? te::TE_ROW_WORDS : ROW_WORDS;
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->n_points = 0;
+    ctx->ensure(ctx->rows, std::max<uint64_t>(n, 1) * row_words * 4);
+    const uint32_t* d_wire = (const uint32_t*)points;
+    if (!on_device && n) {
+      ctx->ensure(ctx->misc, n * wire_bytes);
+      upload_staged(ctx, ctx->misc.p, points, n * wire_bytes);
+      d_wire = (const uint32_t*)ctx->misc.p;
+    }
+    HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
+    if (n) {
+      uint64_t grid = (n + 255) / 256;
+      if (te)
+        hipLaunchKernelGGL(te::k_te_points_from_wire, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p, d_wire,
+                           n, check_curve, (uint32_t*)ctx->errflag.p);
+      else
+        W_LAUNCH(ctx, k_points_from_wire, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p, d_wire, n,
+                           check_curve, (uint32_t*)ctx->errflag.p);
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->errflag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    if (!on_device) ctx->release(ctx->misc);
+    if (ctx->h_info[0] & 1) return fail(ctx, MSM_ERR_POINT, "msm_set_points: coordinate >= p");
+    if (ctx->h_info[0] & 2) return fail(ctx, MSM_ERR_POINT, "msm_set_points: point not on curve");
+    ctx->n_points = n;
+  } MSM_CATCH_ALL(ctx)
+  return MSM_OK;
+}
+
+int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, int check_curve) {
+  if (!ctx || ctx->children.empty()) return set_points_one(ctx, points, n, on_device, check_curve);
+  // multi-device context: every device keeps the whole point set (an MSM then runs over a share of the points per device by
+  // default, or over a share of the windows with msm_opts.by_window: either way without moving points)
+  try {
+    std::vector<uint8_t> host;
+    const void* src = points;
+    if (on_device && n) {   // the buffer lives on devices[0]: the other devices take it through the host
+      host.resize((size_t)n * 2 * ctx->coord_bytes());
+      HIPCHK(hipSetDevice(ctx->device));
+      HIPCHK(hipMemcpy(host.data(), points, host.size(), hipMemcpyDeviceToHost));
+      src = host.data();
+    }
+    return on_all_devices(ctx, [&](msm_ctx* c) {
+      return (c == ctx) ? set_points_one(c, points, n, on_device, check_curve) : set_points_one(c, src, n, 0, check_curve);
+    });
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_out, int32_t* K_out) {
+  Plan pl;   // plain arithmetic: nothing here can throw
+  int rc = make_plan(ctx, n, opts, pl);
+  if (rc) return rc;
+  if (c_out) *c_out = pl.c;
+  if (K_out) *K_out = pl.K;
+  return MSM_OK;
+}
+
+int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, uint8_t* partials_out,
+                    msm_result* stats) {
+  if (!ctx || !partials_out || (!scalars && n)) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: null argument");
+  if ((opts ? opts->point_lo : 0) + n > ctx->n_points)
+    return fail(ctx, MSM_ERR_NO_POINTS, "msm_window_sums: points [%llu, +%llu) but %llu resident points",
+                (unsigned long long)(opts ? opts->point_lo : 0), (unsigned long long)n, (unsigned long long)ctx->n_points);
+  Plan pl;
+  if (make_plan(ctx, n, opts, pl)) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: bad window size");
+  int k_lo = opts ? opts->k_lo : 0, k_hi = opts ? opts->k_hi : 0;
+  if (k_lo == 0 && k_hi == 0) k_hi = pl.K;
+  if (k_lo < 0 || k_hi > pl.K || k_lo >= k_hi) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: bad window shard [%d, %d) of %d", k_lo, k_hi, pl.K);
+  if (stats) memset(stats, 0, sizeof(*stats));
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<uint32_t> words;
+    if (ctx->is_te()) {
+      // extended point (X : Y : Z : T) sent as X || Y || Z; the receiver rebuilds T (msm_combine: T Z = X Y)
+      if (n) any_window_sums(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
+      const auto& C = ctx->hte;
+      msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}}, t;
+      for (int k = 0; k < k_hi - k_lo; k++) {
+        const msm_host::Ext6 P = n ? te_partial_to_host(ctx, &words[(size_t)k * 32]) : C.zero();
+        C.F.mul(t, P.X, one); fe6_to_bytes(partials_out + (size_t)k * 144, t);
+        C.F.mul(t, P.Y, one); fe6_to_bytes(partials_out + (size_t)k * 144 + 48, t);
+        C.F.mul(t, P.Z, one); fe6_to_bytes(partials_out + (size_t)k * 144 + 96, t);
+      }
+      if (stats) { stats->c = pl.c; stats->K = pl.K; }
+      return MSM_OK;
+    }
+    if (n == 0) {
+      words.assign((size_t)(k_hi - k_lo) * 36, 0);
+    } else {
+      any_window_sums(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
+    }
+    // to 48-byte canonical integers (leave device Montgomery form on the host)
+    for (int k = 0; k < k_hi - k_lo; k++) {
+      const uint32_t* w = &words[(size_t)k * 36];
+      bool zero_z = true;
+      for (int j = 0; j < 12; j++) zero_z &= w[24 + j] == 0;
+      msm_host::Proj6 P;
+      if (n == 0 || zero_z) P = ctx->hc.zero();
+      else P = partial_to_host(ctx, w);
+      msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}}, t;
+      ctx->hc.F.mul(t, P.X, one); fe6_to_bytes(partials_out + (size_t)k * 144, t);
+      ctx->hc.F.mul(t, P.Y, one); fe6_to_bytes(partials_out + (size_t)k * 144 + 48, t);
+      ctx->hc.F.mul(t, P.Z, one); fe6_to_bytes(partials_out + (size_t)k * 144 + 96, t);
+    }
+    if (stats) { stats->c = pl.c; stats->K = pl.K; }
+  } MSM_CATCH_ALL(ctx)
+  return MSM_OK;
+}
+
+int msm_combine(msm_ctx* ctx, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
+  // pure host arithmetic: ctx may be NULL (then BLS12-377 G1; msm_combine_curve names the curve without a context)
+  if (!partials || !out || K <= 0 || c <= 0) return fail(ctx, MSM_ERR_ARG, "msm_combine: bad argument");
+  try {
+    if (ctx && ctx->is_te()) {
+      int rc = te_combine_impl(partials, K, c, out);
+      return rc ? fail(ctx, rc, "msm_combine: coordinate >= p") : MSM_OK;
+    }
+    return combine_impl(ctx, ctx ? ctx->hc : *static_host_curve(MSM_CURVE_BLS12_377_G1), partials, K, c, out, 1);
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_combine_groups(int curve, const uint8_t* partials, int32_t G, int32_t K, int32_t c, msm_result* out) {
+  if (!partials || !out || K <= 0 || c <= 0 || G <= 0) return MSM_ERR_ARG;
+  msm_ctx* const no_ctx = nullptr;
+  try {
+    if (curve == MSM_CURVE_ED_ON_BLS12_377) return te_combine_impl(partials, K, c, out, G);
+    const msm_host::Curve6* C = static_host_curve(curve);
+    if (!C) return MSM_ERR_ARG;
+    return combine_impl(nullptr, *C, partials, K, c, out, G);
+  } MSM_CATCH_ALL(no_ctx)
+}
+
+int msm_combine_curve(int curve, const uint8_t* partials, int32_t K, int32_t c, msm_result* out) {
+  return msm_combine_groups(curve, partials, 1, K, c, out);
+}
+
+static int run_impl(msm_ctx* ctx, const void* scalars, const void* const* placed, uint64_t n, int on_device, const msm_opts* opts,
+                    msm_result* out, const char* who) {
+  if ((opts ? opts->point_lo : 0) + n > ctx->n_points)
+    return fail(ctx, MSM_ERR_NO_POINTS, "%s: points [%llu, +%llu) but %llu resident points", who,
+                (unsigned long long)(opts ? opts->point_lo : 0), (unsigned long long)n, (unsigned long long)ctx->n_points);
+  // Host scalars of a big call arrive range by range of the points (PieceUpload) and every range runs with the call's window:
+  // the first ranges are a sixteenth and three sixteenths of the input, so the window is picked for an eighth of the input
+  // rather than for all of it (2^26: c = 16 for every range 164.8 ms, c = 22 180.6 -- a 2^22-point range under 2^21 buckets
+  // per window)
+  msm_opts piped;
+  if (!placed && !on_device && n >= (1ull << 24) && !(opts && opts->c) && !ctx->is_te()) {
+    if (opts) piped = *opts; else memset(&piped, 0, sizeof piped);
+    piped.c = pick_window(false, n / 8, (opts && opts->no_glv) ? 0 : curve_info(ctx->curve).glv_max_bits);
+    opts = &piped;
+  }
+  Plan pl;
+  if (make_plan(ctx, n, opts, pl)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);
+  pl.merged = true;
+  memset(out, 0, sizeof(*out));
+  out->c = pl.c;
+  out->K = pl.K;
+  if (n == 0) {
+    if (ctx->is_te()) out->y[0] = 1;   // identity (0, 1)
+    else out->is_infinity = 1;
+    return MSM_OK;
+  }
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<uint32_t> words;
+    any_window_sums(ctx, scalars, n, on_device, opts, 0, pl.K, pl, words, out, placed);
+    HIPCHK(hipEventRecord(ctx->ev[10], ctx->stream));
+    if (ctx->is_te()) {
+      te_horner_to_affine(ctx, words, pl.K, pl.c, out);
+    } else {
+      std::vector<msm_host::Proj6> P(pl.K);
+      for (int k = 0; k < pl.K; k++) P[k] = partial_to_host(ctx, &words[(size_t)k * 36]);
+      horner_to_affine(ctx->hc, P, pl.c, out);
+    }
+    HIPCHK(hipEventRecord(ctx->ev[11], ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[10], ctx->ev[11]));
+    out->phase_ms[MSM_T_FINAL] = ms;
+    out->phase_ms[MSM_T_TOTAL] += ms;
+  } MSM_CATCH_ALL(ctx)
+  return MSM_OK;
+}
+
+int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, msm_result* out) {
+  if (!ctx || !out || (!scalars && n)) return fail(ctx, MSM_ERR_ARG, "msm_run: null argument");
+  return run_impl(ctx, scalars, nullptr, n, on_device, opts, out, "msm_run");
+}
+
+int msm_run_placed(msm_ctx* ctx, const void* const* dev_scalars, uint64_t n, const msm_opts* opts, msm_result* out) {
+  if (!ctx || !out || !dev_scalars) return fail(ctx, MSM_ERR_ARG, "msm_run_placed: null argument");
+  if (opts && opts->by_window && !ctx->children.empty())
+    return fail(ctx, MSM_ERR_ARG, "msm_run_placed: placed scalars are the shares of a points split (by_window must be 0)");
+  const int ndev = 1 + (int)ctx->children.size();
+  for (int d = 0; d < ndev; d++)
+    if (!dev_scalars[d] && n * (uint64_t)(d + 1) / ndev > n * (uint64_t)d / ndev)
+      return fail(ctx, MSM_ERR_ARG, "msm_run_placed: no scalars for device %d", d);
+  return run_impl(ctx, nullptr, dev_scalars, n, 1, opts, out, "msm_run_placed");
+}
+
+int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy) {
+  if (!ctx || !out_xy || first + count > ctx->n_points) return fail(ctx, MSM_ERR_ARG, "msm_get_points: bad argument");
+  if (ctx->is_te()) {
+    try {
+      HIPCHK(hipSetDevice(ctx->device));
+      std::vector<uint32_t> rows((size_t)count * te::TE_ROW_WORDS);
+      if (count)
+        HIPCHK(hipMemcpy(rows.data(), (const uint32_t*)ctx->rows.p + first * te::TE_ROW_WORDS, rows.size() * 4, hipMemcpyDeviceToHost));
+      msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
+      for (uint64_t i = 0; i < count; i++)
+        for (int j = 0; j < 2; j++) {
+          msm_host::Fe6 t = {{0, 0, 0, 0, 0, 0}};
+          const uint32_t* w = &rows[(size_t)i * te::TE_ROW_WORDS + 8 * j];
+          for (int q = 0; q < 4; q++) t.v[q] = (uint64_t)w[2 * q] | ((uint64_t)w[2 * q + 1] << 32);
+          ctx->hte.F.mul(t, t, ctx->k_te_to_host);
+          ctx->hte.F.mul(t, t, one);
+          for (int q = 0; q < 4; q++)
+            for (int b = 0; b < 8; b++) out_xy[i * 64 + 32 * j + 8 * q + b] = (uint8_t)(t.v[q] >> (8 * b));
+        }
+    } MSM_CATCH_ALL(ctx)
+    return MSM_OK;
+  }
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<uint32_t> rows((size_t)count * ROW_WORDS);
+    if (count)
+      HIPCHK(hipMemcpy(rows.data(), (const uint32_t*)ctx->rows.p + first * ROW_WORDS, rows.size() * 4, hipMemcpyDeviceToHost));
+    const int nw = ctx->nw();
+    const size_t cb = ctx->coord_bytes();
+    memset(out_xy, 0, (size_t)count * 2 * cb);
+    msm_host::Fe6 one = {{1, 0, 0, 0, 0, 0}};
+    for (uint64_t i = 0; i < count; i++) {
+      const uint32_t* row = &rows[(size_t)i * ROW_WORDS];
+      if (row[nw - 1] == INF_WORD) continue;
+      for (int j = 0; j < 2; j++) {
+        msm_host::Fe6 t;
+        words_to_fe6(t, row + nw * j, nw);
+        ctx->hc.F.mul(t, t, ctx->k_dev_to_host);  // host Montgomery
+        ctx->hc.F.mul(t, t, one);                 // plain
+        uint8_t b48[48];
+        fe6_to_bytes(b48, t);
+        memcpy(out_xy + i * 2 * cb + cb * j, b48, cb);
+      }
+    }
+  } MSM_CATCH_ALL(ctx)
+  return MSM_OK;
+}
+
+// ---- point-set handles: several resident point sets per context, one of them current ------------------------
+
+static int pointset_select_one(msm_ctx* ctx, int32_t id) {
+  if (id < 0 || id >= (int)ctx->sets.size() || (id != 0 && !ctx->sets[id].live))
+    return fail(ctx, MSM_ERR_ARG, "msm_pointset_select: no point set %d", (int)id);
+  if (id == ctx->cur_set) return MSM_OK;
+  ctx->sets[ctx->cur_set].rows = ctx->rows;
+  ctx->sets[ctx->cur_set].n = ctx->n_points;
+  ctx->rows = ctx->sets[id].rows;
+  ctx->n_points = ctx->sets[id].n;
+  ctx->cur_set = id;
+  return MSM_OK;
+}
+
+int msm_pointset_create(msm_ctx* ctx, int32_t* id_out) {
+  if (!ctx || !id_out) return fail(ctx, MSM_ERR_ARG, "msm_pointset_create: null argument");
+  try {
+    return on_all_devices(ctx, [&](msm_ctx* c) {
+      int id = -1;
+      for (size_t i = 1; i < c->sets.size(); i++)
+        if (!c->sets[i].live) { id = (int)i; break; }
+      if (id < 0) { c->sets.emplace_back(); id = (int)c->sets.size() - 1; }   // children stay in lockstep: same ids
+      c->sets[id] = msm_ctx::PointSet();
+      c->sets[id].live = true;
+      if (c == ctx) *id_out = id;
+      return pointset_select_one(c, id);
+    });
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_pointset_select(msm_ctx* ctx, int32_t id) {
+  if (!ctx) return MSM_ERR_ARG;
+  try {
+    return on_all_devices(ctx, [&](msm_ctx* c) { return pointset_select_one(c, id); });
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_pointset_destroy(msm_ctx* ctx, int32_t id) {
+  if (!ctx) return MSM_ERR_ARG;
+  if (id <= 0 || id >= (int)ctx->sets.size() || !ctx->sets[id].live)
+    return fail(ctx, MSM_ERR_ARG, "msm_pointset_destroy: no such point set %d (the default set 0 stays)", (int)id);
+  try {
+    return on_all_devices(ctx, [&](msm_ctx* c) {
+      if (c->cur_set == id) pointset_select_one(c, 0);
+      (void)hipSetDevice(c->device);
+      c->release(c->sets[id].rows);
+      c->sets[id] = msm_ctx::PointSet();
+      return (int)MSM_OK;
+    });
+  } MSM_CATCH_ALL(ctx)
+}
+
+// ---- device buffers for scalar handles ------------------------------------------------------------------------
+
+int msm_device_alloc(msm_ctx* ctx, uint64_t bytes, void** dev_ptr_out) {
+  if (!ctx || !dev_ptr_out) return fail(ctx, MSM_ERR_ARG, "msm_device_alloc: null argument");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, std::max<uint64_t>(bytes, 32)));
+    ctx->allocs.push_back(p);
+    *dev_ptr_out = p;
+    return MSM_OK;
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_device_free(msm_ctx* ctx, void* dev_ptr) {
+  if (!ctx) return MSM_ERR_ARG;
+  auto it = std::find(ctx->allocs.begin(), ctx->allocs.end(), dev_ptr);
+  if (it == ctx->allocs.end()) return fail(ctx, MSM_ERR_ARG, "msm_device_free: not a buffer of this context");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->allocs.erase(it);
+    HIPCHK(hipFree(dev_ptr));
+    return MSM_OK;
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_device_upload(msm_ctx* ctx, void* dev_ptr, const void* host, uint64_t bytes) {
+  if (!ctx || !dev_ptr || (!host && bytes)) return fail(ctx, MSM_ERR_ARG, "msm_device_upload: null argument");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (bytes) {
+      upload_staged(ctx, dev_ptr, host, bytes);
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return MSM_OK;
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_set_workspace_limit(msm_ctx* ctx, uint64_t bytes) {
+  if (!ctx) return MSM_ERR_ARG;
+  ctx->ws_limit = bytes;
+  if (!bytes) {   // back to automatic: small calls use the creation-time rule again
+    try {
+      HIPCHK(hipSetDevice(ctx->device));
+      size_t free_b = 0, total_b = 0;
+      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      uint64_t held = 0;
+      for (auto& w : ctx->ws)
+        for (DevBuf* b : w.all) held += b->cap;
+      ctx->ws_budget = (uint64_t)((free_b + held) * 0.55L);
+    } MSM_CATCH_ALL(ctx)
+  }
+  for (msm_ctx* c : ctx->children) {
+    int rc = msm_set_workspace_limit(c, bytes);
+    if (rc != MSM_OK) return rc;
+  }
+  return MSM_OK;
+}
+
+// ---- multi-device context ---------------------------------------------------------------------------------------
+
+int msm_ctx_create_multi(msm_ctx** out, int curve, const int32_t* devices, int32_t n_devices) {
+  if (!out || !devices || n_devices < 1) return MSM_ERR_ARG;
+  *out = nullptr;
+  msm_ctx* ctx = nullptr;
+  int rc = msm_ctx_create(&ctx, curve, devices[0]);
+  if (rc != MSM_OK) return rc;
+  try {
+    for (int i = 1; i < n_devices; i++) {
+      msm_ctx* c = nullptr;
+      rc = msm_ctx_create(&c, curve, devices[i]);
+      if (rc != MSM_OK) {
+        msm_ctx_destroy(ctx);
+        return rc;
+      }
+      ctx->children.push_back(c);
+      ctx->fan.emplace_back(new HelperThread());
+    }
+  } catch (...) {
+    msm_ctx_destroy(ctx);
+    return MSM_ERR_INTERNAL;
+  }
+  *out = ctx;
+  return MSM_OK;
+}
+
+int msm_ctx_device_count(const msm_ctx* ctx) { return ctx ? 1 + (int)ctx->children.size() : 0; }
+
+}  // extern "C"

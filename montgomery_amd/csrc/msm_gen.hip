@@ -6,13 +6,13 @@
 //   generate_scalars : uniform scalars < q by masked rejection sampling (src/curve-random.ts:151-194)
 // Randomness is a counter-based splitmix64 stream, identical on host and device, keyed by (seed, index).
 //
-// Included by msm_api.hip after msm_ctx / HIPCHK are defined.
-#pragma once
-#include "msm_gen_kernels.h"
+#include "msm_internal.h"
+
+using namespace msmi;
 
 namespace msm_gen {
 
-inline Q256 scalar_order(const msm_ctx* ctx) {
+static inline Q256 scalar_order(const msm_ctx* ctx) {
   const CurveInfo& ci = curve_info(ctx->curve);
   Q256 q;
   for (int j = 0; j < 4; j++) q.v[j] = (uint64_t)ci.q[2 * j] | ((uint64_t)ci.q[2 * j + 1] << 32);
@@ -20,7 +20,7 @@ inline Q256 scalar_order(const msm_ctx* ctx) {
   return q;
 }
 
-__global__ void __launch_bounds__(256) k_gen_scalars(uint64_t* out, uint64_t n, uint64_t seed, Q256 qq) {
+static __global__ void __launch_bounds__(256) k_gen_scalars(uint64_t* out, uint64_t n, uint64_t seed, Q256 qq) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t q[4], s[4];
@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) k_gen_scalars(uint64_t* out, uint64_t n, 
   for (int j = 0; j < 4; j++) out[i * 4 + j] = s[j];
 }
 
-inline int generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void* dev_dst, uint8_t* host_out) {
+int generate_scalars(msm_ctx* ctx, uint64_t n, uint64_t seed, void* dev_dst, uint8_t* host_out) {
   // dev_dst: caller-owned device buffer of n * 32 bytes; NULL (host copy only): the staging buffer carries them
   void* dst = dev_dst;
   if (!dst) {
@@ -52,7 +52,7 @@ struct U256 {
   uint64_t v[4];
 };
 
-inline void addmod_q(U256& r, const U256& a, const U256& b, const uint64_t* q) {
+static inline void addmod_q(U256& r, const U256& a, const U256& b, const uint64_t* q) {
   unsigned __int128 c = 0;
   U256 t;
   for (int i = 0; i < 4; i++) {
@@ -73,7 +73,7 @@ inline void addmod_q(U256& r, const U256& a, const U256& b, const uint64_t* q) {
 
 // a_i = sum_j tbl_scalar[j][idx_ij] mod q for all n points (32-byte little-endian each), on the host cores: at 2^26 the
 // plain loop is 3.4e8 modular additions, so it is split over threads
-inline void write_discrete_logs(uint8_t* a_out, uint64_t n, uint64_t seed, const std::vector<U256>& tbl_scalar, const uint64_t* q) {
+static inline void write_discrete_logs(uint8_t* a_out, uint64_t n, uint64_t seed, const std::vector<U256>& tbl_scalar, const uint64_t* q) {
   const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
   const unsigned nt = (unsigned)std::min<uint64_t>(hw, std::max<uint64_t>(1, n >> 14));
   auto work = [&](uint64_t lo, uint64_t hi) {
@@ -91,7 +91,7 @@ inline void write_discrete_logs(uint8_t* a_out, uint64_t n, uint64_t seed, const
   for (auto& x : th) x.join();
 }
 
-inline int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
+int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
   using namespace msm_host;
   if (n >= (1ull << 30)) return MSM_ERR_ARG;
   const Curve6& C = ctx->hc;
@@ -185,7 +185,7 @@ inline int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_o
 }
 
 // Edwards curve: the same scheme over the unified extended addition (host: TeCurve6, device: k_te_gen_points)
-inline int generate_points_te(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
+int generate_points_te(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
   using namespace msm_host;
   if (n >= (1ull << 30)) return MSM_ERR_ARG;
   const TeCurve6& C = ctx->hte;

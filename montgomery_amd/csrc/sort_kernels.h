@@ -1,8 +1,9 @@
 // Curve-independent kernels of the MSM pipeline: bucket-size scans, the LDS-privatised counting sort (one level for small
 // inputs, LDS-staged two-pass split for c <= 16, three-pass split up to the largest accepted window c = 24) and the operand
-// descriptors of the tail rounds.
+// descriptors of the tail rounds (tree_kernels.h).
 // (reference phases: integrateBucketCounts src/msm-batched-affine.ts:423-447, sortPoints :456-502)
-// Included by msm_api.hip only; the curve-templated kernels live in msm_kernels.h.
+// Defined in sort_kernels.hip (MSM_SORT_TU); the host translation units see declarations.  The curve-templated kernels live in
+// msm_kernels.h, the kernels around the tree rounds in tree_kernels.h.
 #pragma once
 #include "msm_kernels.h"
 
@@ -75,7 +76,11 @@ MSM_DEV int pscan_nq(const uint32_t* info, uint32_t logG) {
 // additions the bucket sums need whatever the tree looks like (msm_result.n_pairs_algo; the tree also issues the additions
 // of its padding lanes, msm_result.n_pairs)
 constexpr int INFO_ALGO_PAIRS = 40;
-__global__ void __launch_bounds__(256) k_bucket_max(const uint32_t* counts, uint32_t nb, uint32_t* info) {
+__global__ void __launch_bounds__(256) k_bucket_max(const uint32_t* counts, uint32_t nb, uint32_t* info)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   __shared__ uint32_t lds_max;
   __shared__ unsigned long long lds_sum;
   if (threadIdx.x == 0) { lds_max = 0; lds_sum = 0; }
@@ -96,9 +101,14 @@ __global__ void __launch_bounds__(256) k_bucket_max(const uint32_t* counts, uint
     atomicAdd(reinterpret_cast<unsigned long long*>(info + INFO_ALGO_PAIRS), lds_sum);
   }
 }
+#endif
 
 __global__ void __launch_bounds__(PS_BLOCK) k_pscan_partial(const uint32_t* counts, uint32_t nb, uint32_t logG, const uint32_t* info,
-                                                            uint32_t* partial, uint32_t nblocks) {
+                                                            uint32_t* partial, uint32_t nblocks)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   __shared__ uint32_t lds_wave[PS_BLOCK / 64];
   const int nq = pscan_nq(info, logG);
   const uint32_t b0 = blockIdx.x * PS_SPAN + threadIdx.x * PS_ITEMS;
@@ -114,8 +124,13 @@ __global__ void __launch_bounds__(PS_BLOCK) k_pscan_partial(const uint32_t* coun
     if (threadIdx.x == 0) partial[(uint64_t)q * nblocks + blockIdx.x] = tot;
   }
 }
+#endif
 
-__global__ void __launch_bounds__(SCAN_THREADS) k_pscan_top(uint32_t* partial, uint32_t nblocks, uint32_t logG, uint32_t* info) {
+__global__ void __launch_bounds__(SCAN_THREADS) k_pscan_top(uint32_t* partial, uint32_t nblocks, uint32_t logG, uint32_t* info)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
   const int nq = pscan_nq(info, logG);
   for (int q = 0; q < nq; q++) {
@@ -134,10 +149,15 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_pscan_top(uint32_t* partial, u
     }
   }
 }
+#endif
 
 __global__ void __launch_bounds__(PS_BLOCK) k_pscan_final(const uint32_t* counts, uint32_t nb, uint32_t logG,
                                                           const uint32_t* partial, uint32_t nblocks, uint32_t* cursor,
-                                                          uint32_t* tail_off, const uint32_t* info) {
+                                                          uint32_t* tail_off, const uint32_t* info)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   __shared__ uint32_t lds_wave[PS_BLOCK / 64];
   const int nq = pscan_nq(info, logG);
   const uint32_t b0 = blockIdx.x * PS_SPAN + threadIdx.x * PS_ITEMS;
@@ -159,46 +179,7 @@ __global__ void __launch_bounds__(PS_BLOCK) k_pscan_final(const uint32_t* counts
     if (q > 0 && blockIdx.x == 0 && threadIdx.x == 0) out[nb] = info[3 + (q - 1)];
   }
 }
-
-// ---------------------------------------------------------------------------------------------
-// k_tail_desc: per tail round, the operand locations of every output element, found once by binary
-// search here (thousands of resident waves hide the dependent loads) instead of twice per pair inside
-// the latency-critical batch-add kernel.  desc[e] = (index of the first operand << 1) | second operand present.
-// ---------------------------------------------------------------------------------------------
-
-// Big windows have millions of buckets (23 dependent loads per output in a plain binary search, 1.4 ms per call at 2^26 /
-// c = 22): the 256 consecutive outputs of a block belong to a short run of buckets, so the block's first and last lane
-// search the whole table once, and every lane then searches only that run (a handful of steps on lines the block has just
-// touched).
-__global__ void __launch_bounds__(256) k_tail_desc(uint32_t* desc, const uint32_t* off_in, const uint32_t* off_out, uint32_t nb,
-                                                   uint32_t n_out) {
-  __shared__ uint32_t run[2];
-  const uint32_t e0 = blockIdx.x * blockDim.x;
-  const uint32_t e = e0 + threadIdx.x;
-#ifdef MSM_X_FLAT_TAIL_DESC   // experiment: every lane searches the whole table (the kernel of rounds 1-3)
-  if (threadIdx.x == 0) { run[0] = 0; run[1] = nb - 1; }
-#else
-  if (threadIdx.x == 0 || threadIdx.x == blockDim.x - 1) {
-    const uint32_t ee = min(threadIdx.x == 0 ? e0 : e0 + blockDim.x - 1, n_out - 1);
-    uint32_t lo = 0, hi = nb;
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (off_out[mid] <= ee) lo = mid; else hi = mid;
-    }
-    run[threadIdx.x == 0 ? 0 : 1] = lo;
-  }
 #endif
-  __syncthreads();
-  if (e >= n_out) return;
-  uint32_t lo = run[0], hi = run[1] + 1;   // the bucket of e lies in [run[0], run[1]]: off_out[lo] <= e < off_out[hi]
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (off_out[mid] <= e) lo = mid; else hi = mid;
-  }
-  uint32_t j = e - off_out[lo];
-  uint32_t ia = off_in[lo] + 2 * j;
-  desc[e] = (ia << 1) | ((ia + 1) < off_in[lo + 1] ? 1u : 0u);
-}
 
 // ---------------------------------------------------------------------------------------------
 // LDS-privatised counting sort (used whenever one window's L counters fit the 160 KB LDS, c <= 16).
@@ -250,7 +231,11 @@ __device__ __forceinline__ uint32_t lds_rank_add(uint32_t* lds, uint32_t bin, bo
 // bin = l - 1, or (l - 1) >> ws.fb[kk] with fine_windows set (the three-pass split counts its fine windows).
 __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, const uint32_t* dig, uint64_t two_n,
                                                        uint64_t chunk, uint32_t L, WinSplit ws, uint32_t fine_windows,
-                                                       uint32_t agg_bits) {
+                                                       uint32_t agg_bits)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   extern __shared__ uint32_t lds_hist[];
   const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
   const uint32_t shift = fine_windows ? ws.fb[kk] : 0u;
@@ -297,8 +282,13 @@ __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, con
   uint32_t* out = block_hist + hist_row * L;
   for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) out[l] = lds_hist[l];
 }
+#endif
 
-__global__ void __launch_bounds__(256) k_colscan(uint32_t* block_hist, uint32_t* counts, uint32_t B, uint32_t L, uint32_t k_cnt) {
+__global__ void __launch_bounds__(256) k_colscan(uint32_t* block_hist, uint32_t* counts, uint32_t B, uint32_t L, uint32_t k_cnt)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= (uint64_t)k_cnt * L) return;
   uint32_t kk = (uint32_t)(id / L), l = (uint32_t)(id - (uint64_t)kk * L);
@@ -318,10 +308,15 @@ __global__ void __launch_bounds__(256) k_colscan(uint32_t* block_hist, uint32_t*
   }
   counts[id] = run;
 }
+#endif
 
 __global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(uint32_t* slots, const uint32_t* cursor,
                                                               const uint32_t* block_hist, const uint32_t* dig,
-                                                              uint64_t two_n, uint64_t chunk, uint32_t L, uint32_t agg_bits) {
+                                                              uint64_t two_n, uint64_t chunk, uint32_t L, uint32_t agg_bits)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   extern __shared__ uint32_t lds_pos[];
   const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
   const uint32_t* base = block_hist + ((uint64_t)kk * B + b) * L;
@@ -338,6 +333,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(uint32_t* slots, c
     if (l) slots[pos] = ((uint32_t)j << 1) | (v >> 31);
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // LDS-staged radix split (big inputs at c <= 16; replaces the one-level scatter there).
@@ -380,7 +376,11 @@ __device__ __forceinline__ void rx_scan_bins(uint32_t* start, const uint32_t* cn
 }
 
 __global__ void __launch_bounds__(256) k_coarse_offsets(uint32_t* blk_off, uint32_t* v_tot, const uint32_t* block_hist,
-                                                        const uint32_t* counts, uint32_t B, uint32_t L, uint32_t Hn, uint32_t kc) {
+                                                        const uint32_t* counts, uint32_t B, uint32_t L, uint32_t Hn, uint32_t kc)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   // one thread per (kk, b, h): b == B is the extra row that produces the totals from `counts`
   const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t total = (uint64_t)kc * (B + 1) * Hn;
@@ -399,8 +399,13 @@ __global__ void __launch_bounds__(256) k_coarse_offsets(uint32_t* blk_off, uint3
   if (b == B) v_tot[(uint64_t)kk * Hn + h] = sum;
   else blk_off[((uint64_t)kk * B + b) * Hn + h] = sum;
 }
+#endif
 
-__global__ void __launch_bounds__(SCAN_THREADS) k_vscan(uint32_t* v_start, const uint32_t* v_tot, uint32_t V) {
+__global__ void __launch_bounds__(SCAN_THREADS) k_vscan(uint32_t* v_start, const uint32_t* v_tot, uint32_t V)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
   uint32_t carry = 0;
   for (uint32_t base = 0; base < V; base += SCAN_THREADS) {
@@ -414,12 +419,17 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_vscan(uint32_t* v_start, const
   }
   if (threadIdx.x == 0) v_start[V] = carry;
 }
+#endif
 
 // pass A.  grid (B, kc); block (b, kk) owns entries [b * chunk, (b + 1) * chunk) of window kk.  Coarse bin h of window kk
 // starts at v_start[kk * vs_stride + (h << mb)]; this block's share of it at + blk_off[(kk * B + b) * bo_stride + h].
 __global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t* dig2, uint32_t* idx2, const uint32_t* v_start,
                                                              const uint32_t* blk_off, const uint32_t* dig, uint64_t two_n,
-                                                             uint64_t chunk, uint32_t vs_stride, uint32_t bo_stride, WinSplit ws) {
+                                                             uint64_t chunk, uint32_t vs_stride, uint32_t bo_stride, WinSplit ws)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   __shared__ uint2 stage[RXA_TILE];
   __shared__ uint32_t t_cnt[256], t_start[256], g_base[256], lds_wave[RX_THREADS / 64];
   const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x, tid = threadIdx.x;
@@ -470,6 +480,7 @@ __global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t
     if (tid < Hn) g_base[tid] += t_cnt[tid];
   }
 }
+#endif
 
 // pass B.  One block per fine window: block v = kk * Lp + f owns the 2^fb buckets from f << fb of window kk (heaviest -- the
 // top window's few coarse bins on the two-pass path -- first: v = V - 1 - blockIdx.x).  Records: (bucket's low fb bits) + 1 |
@@ -477,7 +488,11 @@ __global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t
 // of a handful of bits): ranking is the identity there, and all Lp blocks of the window copy an equal slice of its records.
 __global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, const uint32_t* cursor, const uint32_t* v_start,
                                                            const uint32_t* dig2, const uint32_t* idx2, uint32_t Lp, uint32_t L,
-                                                           WinSplit ws) {
+                                                           WinSplit ws)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   constexpr uint32_t NBMAX = 256;
   __shared__ uint32_t stage[RXB_TILE];
   __shared__ uint8_t stage_b[RXB_TILE];
@@ -539,6 +554,7 @@ __global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, con
     if (tid < NB) g_cur[tid] += t_cnt[tid];
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Three-pass split for windows of more than 2^15 buckets (c > 16), where one window's counters no longer fit the LDS.
@@ -552,7 +568,11 @@ __global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, con
 // ---------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256) k_coarse_offsets3(uint32_t* blk_off, const uint32_t* block_hist, uint32_t B, uint32_t Lp,
-                                                         uint32_t kc, WinSplit ws) {
+                                                         uint32_t kc, WinSplit ws)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= (uint64_t)kc * B * 256) return;
   const uint32_t h = (uint32_t)(id & 255u);
@@ -566,11 +586,16 @@ __global__ void __launch_bounds__(256) k_coarse_offsets3(uint32_t* blk_off, cons
   }
   blk_off[id] = sum;
 }
+#endif
 
 // pass M.  grid (256, kc): block (h, kk) owns coarse bin h of window kk = the fine windows [h << mb, (h + 1) << mb).
 // A window without mid bits (mb = 0) keeps its order: all 256 blocks copy an equal slice of its records.
 __global__ void __launch_bounds__(RXB_THREADS) k_radix_mid(uint32_t* dig3, uint32_t* idx3, const uint32_t* v2_start,
-                                                          const uint32_t* dig2, const uint32_t* idx2, uint32_t Lp, WinSplit ws) {
+                                                          const uint32_t* dig2, const uint32_t* idx2, uint32_t Lp, WinSplit ws)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   constexpr uint32_t NBMAX = 128;
   __shared__ uint2 stage[RXB_TILE];
   __shared__ uint8_t stage_b[RXB_TILE];
@@ -633,11 +658,16 @@ __global__ void __launch_bounds__(RXB_THREADS) k_radix_mid(uint32_t* dig3, uint3
     if (tid < NB) g_cur[tid] += t_cnt[tid];
   }
 }
+#endif
 
 // bucket sizes of fine window v = kk * Lp + f (2^fb buckets from f << fb) from its records; `counts` is zeroed before
 // (a short top window does not reach the upper buckets)
 __global__ void __launch_bounds__(256) k_fine_hist(uint32_t* counts, const uint32_t* v2_start, const uint32_t* dig3, uint32_t Lp,
-                                                   uint32_t L, WinSplit ws) {
+                                                   uint32_t L, WinSplit ws)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   __shared__ uint32_t hist[256];
   const uint32_t v = blockIdx.x, tid = threadIdx.x;
   const uint32_t kk = v / Lp, f = v - kk * Lp, fb = ws.fb[kk], NB = 1u << fb;
@@ -657,6 +687,7 @@ __global__ void __launch_bounds__(256) k_fine_hist(uint32_t* counts, const uint3
   __syncthreads();
   if (tid < NB) out[tid] = hist[tid];
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // k_chunk_order: round 1 of the tree gathers its operands from the point rows, and scattered 128-byte line reads run 2.3x
@@ -677,7 +708,11 @@ constexpr int CO_THREADS = 256, CO_PPT = CO_PAIRS / CO_THREADS;   // 16 consecut
 constexpr int CO_MAX_KEYS = MSM_CO_MAX_KEYS;                      // up to 64 chunks + the pads
 
 __global__ void __launch_bounds__(CO_THREADS) k_chunk_order(uint2* pairs_out, uint16_t* oidx, const uint2* pairs_in, uint64_t n_pairs,
-                                                            uint32_t row_shift, uint32_t nkeys) {
+                                                            uint32_t row_shift, uint32_t nkeys)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
   __shared__ uint2 stage[CO_PAIRS];
   __shared__ uint16_t stage_o[CO_PAIRS];
   __shared__ uint16_t cnt[CO_MAX_KEYS * CO_THREADS];   // [key][thread]
@@ -731,64 +766,6 @@ __global__ void __launch_bounds__(CO_THREADS) k_chunk_order(uint2* pairs_out, ui
     oidx[base + i] = stage_o[i];
   }
 }
-
-// point rows (k_points_from_wire) -> tree planes, element e of the planes = row e: test input of the plane-reading modes
-template <int W>   // W = packed words per coordinate (12 or 8)
-__global__ void __launch_bounds__(256) k_test_rows_to_planes(uint4* planes, uint64_t cap, const uint32_t* rows, uint32_t n) {
-  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  uint32_t w[W];
-  load_words12(w, rows + (uint64_t)e * ROW_WORDS);
-  store_planes3(planes, cap, 0, e, w);
-  load_words12(w, rows + (uint64_t)e * ROW_WORDS + W);
-  store_planes3(planes, cap, W / 4, e, w);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_finish_hist / k_finish_perm: order the buckets by the number of elements they still hold when the tree stops,
-// largest first, so that the 64 lanes of a k_bucket_finish wave run the same number of additions (a wave costs its
-// longest lane: with counts of 3..7 in natural order that is ~1.5x the mean).  Counting sort over <= 64 distinct
-// counts, block-private in LDS: one global atomic per distinct count per 1024 buckets.
-// ---------------------------------------------------------------------------------------------
-
-constexpr int FINISH_BINS = 64;
-
-MSM_DEV uint32_t finish_bin(const uint32_t* off, uint32_t b) {
-  uint32_t c = off[b + 1] - off[b];
-  return c < FINISH_BINS ? c : FINISH_BINS - 1;
-}
-
-constexpr int FINISH_THREADS = 1024;
-
-__global__ void __launch_bounds__(FINISH_THREADS) k_finish_hist(const uint32_t* off, uint32_t nb, uint32_t* hist) {
-  __shared__ uint32_t lh[FINISH_BINS];
-  if (threadIdx.x < FINISH_BINS) lh[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < nb) atomicAdd(&lh[finish_bin(off, b)], 1u);
-  __syncthreads();
-  if (threadIdx.x < FINISH_BINS && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
-}
-
-// cursor: FINISH_BINS zeroed words; perm[j] = j-th bucket in descending order of count
-__global__ void __launch_bounds__(FINISH_THREADS) k_finish_perm(const uint32_t* off, uint32_t nb, const uint32_t* hist,
-                                                                uint32_t* cursor, uint32_t* perm) {
-  __shared__ uint32_t lcnt[FINISH_BINS], lbase[FINISH_BINS];
-  if (threadIdx.x < FINISH_BINS) lcnt[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = b < nb;
-  const uint32_t key = active ? finish_bin(off, b) : 0u;
-  uint32_t rank = 0;
-  if (active) rank = atomicAdd(&lcnt[key], 1u);
-  __syncthreads();
-  if (threadIdx.x < FINISH_BINS && lcnt[threadIdx.x]) {
-    uint32_t base = 0;
-    for (uint32_t k = FINISH_BINS - 1; k > threadIdx.x; k--) base += hist[k];   // larger counts first
-    lbase[threadIdx.x] = base + atomicAdd(&cursor[threadIdx.x], lcnt[threadIdx.x]);
-  }
-  __syncthreads();
-  if (active) perm[lbase[key] + rank] = b;
-}
+#endif
 
 }  // namespace msm

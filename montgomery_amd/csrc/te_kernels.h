@@ -20,6 +20,7 @@
 // (X, Y, Z, T two planes each); payload = (point index << 1) | negative.
 #pragma once
 #include "msm_kernels.h"
+#include "msm_gen_kernels.h"
 
 namespace msm {
 namespace te {
@@ -169,7 +170,11 @@ MSM_DEV bool words8_ge_p(const uint32_t (&w)[TW]) {
 }
 
 __global__ void __launch_bounds__(256) k_te_points_from_wire(uint32_t* rows, const uint32_t* wire, uint64_t n, int check_curve,
-                                                             uint32_t* err) {
+                                                             uint32_t* err)
+#ifndef MSM_TE_TU
+    ;
+#else
+{
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t xw[TW], yw[TW];
@@ -211,13 +216,18 @@ __global__ void __launch_bounds__(256) k_te_points_from_wire(uint32_t* rows, con
   fe_store<FT>(row + 16, t);
   fe_store<FT>(row + 24, kt);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // k_te_digits: signed window digits of full-width scalars (no GLV), src/msm-basic.ts:72-91
 // ---------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256) k_te_digits(uint32_t* dig, const uint32_t* scalars, uint32_t n, int c, int k_total, int k_lo,
-                                                   int k_cnt, int strict, uint32_t* err) {
+                                                   int k_cnt, int strict, uint32_t* err)
+#ifndef MSM_TE_TU
+    ;
+#else
+{
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -244,6 +254,7 @@ __global__ void __launch_bounds__(256) k_te_digits(uint32_t* dig, const uint32_t
     }
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // k_te_add: one round of the bucket tree, output e = input 2e + input 2e+1 (unified addition)
@@ -280,13 +291,28 @@ __global__ void __launch_bounds__(256) k_te_add(BatchArgs a) {
     store_ext(a.out, a.out_cap, e, R);
   }
 }
+// the three modes are compiled in te_kernels.hip
+#ifdef MSM_TE_TU
+template __global__ void k_te_add<MODE_GATHER>(BatchArgs);
+template __global__ void k_te_add<MODE_REGULAR>(BatchArgs);
+template __global__ void k_te_add<MODE_SEARCH>(BatchArgs);
+#else
+extern template __global__ void k_te_add<MODE_GATHER>(BatchArgs);
+extern template __global__ void k_te_add<MODE_REGULAR>(BatchArgs);
+extern template __global__ void k_te_add<MODE_SEARCH>(BatchArgs);
+#endif
+
 
 // ---------------------------------------------------------------------------------------------
 // k_te_gen_points: synthetic inputs, P_i = sum_j T_j[idx_ij] over 5 basis tables (randomPointsFast,
 // src/curve-random.ts:14-92, with the discrete logs known to the host; see msm_gen.h).  Writes wire format.
 // ---------------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) k_te_gen_points(uint32_t* wire_out, const uint32_t* tables, uint64_t n, uint64_t seed) {
+__global__ void __launch_bounds__(256) k_te_gen_points(uint32_t* wire_out, const uint32_t* tables, uint64_t n, uint64_t seed)
+#ifndef MSM_TE_TU
+    ;
+#else
+{
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Ext acc;
@@ -314,6 +340,7 @@ __global__ void __launch_bounds__(256) k_te_gen_points(uint32_t* wire_out, const
   fe_store<FT>(wire_out + i * 16, x);
   fe_store<FT>(wire_out + i * 16 + 8, y);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // k_te_bucket_reduce / k_te_window_sum: reduceBucketsChunk (src/msm-basic.ts:180-211) per chunk of TC
@@ -333,7 +360,11 @@ MSM_DEV void ext_load_raw(Ext& P, const uint32_t* src) {
 // bucket is down to a few elements one lane per bucket sums them in sequence (replaces ~5 latency-bound tail rounds).
 // perm: buckets in descending order of remaining count (k_finish_perm), so a wave's lanes finish together.
 __global__ void __launch_bounds__(256) k_te_bucket_finish(uint32_t* bucket_ext, const uint4* in, uint64_t in_cap, const uint32_t* off,
-                                                          uint32_t nb, const uint32_t* perm) {
+                                                          uint32_t nb, const uint32_t* perm)
+#ifndef MSM_TE_TU
+    ;
+#else
+{
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   if (perm) b = perm[b];
@@ -348,10 +379,15 @@ __global__ void __launch_bounds__(256) k_te_bucket_finish(uint32_t* bucket_ext, 
   }
   ext_store_raw(bucket_ext + (uint64_t)b * (4 * TL), acc);
 }
+#endif
 
 __global__ void __launch_bounds__(64) k_te_bucket_reduce(uint32_t* columns, const uint4* fin, uint64_t fin_cap, const uint32_t* off_fin,
                                                           const uint32_t* bucket_ext, uint32_t L, uint32_t TC, uint32_t nchunks,
-                                                          uint32_t k_cnt) {
+                                                          uint32_t k_cnt)
+#ifndef MSM_TE_TU
+    ;
+#else
+{
   uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= nchunks * k_cnt) return;
   uint32_t kk = id / nchunks, ch = id - kk * nchunks;
@@ -389,11 +425,16 @@ __global__ void __launch_bounds__(64) k_te_bucket_reduce(uint32_t* columns, cons
   }
   ext_store_raw(columns + (uint64_t)id * (4 * TL), tri);
 }
+#endif
 
 constexpr int TE_WS_THREADS = 256;
 
 // output: 4 x 8 packed words (X, Y, Z, T), Montgomery form, values < 2p
-__global__ void __launch_bounds__(TE_WS_THREADS) k_te_window_sum(uint32_t* partials, const uint32_t* columns, uint32_t nchunks) {
+__global__ void __launch_bounds__(TE_WS_THREADS) k_te_window_sum(uint32_t* partials, const uint32_t* columns, uint32_t nchunks)
+#ifndef MSM_TE_TU
+    ;
+#else
+{
   __shared__ uint32_t lds[4 * TL * TE_WS_THREADS];
   const uint32_t kk = blockIdx.x, tid = threadIdx.x;
   Ext acc;
@@ -446,9 +487,14 @@ __global__ void __launch_bounds__(TE_WS_THREADS) k_te_window_sum(uint32_t* parti
     for (int j = 0; j < TW; j++) dst[24 + j] = w[j];
   }
 }
+#endif
 
 // element-wise base-field operators for parity tests (same op codes as k_test_fp)
-__global__ void __launch_bounds__(256) k_te_test_fp(uint32_t* out, const uint32_t* a, const uint32_t* b, uint32_t n, int op) {
+__global__ void __launch_bounds__(256) k_te_test_fp(uint32_t* out, const uint32_t* a, const uint32_t* b, uint32_t n, int op)
+#ifndef MSM_TE_TU
+    ;
+#else
+{
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fe<FT> x, y, r;
@@ -480,9 +526,14 @@ __global__ void __launch_bounds__(256) k_te_test_fp(uint32_t* out, const uint32_
   fe_reduce_4p<FT>(r);
   fe_store<FT>(out + (uint64_t)i * TW, r);
 }
+#endif
 
 // raw-limb multiplier test on the 253-bit field (see k_test_fp_raw)
-__global__ void __launch_bounds__(256) k_te_test_fp_raw(uint32_t* out, const uint32_t* a, const uint32_t* b, uint32_t n, int op) {
+__global__ void __launch_bounds__(256) k_te_test_fp_raw(uint32_t* out, const uint32_t* a, const uint32_t* b, uint32_t n, int op)
+#ifndef MSM_TE_TU
+    ;
+#else
+{
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fe<FT> x, y, r;
@@ -493,10 +544,15 @@ __global__ void __launch_bounds__(256) k_te_test_fp_raw(uint32_t* out, const uin
 #pragma unroll
   for (int l = 0; l < TL; l++) out[(uint64_t)i * TL + l] = r.l[l];
 }
+#endif
 
 // general unified addition (te_add, 9M) on extended points (X, Y, Z, T: 4 x 8 canonical plain-integer words each):
 // the operator of src/curve-twisted-edwards.test.ts:55-158; op 1 = doubling through the same formula (P + P)
-__global__ void __launch_bounds__(64) k_te_test_curve_op(uint32_t* out, const uint32_t* pp, const uint32_t* qq, uint32_t n, int op) {
+__global__ void __launch_bounds__(64) k_te_test_curve_op(uint32_t* out, const uint32_t* pp, const uint32_t* qq, uint32_t n, int op)
+#ifndef MSM_TE_TU
+    ;
+#else
+{
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fe<FT> r2, one;
@@ -518,6 +574,7 @@ __global__ void __launch_bounds__(64) k_te_test_curve_op(uint32_t* out, const ui
     fe_store<FT>(out + (uint64_t)i * 32 + j * 8, *ro[j]);
   }
 }
+#endif
 
 }  // namespace te
 }  // namespace msm

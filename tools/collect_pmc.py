@@ -6,7 +6,10 @@ both reported in KB) and SQ_INSTS_VALU / 64 lanes, each divided by the ALGORITHM
 import collections, csv, glob, json, os, sys
 
 tag, lg = sys.argv[1], int(sys.argv[2])
-src = f"gpurun_out/pmc_{tag}_2p{lg}"
+curve = sys.argv[3] if len(sys.argv) > 3 else "bls12-377"     # ed377: the twisted Edwards tree kernel k_te_add
+sfx = "" if curve == "bls12-377" else "_" + curve
+src = f"gpurun_out/pmc_{tag}{sfx}_2p{lg}"
+TREE = "te::k_te_add<" if curve == "ed377" else "k_batch_add<msm::CvBls377"
 out, clocks = {}, {}
 for kind in ("fetch", "write", "sq", "grbm"):
     fs = sorted(glob.glob(f"{src}/pmc_{kind}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1:]
@@ -32,21 +35,22 @@ for kind in ("fetch", "write", "sq", "grbm"):
                   if c / 8 / d < 3.0}
 
 # the bench line of the fetch pass: pair additions of the MSMs the run held (timed step + serialised step)
-pairs_algo = pairs_issued = msms = None
+pairs_algo = pairs_issued = msms = entries = None
 window_bits = None
 for line in open(f"{src}/pmc_fetch.log", errors="ignore"):
     if line.startswith("{"):
         b = json.loads(line)
-        msms = b["steps"] + b["warmup"] + 1
+        msms = b["steps"] + b["warmup"] + (0 if curve == "ed377" else 1)   # + the serialised "exclusive" step
         pairs_algo = b["roofline"]["pair_adds_per_step"] * msms
         pairs_issued = b["roofline"]["pair_adds_issued_per_step"] * msms
         window_bits = b["config"]["window_bits"]
+        entries = (1 if curve == "ed377" else 2) * (1 << lg) * b["config"]["windows"] * msms
 per_pair = {}
 if pairs_algo:
     def tot(kind, ctr, key):
         return sum(v.get(ctr, 0.0) for k, v in out.get(kind, {}).items() if key in k)
-    for name, key in (("gather_round", "k_batch_add<msm::CvBls377, 0>"), ("regular_rounds", "k_batch_add<msm::CvBls377, 1>"),
-                      ("all_rounds", "k_batch_add<msm::CvBls377")):
+    gk, rk = (TREE + "0>", TREE + "1>") if curve == "ed377" else (TREE + ", 0>", TREE + ", 1>")
+    for name, key in (("gather_round", gk), ("regular_rounds", rk), ("all_rounds", TREE)):
         fetch, write, valu = tot("fetch", "FETCH_SIZE", key) * 1024, tot("write", "WRITE_SIZE", key) * 1024, tot("sq", "SQ_INSTS_VALU", key)
         per_pair[name] = {"fetch_bytes_x2": 2 * fetch, "write_bytes": write, "valu_wave_insts": valu}
     # pair additions per kind of round: the gather round does half of a bucket's additions (n - 1 of them for n entries split
@@ -62,13 +66,25 @@ if pairs_algo:
         p["pair_adds_basis"] = denom
         p["hbm_bytes_per_pair_add"] = (p["fetch_bytes_x2"] + p["write_bytes"]) / denom
         p["valu_insts_per_pair_add"] = p["valu_wave_insts"] / (denom / 64)
+# the scatter phase (digits + sort kernels): HBM bytes per (entry, window) and its share of the wall time
+sort_keys = ("k_digits", "k_te_digits", "k_hist", "k_colscan", "k_coarse_offsets", "k_vscan", "k_radix_", "k_fine_hist", "k_scatter_lds",
+             "k_chunk_order", "k_pscan", "k_bucket_max", "k_pair_", "k_bin_")
+def is_sort(k):
+    return any(s in k for s in sort_keys)
+scatter = None
+if entries:
+    fb = sum(v.get("FETCH_SIZE", 0.0) for k, v in out.get("fetch", {}).items() if is_sort(k)) * 1024 * 2
+    wb = sum(v.get("WRITE_SIZE", 0.0) for k, v in out.get("write", {}).items() if is_sort(k)) * 1024
+    wall = sum(v["wall_ms"] for k, v in clocks.items() if is_sort(k))
+    scatter = {"entries": entries, "fetch_bytes_x2": fb, "write_bytes": wb, "hbm_bytes_per_entry": (fb + wb) / entries,
+               "wall_ms_of_kernels_over_0p3ms": wall, "note": "digits + histogram + scans + radix passes (+ fills excluded); entries = 2 N K x MSMs in the run"}
 os.makedirs("profiles", exist_ok=True)
 json.dump({"command": f"rocprofv3 --pmc <one counter group per run: FETCH_SIZE | WRITE_SIZE | SQ_* | GRBM_GUI_ACTIVE> -- python3 bench.py "
-                      f"--steps 1 --warmup 0 --log2n {lg} --no-cpu-baseline --no-verify --no-other-configs --no-pcie",
+                      f"--steps 1 --warmup 0 --log2n {lg}{' --curve ' + curve if sfx else ''} --no-cpu-baseline --no-verify --no-other-configs --no-pcie",
            "note": "FETCH_SIZE / WRITE_SIZE in KB as reported (x 1024 below); FETCH_SIZE is doubled for HBM bytes (gfx950 halves wide "
                    "coalesced reads, MI355X_MICROARCH.md); SQ_* cycle counters in quad-cycles; GRBM_GUI_ACTIVE summed over the 8 XCDs. "
                    "Per-pair figures divide by algorithmic pair additions (half of them in the gather round).",
            "window_bits": window_bits, "msms_in_run": msms, "pair_adds_algorithmic": pairs_algo, "pair_adds_issued": pairs_issued,
-           "per_pair_addition": per_pair, "effective_clock_ghz": clocks, "counters": out},
-          open(f"profiles/{tag}_pmc_2p{lg}.json", "w"), indent=1)
+           "per_pair_addition": per_pair, "scatter_phase": scatter, "effective_clock_ghz": clocks, "counters": out},
+          open(f"profiles/{tag}_pmc{sfx}_2p{lg}.json", "w"), indent=1)
 print("collected", tag, lg, json.dumps(per_pair.get("all_rounds", {})))
