@@ -43,7 +43,7 @@ struct BatchArgs {
   uint32_t steps;
   const uint32_t* desc;     // MODE_SEARCH: operand descriptors from k_tail_desc
   uint64_t sstride;         // lanes per scratch plane (>= T; see ba_store_pre)
-  const uint16_t* oidx;     // MODE_GATHER, chunk-ordered pairs (k_chunk_order): pair e writes element (e & ~(CO_PAIRS - 1)) + oidx[e]
+  const uint32_t* dest;     // MODE_GATHER, pairs in the sort's tile order (k_bin_pairs): pair e writes element dest[e]
   uint32_t* out_rows;       // MODE_GATHER: if set, results leave as 64-byte element records instead of planes (element k: its x record
                             // at byte 64 k, its y record out_y_off bytes further; 8-word fields: one record [x | y]); a round with
                             // slots == nullptr reads such records back through `points` (pair e = elements 2e, 2e + 1)
@@ -53,10 +53,6 @@ struct BatchArgs {
   uint32_t inplace;         // MODE_SEARCH: the sum replaces the FIRST operand (out == in): the in-place batched additions of the
                             // all-affine bucket reduction, src/msm-batched-affine-single-thread.ts:522-667
 };
-#ifndef MSM_CO_PAIRS
-#define MSM_CO_PAIRS 4096
-#endif
-constexpr uint32_t CO_PAIRS = MSM_CO_PAIRS;   // pairs per block of k_chunk_order (sort_kernels.h)
 
 constexpr int BA_THREADS = 256;
 // Phase fence: hipcc's scheduler otherwise interleaves independent multiplications of one step (inv * den with num * d,
@@ -440,7 +436,7 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
       const bool active = is_active((uint32_t)i);
       const uint64_t e_cur = (uint64_t)BA_STEP(i) * T + t;
       uint32_t o_local = 0;
-      if (MODE == MODE_GATHER && a.oidx && active) o_local = a.oidx[e_cur];
+      if (MODE == MODE_GATHER && a.dest && active) o_local = a.dest[e_cur];
       Fe<F> d, den, num;
       BA_MUL(d, inv, pre);                         // 1 / den_i
       BA_FENCE();
@@ -530,13 +526,13 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
       if (i > 0) ba_load_y<F, MODE>(y1, y2, Ln, a, t);   // the next pair's y: in flight during the stores and d = inv * pre
       if (!(kind & BA_SKIP)) {
         if (MODE == MODE_GATHER && a.out_rows) {
-          // Uniform: chunk-ordered round 1.  The pair's element index comes from the table, and the element leaves as whole
+          // Uniform: round 1 over the sort's tile-ordered pairs.  The pair's element index comes from the table, and the element leaves as whole
           // 64-byte records: a permuted store of 16-byte plane pieces leaves every line partly written by several workgroups (on
           // different XCDs), and the memory side then reads, merges and rewrites each of them (measured: round 1 68 -> 107 ms);
           // aligned 64-byte pieces go through.  12-word fields: an x record [x | 16 bytes] and, a.out_y_off bytes further, a y record
           // -- the two x of the next round's pair (2k, 2k + 1) are then one 128-byte line, and its forward sweep touches nothing
           // else.  8-word fields: one record [x | y].
-          const uint64_t o = a.oidx ? (e_cur & ~(uint64_t)(CO_PAIRS - 1)) + o_local : e_cur;
+          const uint64_t o = a.dest ? (uint64_t)o_local : e_cur;
           uint4* rx = reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.out_rows) + o * 64);
           if constexpr (NP == 3) {
             uint4* ry = reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.out_rows) + a.out_y_off + o * 64);

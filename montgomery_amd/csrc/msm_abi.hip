@@ -42,8 +42,7 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     // leave room for the resident points (144 B/point at 2^26 = 9.7 GB) and fragmentation
     ctx->ws_budget = (uint64_t)(free_b * 0.55);
     ctx->ensure(ctx->errflag, 16);
-    HIPCHK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    sort_kernel_attributes();
   } catch (const HipFail& f) {
     fprintf(stderr, "msm_ctx_create: HIP error %s at line %d\n", hipGetErrorString(f.e), f.line);
     msm_ctx_destroy(ctx);

@@ -213,13 +213,13 @@ struct msm_ctx {
   // window group runs under the ALU-bound accumulation of the other
   struct Workspace {
     msmi::DevBuf dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, columns2, rows_sum, bucket_proj, bufA, bufB,
-        scratch, columns, partials, part, dig2, idx2, idx3, blk_tab2, slots2, oidx, rows1;
+        scratch, columns, partials, part, dig2, idx2, rec, blk_tab2, slots2, dest, rows1;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     uint32_t* h_info = nullptr;   // pinned, 64 words
     uint32_t* h_part = nullptr;   // pinned, window sums read-back
     msmi::DevBuf* all[25] = {&dig, &counts, &cursor, &tail_off, &info, &slots, &block_hist, &scan_partial, &desc, &columns2, &rows_sum,
-                       &bucket_proj, &bufA, &bufB, &scratch, &columns, &partials, &part, &dig2, &idx2, &idx3, &blk_tab2, &slots2, &oidx, &rows1};
+                       &bucket_proj, &bufA, &bufB, &scratch, &columns, &partials, &part, &dig2, &idx2, &rec, &blk_tab2, &slots2, &dest, &rows1};
   };
   static constexpr int N_WS = 2;
   Workspace ws[N_WS];
@@ -351,10 +351,10 @@ struct SortOut {
   int RT = 0;                   // tail rounds the largest bucket would need
   uint64_t total_slots = 0;
   uint32_t max_bucket = 0;
-  const uint32_t* round1_slots = nullptr;   // pairs round 1 walks (bucket order, or chunk order)
-  const uint16_t* round1_oidx = nullptr;    // chunk order: element index of every pair inside its block
+  const uint32_t* round1_slots = nullptr;   // pairs round 1 walks (bucket order, or the tile order of k_bin_pairs)
+  const uint32_t* round1_dest = nullptr;    // tile order: the element index every pair's sum belongs to
   uint64_t rec_y_off = 0;       // 12-word fields: where the y records of round 1's results start inside w.rows1
-  bool chunked = false;         // round 1 walks chunk-ordered pairs and writes element records, round 2 reads them
+  bool chunked = false;         // round 1 walks tile-ordered pairs and writes element records, round 2 reads them
 };
 void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars, uint64_t n, const Plan& pl, int k_lo, int k_hi,
                        GroupStats& st, SortOut& so);

@@ -47,6 +47,13 @@ constexpr int ROW_Y = 12;       // word offset of y inside a line of the 12-word
 constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t INF_WORD = 0xFFFFFFFFu;
 
+// How window kk's bucket index (l - 1) is cut for the LDS-staged passes of the sort (sort_kernels.h):
+// | ab coarse bits | mb mid bits | fb fine bits |.  Two-pass radix split (c <= 16): mb = 0, fb = 7.  Bin split (c > 16): mb = 0,
+// the cut is made on the window's EFFECTIVE bits (a short top window fills only the low end of its bucket range).
+struct WinSplit {
+  uint8_t ab[16], mb[16], fb[16];
+};
+
 }  // namespace msm
 #include "batch_add.h"   // k_batch_add: the accumulation tree round
 namespace msm {
@@ -194,13 +201,29 @@ MSM_DEV bool words8_ge(const uint32_t (&a)[8], const uint32_t* q) {
 // windows [k_lo, k_lo + k_cnt) of K_total are emitted (window groups / multi-GPU window shards)
 // glv: bit 0 = endomorphism split, bit 1 = folded top window (Plan::fold, msm_api.hip): window K_total - 1 is c + 1 bits wide
 // and keeps its value as it is -- at most 2^c, it cannot carry out.
+// Slices: block b owns the points [b * pps, (b + 1) * pps).  slice_hist != nullptr (the bin split of big windows): the block also
+// counts, per window, the coarse bins ((l - 1) >> ws.fb[kk]) of the digits it writes -- in the LDS, `hb` counters per window -- and
+// leaves them in slice_hist[(kk * gridDim.x + b) * hb + bin]: the digits are in registers here, a separate histogram pass would
+// read all of them again.
+MSM_DEV void digit_note(uint32_t* lds_hist, uint32_t hb, const WinSplit& ws, int kk, uint32_t l) {
+  if (lds_hist && l) atomicAdd(&lds_hist[(uint32_t)kk * hb + ((l - 1) >> ws.fb[kk])], 1u);
+}
+
 template <class CV>
 __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, const uint32_t* scalars, uint32_t n, int c, int k_total,
-                                                int k_lo, int k_cnt, int glv_flags, int strict, uint32_t* err) {
+                                                int k_lo, int k_cnt, int glv_flags, int strict, uint32_t* err, uint32_t pps,
+                                                uint32_t* slice_hist, uint32_t hb, WinSplit ws) {
+  extern __shared__ uint32_t lds_dig_hist[];
+  uint32_t* lds_hist = slice_hist ? lds_dig_hist : nullptr;
+  if (lds_hist) {
+    for (uint32_t j = threadIdx.x; j < (uint32_t)k_cnt * hb; j += blockDim.x) lds_hist[j] = 0;
+    __syncthreads();
+  }
   const int glv = glv_flags & 1;
   const bool fold = glv_flags & 2;
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const uint64_t p_end = min((uint64_t)(blockIdx.x + 1) * pps, (uint64_t)n);
+  for (uint64_t i64 = (uint64_t)blockIdx.x * pps + threadIdx.x; i64 < p_end; i64 += blockDim.x) {
+  const uint32_t i = (uint32_t)i64;
   uint32_t s[8];
   {
     const uint4* p4 = reinterpret_cast<const uint4*>(scalars + (uint64_t)i * 8);
@@ -231,9 +254,10 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, const uint32_t* s
       if (kk >= 0 && kk < k_cnt) {
         dig[(uint64_t)kk * two_n + 2ull * i] = l | (carry << 31);
         dig[(uint64_t)kk * two_n + 2ull * i + 1] = 0u;
+        digit_note(lds_hist, hb, ws, kk, l);
       }
     }
-    return;
+    continue;
   }
   GlvHalf h[2];
   glv_decompose<typename CV::G>(h[0], h[1], s);
@@ -248,7 +272,16 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, const uint32_t* s
       if (kk >= 0 && kk < k_cnt) {
         uint32_t neg = carry ^ (h[hh].neg ? 1u : 0u);
         dig[(uint64_t)kk * two_n + 2ull * i + hh] = l | (neg << 31);
+        digit_note(lds_hist, hb, ws, kk, l);
       }
+    }
+  }
+  }
+  if (lds_hist) {
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < (uint32_t)k_cnt * hb; j += blockDim.x) {
+      const uint32_t kk = j / hb, h = j - kk * hb;
+      slice_hist[((uint64_t)kk * gridDim.x + blockIdx.x) * hb + h] = lds_hist[j];
     }
   }
 }

@@ -125,14 +125,14 @@ RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather, bool lone)
 
 // how many windows fit one group under the workspace budget
 long double window_bytes(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
-  // bytes per window and point (Weierstrass: 2 entries per point): digits 8, record arrays of the radix passes 16 (+ 8 for the
-  // third pass of windows above 2^15 buckets), slots ~9, tree buffers 96 + 48, prefix scratch 56; a chunk-ordered round 1
-  // (c >= 18) adds its reordered slots, the index table and the element records (128 bytes per pair), and its plane buffers start one round
+  // bytes per window and point (Weierstrass: 2 entries per point): digits 8, records of the sort's passes 16, slots (or the pair
+  // list of a big window) ~9, tree buffers 96 + 48, prefix scratch 56; the tile-ordered round 1 of a big window (c >= 18) adds
+  // the element index of every pair (4) and the element records (128 bytes per pair), and its plane buffers start one round
   // later.  Per window and bucket: counters, cursors, up to 34 offset tables, and the block histograms of the sort.
   const bool te = ctx->is_te();
   const bool big = pl.c > 16;
   long double per_point = te ? (4 + 8 + 5 + 64 + 32) : (8 + 16 + 9 + 96 + 48 + 56);
-  if (big && !te) per_point += 8 + 9 + 2 + 128 - 72;
+  if (big && !te) per_point += 4 + 128 - 72;
   const long double hist_bins = big ? (long double)(pl.L >> 7) : (long double)pl.L;
   return (long double)n * per_point + (long double)pl.L * 4 * 40 + hist_bins * 4 * (2.0L * ctx->n_cu);
 }

@@ -9,8 +9,17 @@ using namespace msmi;
 namespace msmi {
 
 void sort_kernel_attributes() {
+  // dynamic LDS above the 64 KB a launch gets by default
   HIPCHK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_bin_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_split_lds(1u << BS_MAX_AB)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_bin_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_pairs_lds(1u << BS_MAX_FB)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_bin_slots, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_slots_lds(1u << BS_MAX_FB)));
+  const int dig_lds = 16 * (1 << BS_MAX_AB) * 4;   // the fused histogram of up to 16 windows
+  HIPCHK(hipFuncSetAttribute((const void*)k_digits<CvBls377>, hipFuncAttributeMaxDynamicSharedMemorySize, dig_lds));
+  HIPCHK(hipFuncSetAttribute((const void*)k_digits<CvBls381>, hipFuncAttributeMaxDynamicSharedMemorySize, dig_lds));
+  HIPCHK(hipFuncSetAttribute((const void*)k_digits<CvPallas>, hipFuncAttributeMaxDynamicSharedMemorySize, dig_lds));
+  HIPCHK(hipFuncSetAttribute((const void*)te::k_te_digits, hipFuncAttributeMaxDynamicSharedMemorySize, dig_lds));
 }
 
 // windows [k_lo, k_hi) over n points whose scalars start at d_scalars (n x 8 words); queues everything on w.stream, records
@@ -41,108 +50,106 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
 
   ctx->ensure(w.dig, n_entries * 4);
   ctx->ensure(w.counts, nb * 4);
-  ctx->ensure(w.cursor, nb * 4);
+  ctx->ensure(w.cursor, (nb + 1) * 4);   // [nb] = the total (k_pscan_final)
   ctx->ensure(w.tail_off, (size_t)34 * (nb + 1) * 4);
   ctx->ensure(w.info, 64 * 4);
 
   // Sort path: LDS-privatised histogram / ranking, every pass staged through the LDS so that a wave store is a full segment
   // (sort_kernels.h; a direct scatter sends each 4-byte payload to a line of its own: round 1 wrote 7.7x the algorithmic bytes).
   //   one level  : a window's counters fit the LDS (c <= 16) and the input is small
-  //   two passes : c <= 16, big inputs -- 2^(c-8) coarse bins x 128 buckets
-  //   three passes: c > 16 (up to c = 24, the largest window make_plan accepts) -- coarse bins x mid bins x 128 (256) buckets
+  //   radix split: c <= 16, big inputs -- 2^(c-8) coarse bins x 128 buckets, two passes over pairs of 4-byte arrays
+  //   bin split  : c > 16 (up to c = 24, the largest window make_plan accepts) -- coarse bins x up to 2^12 buckets, two passes
+  //                over 8-byte records, the histogram of the first fused into the digit kernel, the second emitting the pairs
+  //                of round 1 in an order that keeps its row gathers local
   const int cbits = pl.L_log;   // bits of a bucket index
   const bool fits_lds = (size_t)L * 4 <= 128 * 1024;
   long long want_radix = (fits_lds && cbits > (int)RX_FINE_BITS && two_n >= (1ull << 22)) ? 1 : 0;   // measured: wins from N = 2^21 up
   MSM_KNOB(want_radix, "MSM_RADIX", 0);
   const bool radix = fits_lds && want_radix && cbits > (int)RX_FINE_BITS && cbits - (int)RX_FINE_BITS <= 8;
   const bool one_level = fits_lds && !radix;
-  const bool three_pass = !fits_lds;
-  const uint32_t fb = three_pass ? (cbits >= 23 ? 8u : 7u) : RX_FINE_BITS;   // bucket bits sorted by the last pass (full windows)
-  const uint32_t shift = radix ? (uint32_t)cbits - fb : 0;                  // two passes: log2 of the coarse bins
-  const uint32_t Hn = 1u << shift;
-  const uint32_t Lp = three_pass ? 1u << ((uint32_t)cbits - fb) : Hn;        // fine windows (blocks of the last pass) per window
-  const uint32_t V = (uint32_t)kc * Lp;
+  const bool bin_split = !fits_lds;
   WinSplit ws{};
-  if (three_pass) {
+  uint32_t hb = 1, nbmax = 1;   // bin split: coarse bins per window (stride of the bin tables), most buckets of one bin
+  if (bin_split) {
     if (kc > 16) throw MsmFail{MSM_ERR_INTERNAL, "more than 16 windows in a group of a window size above 16"};
-    const int lp_log = cbits - (int)fb;
     for (int kk = 0; kk < kc; kk++) {
-      // bits the digits of this window really have: the top window of a scalar is usually short (sort_kernels.h, WinSplit)
+      // bits the digits of this window really have: the top window of a scalar is usually short (msm_kernels.h, WinSplit)
       // (a window below the top one holds signed digits of magnitude <= 2^(c - 1); the top one what is left of the scalar)
       const bool top = k_lo + kk == pl.K - 1;
       const int eff = std::max(1, top ? std::min(cbits, pl.bits - (k_lo + kk) * pl.c) : std::min(cbits, pl.c - 1));
-      const int fbk = std::max(0, eff - lp_log);
-      const int hi = eff - fbk;
-      ws.fb[kk] = (uint8_t)fbk;
-      ws.ab[kk] = (uint8_t)std::min(8, hi);
-      ws.mb[kk] = (uint8_t)(hi - ws.ab[kk]);
+      // up to 10 bits: pass A sorts the window outright; else 2^10 coarse bins (16-entry runs of a 16 k tile), 2^11 if the
+      // fine part would otherwise exceed 2^12 buckets per bin
+      const int abk = eff <= 10 ? eff : std::max(10, eff - (int)BS_MAX_FB);
+      if (abk > (int)BS_MAX_AB) throw MsmFail{MSM_ERR_INTERNAL, "window too wide for the bin split"};
+      ws.ab[kk] = (uint8_t)abk;
+      ws.fb[kk] = (uint8_t)(eff - abk);
+      hb = std::max(hb, 1u << abk);
+      nbmax = std::max(nbmax, 1u << (eff - abk));
     }
   } else if (radix) {
     if (kc > 16) throw MsmFail{MSM_ERR_INTERNAL, "more than 16 windows in a radix-split group"};
-    for (int kk = 0; kk < kc; kk++) { ws.ab[kk] = (uint8_t)shift; ws.fb[kk] = (uint8_t)fb; }
+    for (int kk = 0; kk < kc; kk++) { ws.ab[kk] = (uint8_t)(cbits - (int)RX_FINE_BITS); ws.fb[kk] = (uint8_t)RX_FINE_BITS; }
   }
+  const uint32_t Hn = radix ? 1u << (cbits - (int)RX_FINE_BITS) : 1u;   // radix split: coarse bins = blocks of its last pass per window
+  const uint32_t V = (uint32_t)kc * (bin_split ? hb : Hn);              // bins of the group
+  // slices of the entries: block (b, kk) of the histogram and of the first pass owns entries [b * chunk, (b + 1) * chunk)
   uint32_t sortB = 1;
-  uint64_t chunk = two_n;
-  {
+  uint64_t chunk = two_n, pps = n;   // entries per slice and window; points per slice
+  if (bin_split) {
+    // the digit kernel histograms ALL windows of the group over its slice of the points: four slices per CU
+    long long mult = 4;
+    MSM_KNOB(mult, "MSM_SORTB_MULT", 1);
+    sortB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)mult * ctx->n_cu, n / 4096));
+    pps = (n + sortB - 1) / sortB;
+    chunk = (te ? 1 : 2) * pps;
+    ctx->ensure(w.block_hist, (size_t)kc * sortB * hb * 4 + 64);
+  } else {
     // big inputs: finer slices also keep the round-1 gathers of neighbouring lanes inside one Infinity-Cache-sized
     // range of point rows (measured: 193 -> 183 ms at 2^26); small inputs: fewer, larger blocks (less fixed cost)
     uint64_t mult = two_n >= (1ull << 27) ? 8 : two_n >= (1ull << 24) ? 4 : 2;   // measured 2^21 .. 2^26
-    if (three_pass) mult = std::min<uint64_t>(mult, 4);   // the chunk-ordered round 1 makes its own locality: fewer, larger slices
     MSM_KNOB(mult, "MSM_SORTB_MULT", 1);
     uint64_t want = std::max<uint64_t>(1, (mult * ctx->n_cu + kc - 1) / kc);
     uint64_t maxb = std::max<uint64_t>(1, two_n / 8192);
     sortB = (uint32_t)std::min<uint64_t>(want, maxb);
     chunk = (two_n + sortB - 1) / sortB;
-    ctx->ensure(w.block_hist, (size_t)kc * sortB * (three_pass ? Lp : L) * 4 + 64);
+    ctx->ensure(w.block_hist, (size_t)kc * sortB * L * 4 + 64);
   }
-  const uint32_t* d_v2start = nullptr;   // three passes: starts of the fine windows in the record arrays
-  const uint32_t* d_rec_dig = nullptr;   // records read by the last pass
-  const uint32_t* d_rec_idx = nullptr;
+  uint32_t* d_bin_start = nullptr;   // bin split: V + 1 starts of the bins in the record array
 
   HIPCHK(hipEventRecord(w.ev[0], s));
   {
-    uint32_t grid = (uint32_t)((n + 255) / 256);
+    // digits; the bin split also takes the histogram of its first pass from here (one slice of the points per block)
+    const uint32_t grid = bin_split ? sortB : (uint32_t)((n + 255) / 256);
+    const uint32_t per = bin_split ? (uint32_t)pps : 256u;
+    uint32_t* hist = bin_split ? (uint32_t*)w.block_hist.p : nullptr;
+    const size_t lds = bin_split ? (size_t)kc * hb * 4 : 0;
     if (te)
-      hipLaunchKernelGGL(te::k_te_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K,
-                         k_lo, kc, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p);
+      hipLaunchKernelGGL(te::k_te_digits, dim3(grid), dim3(256), lds, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K,
+                         k_lo, kc, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, ws);
     else
-      W_LAUNCH(ctx, k_digits, dim3(grid), dim3(256), 0, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K, k_lo, kc,
-                         (pl.no_glv ? 0 : 1) | (pl.fold ? 2 : 0), pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p);
+      W_LAUNCH(ctx, k_digits, dim3(grid), dim3(256), lds, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K, k_lo, kc,
+                         (pl.no_glv ? 0 : 1) | (pl.fold ? 2 : 0), pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, ws);
   }
   HIPCHK(hipEventRecord(w.ev[1], s));
-  if (!three_pass) {
+  if (!bin_split) {
     hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.block_hist.p,
-                       (const uint32_t*)w.dig.p, two_n, chunk, L, ws, 0u, 0u);
+                       (const uint32_t*)w.dig.p, two_n, chunk, L, 0u);
     hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.block_hist.p,
                        (uint32_t*)w.counts.p, sortB, L, (uint32_t)kc);
   } else {
-    // totals of the fine windows -> their starts (= the starts of the mid and coarse bins too); pass A; pass M; bucket sizes
-    const size_t n_off = (size_t)kc * sortB * 256;
-    ctx->ensure(w.part, ((size_t)2 * V + 2 + n_off) * 4);
-    uint32_t* d_v2tot = (uint32_t*)w.part.p;
-    uint32_t* d_vs = d_v2tot + V;
-    uint32_t* d_blk_off = d_vs + V + 1;
-    ctx->ensure(w.dig2, n_entries * 4);
-    ctx->ensure(w.idx2, n_entries * 4);
-    ctx->ensure(w.idx3, n_entries * 4);
-    hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)Lp * 4, s, (uint32_t*)w.block_hist.p,
-                       (const uint32_t*)w.dig.p, two_n, chunk, Lp, ws, 1u, 0u);
-    hipLaunchKernelGGL(k_colscan, dim3((V + 255) / 256), dim3(256), 0, s, (uint32_t*)w.block_hist.p, d_v2tot, sortB, Lp,
+    // per (window, bin): the slices' prefixes and the total -> the bin starts; pass A; the bucket sizes
+    ctx->ensure(w.part, ((size_t)2 * V + 2) * 4);
+    uint32_t* d_bin_tot = (uint32_t*)w.part.p;
+    d_bin_start = d_bin_tot + V;
+    ctx->ensure(w.rec, n_entries * 8);
+    hipLaunchKernelGGL(k_colscan, dim3((V + 255) / 256), dim3(256), 0, s, (uint32_t*)w.block_hist.p, d_bin_tot, sortB, hb,
                        (uint32_t)kc);
-    hipLaunchKernelGGL(k_coarse_offsets3, dim3((uint32_t)((n_off + 255) / 256)), dim3(256), 0, s, d_blk_off,
-                       (const uint32_t*)w.block_hist.p, sortB, Lp, (uint32_t)kc, ws);
-    hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_vs, (const uint32_t*)d_v2tot, V);
-    hipLaunchKernelGGL(k_radix_coarse, dim3(sortB, kc), dim3(RX_THREADS), 0, s, (uint32_t*)w.dig2.p, (uint32_t*)w.idx2.p,
-                       (const uint32_t*)d_vs, (const uint32_t*)d_blk_off, (const uint32_t*)w.dig.p, two_n, chunk, Lp, 256u, ws);
-    // the digits are dead now: the second record array reuses their buffer
-    hipLaunchKernelGGL(k_radix_mid, dim3(256, kc), dim3(RXB_THREADS), 0, s, (uint32_t*)w.dig.p, (uint32_t*)w.idx3.p,
-                       (const uint32_t*)d_vs, (const uint32_t*)w.dig2.p, (const uint32_t*)w.idx2.p, Lp, ws);
+    hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_bin_start, (const uint32_t*)d_bin_tot, V);
+    hipLaunchKernelGGL(k_bin_split, dim3(sortB, kc), dim3(BS_THREADS), bin_split_lds(hb), s, (uint2*)w.rec.p,
+                       (const uint32_t*)d_bin_start, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n, chunk, hb, ws);
     HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));
-    hipLaunchKernelGGL(k_fine_hist, dim3(V), dim3(256), 0, s, (uint32_t*)w.counts.p, (const uint32_t*)d_vs,
-                       (const uint32_t*)w.dig.p, Lp, L, ws);
-    d_v2start = d_vs;
-    d_rec_dig = (const uint32_t*)w.dig.p;
-    d_rec_idx = (const uint32_t*)w.idx3.p;
+    hipLaunchKernelGGL(k_bin_count, dim3(V), dim3(256), (size_t)nbmax * 4, s, (uint32_t*)w.counts.p, (const uint32_t*)d_bin_start,
+                       (const uint2*)w.rec.p, hb, L, ws);
   }
   int RT = 0;
   uint64_t total_slots = 0;
@@ -172,59 +179,60 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   }
   st.max_bucket = std::max<uint64_t>(st.max_bucket, max_bucket);
 
-  // scatter
-  ctx->ensure(w.slots, std::max<uint64_t>(total_slots, 2) * 4);
-  HIPCHK(hipMemsetAsync(w.slots.p, 0xFF, std::max<uint64_t>(total_slots, 2) * 4, s));
-  if (radix) {
-    // pass A: coarse split into dig2 / idx2; pass B: one block per virtual window, payloads to their padded slots
-    ctx->ensure(w.part, ((size_t)kc * sortB * Hn + 2 * (size_t)V + 2) * 4);
-    uint32_t* d_blk_off = (uint32_t*)w.part.p;
-    uint32_t* d_vtot = d_blk_off + (size_t)kc * sortB * Hn;
-    uint32_t* d_vstart = d_vtot + V;
-    ctx->ensure(w.dig2, n_entries * 4);
-    ctx->ensure(w.idx2, n_entries * 4);
-    const uint64_t co = (uint64_t)kc * (sortB + 1) * Hn;
-    hipLaunchKernelGGL(k_coarse_offsets, dim3((uint32_t)((co + 255) / 256)), dim3(256), 0, s, d_blk_off, d_vtot,
-                       (const uint32_t*)w.block_hist.p, (const uint32_t*)w.counts.p, sortB, L, Hn, (uint32_t)kc);
-    hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_vstart, (const uint32_t*)d_vtot, V);
-    hipLaunchKernelGGL(k_radix_coarse, dim3(sortB, kc), dim3(RX_THREADS), 0, s, (uint32_t*)w.dig2.p, (uint32_t*)w.idx2.p,
-                       (const uint32_t*)d_vstart, (const uint32_t*)d_blk_off, (const uint32_t*)w.dig.p, two_n, chunk, Hn, Hn, ws);
-    hipLaunchKernelGGL(k_radix_fine, dim3(V), dim3(RXB_THREADS), 0, s, (uint32_t*)w.slots.p, (const uint32_t*)w.cursor.p,
-                       (const uint32_t*)d_vstart, (const uint32_t*)w.dig2.p, (const uint32_t*)w.idx2.p, Lp, L, ws);
-  } else if (one_level) {
-    hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.slots.p,
-                       (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n,
-                       chunk, L, 0u);
-  } else {
-    hipLaunchKernelGGL(k_radix_fine, dim3(V), dim3(RXB_THREADS), 0, s, (uint32_t*)w.slots.p, (const uint32_t*)w.cursor.p,
-                       d_v2start, d_rec_dig, d_rec_idx, Lp, L, ws);
-  }
-  // Big windows over a big table: walk round 1 chunk by chunk of the point rows (k_chunk_order, sort_kernels.h).  Needed once
-  // the 128 slots of a wave span more than ~1 GB of rows: 64 L rows of 256 bytes, i.e. from c = 18 with more than 2^22 points.
-  const uint32_t* round1_slots = (const uint32_t*)w.slots.p;
-  const uint16_t* round1_oidx = nullptr;
+  // Big windows over a big table: round 1 walks the pairs in the order the last pass of the sort emits them -- tile by tile of
+  // a bin's records, which are in point order -- and writes every sum to the element index that comes with the pair, as
+  // 64-byte records that round 2 reads back (batch_add.h).  Needed once the 128 slots of a wave span more than ~1 GB of
+  // rows: 64 L rows of 256 bytes, i.e. from c = 18 with more than 2^22 points.
+  const uint32_t* round1_slots = nullptr;
+  const uint32_t* round1_dest = nullptr;
   uint64_t rec_y_off = 0;   // 12-word fields: where the y records of round 1's results start inside w.rows1
-  bool chunked = false;   // round 1 walks chunk-ordered pairs and writes element records, round 2 reads them
+  bool chunked = false;
   {
     long long chunk_rows_log = 22;   // 2^22 rows of 256 bytes = 1 GB
     MSM_KNOB(chunk_rows_log, "MSM_CHUNK_LOG", 10);
-    long long want_chunks = (!te && pl.c >= 18 && n > (1ull << chunk_rows_log)) ? 1 : 0;
+    long long want_chunks = (bin_split && !te && pl.c >= 18 && n > (1ull << chunk_rows_log)) ? 1 : 0;
     MSM_KNOB(want_chunks, "MSM_CHUNKED", 0);
-    const uint64_t nch = (n + (1ull << chunk_rows_log) - 1) >> chunk_rows_log;
     // (round 2 must be an index-free round to read the element records round 1 then writes: logG >= 2)
-    if (want_chunks && !te && logG >= 2 && total_slots >= 2 && nch >= 2 && nch + 1 <= (uint64_t)CO_MAX_KEYS) {
-      const uint64_t n_pairs = total_slots / 2;
-      ctx->ensure(w.slots2, total_slots * 4);
-      ctx->ensure(w.oidx, n_pairs * 2);
-      rec_y_off = (n_pairs * 64 + 255) & ~(uint64_t)255;
-      ctx->ensure(w.rows1, 2 * rec_y_off + 256);
-      hipLaunchKernelGGL(k_chunk_order, dim3((uint32_t)((n_pairs + CO_PAIRS - 1) / CO_PAIRS)), dim3(CO_THREADS), 0, s,
-                         (uint2*)w.slots2.p, (uint16_t*)w.oidx.p, (const uint2*)w.slots.p, n_pairs, (uint32_t)chunk_rows_log,
-                         (uint32_t)nch + 1);
-      round1_slots = (const uint32_t*)w.slots2.p;
-      round1_oidx = (const uint16_t*)w.oidx.p;
-      if (MSM_KNOB_SET("MSM_CHUNK_NOSTORE")) round1_oidx = nullptr;   // experiment (wrong sums): chunk-ordered loads, natural stores
-      chunked = true;
+    chunked = bin_split && want_chunks && !te && logG >= 2 && total_slots >= 2;
+  }
+  // scatter
+  if (chunked) {
+    const uint64_t n_pairs = total_slots / 2;
+    ctx->ensure(w.slots2, total_slots * 4);
+    ctx->ensure(w.dest, n_pairs * 4);
+    rec_y_off = (n_pairs * 64 + 255) & ~(uint64_t)255;
+    ctx->ensure(w.rows1, 2 * rec_y_off + 256);
+    hipLaunchKernelGGL(k_bin_pairs, dim3(V), dim3(BP_THREADS), bin_pairs_lds(nbmax), s, (uint2*)w.slots2.p, (uint32_t*)w.dest.p,
+                       (const uint2*)w.rec.p, (const uint32_t*)d_bin_start, (const uint32_t*)w.cursor.p, hb, L, nbmax, ws);
+    round1_slots = (const uint32_t*)w.slots2.p;
+    round1_dest = (const uint32_t*)w.dest.p;
+  } else {
+    ctx->ensure(w.slots, std::max<uint64_t>(total_slots, 2) * 4);
+    HIPCHK(hipMemsetAsync(w.slots.p, 0xFF, std::max<uint64_t>(total_slots, 2) * 4, s));
+    round1_slots = (const uint32_t*)w.slots.p;
+    if (radix) {
+      // pass A: coarse split into dig2 / idx2; pass B: one block per coarse bin, payloads to their padded slots
+      ctx->ensure(w.part, ((size_t)kc * sortB * Hn + 2 * (size_t)V + 2) * 4);
+      uint32_t* d_blk_off = (uint32_t*)w.part.p;
+      uint32_t* d_vtot = d_blk_off + (size_t)kc * sortB * Hn;
+      uint32_t* d_vstart = d_vtot + V;
+      ctx->ensure(w.dig2, n_entries * 4);
+      ctx->ensure(w.idx2, n_entries * 4);
+      const uint64_t co = (uint64_t)kc * (sortB + 1) * Hn;
+      hipLaunchKernelGGL(k_coarse_offsets, dim3((uint32_t)((co + 255) / 256)), dim3(256), 0, s, d_blk_off, d_vtot,
+                         (const uint32_t*)w.block_hist.p, (const uint32_t*)w.counts.p, sortB, L, Hn, (uint32_t)kc);
+      hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_vstart, (const uint32_t*)d_vtot, V);
+      hipLaunchKernelGGL(k_radix_coarse, dim3(sortB, kc), dim3(RX_THREADS), 0, s, (uint32_t*)w.dig2.p, (uint32_t*)w.idx2.p,
+                         (const uint32_t*)d_vstart, (const uint32_t*)d_blk_off, (const uint32_t*)w.dig.p, two_n, chunk, Hn, ws);
+      hipLaunchKernelGGL(k_radix_fine, dim3(V), dim3(RXB_THREADS), 0, s, (uint32_t*)w.slots.p, (const uint32_t*)w.cursor.p,
+                         (const uint32_t*)d_vstart, (const uint32_t*)w.dig2.p, (const uint32_t*)w.idx2.p, Hn, L, ws);
+    } else if (one_level) {
+      hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.slots.p,
+                         (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n,
+                         chunk, L, 0u);
+    } else {
+      hipLaunchKernelGGL(k_bin_slots, dim3(V), dim3(BP_THREADS), bin_slots_lds(nbmax), s, (uint32_t*)w.slots.p,
+                         (const uint2*)w.rec.p, (const uint32_t*)d_bin_start, (const uint32_t*)w.cursor.p, hb, L, nbmax, ws);
     }
   }
   HIPCHK(hipEventRecord(w.ev[2], s));
@@ -233,7 +241,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   so.total_slots = total_slots;
   so.max_bucket = max_bucket;
   so.round1_slots = round1_slots;
-  so.round1_oidx = round1_oidx;
+  so.round1_dest = round1_dest;
   so.rec_y_off = rec_y_off;
   so.chunked = chunked;
 }

@@ -22,7 +22,7 @@ void accumulate_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const Plan& pl
   const uint64_t total_slots = so.total_slots;
   const uint32_t max_bucket = so.max_bucket;
   const uint32_t* round1_slots = so.round1_slots;
-  const uint16_t* round1_oidx = so.round1_oidx;
+  const uint32_t* round1_dest = so.round1_dest;
   const uint64_t rec_y_off = so.rec_y_off;
   const bool chunked = so.chunked;
 
@@ -88,7 +88,7 @@ void accumulate_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const Plan& pl
       BatchArgs a{};
       a.points = (const uint32_t*)ctx->rows.p + p_lo * (te ? (uint64_t)te::TE_ROW_WORDS : (uint64_t)ROW_WORDS);
       a.slots = r == 1 ? round1_slots : (const uint32_t*)w.slots.p;
-      a.oidx = r == 1 ? round1_oidx : nullptr;
+      a.dest = r == 1 ? round1_dest : nullptr;
       a.in = buf[cur ^ 1];
       a.in_cap = cap[cur ^ 1];
       a.out = buf[cur];

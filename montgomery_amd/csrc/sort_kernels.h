@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(PS_BLOCK) k_pscan_final(const uint32_t* counts
       if (b0 + j < nb) out[b0 + j] = ex;
       ex += v[j];
     }
-    if (q > 0 && blockIdx.x == 0 && threadIdx.x == 0) out[nb] = info[3 + (q - 1)];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[nb] = q == 0 ? info[0] : info[3 + (q - 1)];   // (the cursor has nb + 1 entries too)
   }
 }
 #endif
@@ -194,15 +194,6 @@ __global__ void __launch_bounds__(PS_BLOCK) k_pscan_final(const uint32_t* counts
 
 constexpr int SORT_THREADS = 1024;
 
-// How window kk's bucket index (l - 1) is cut for the LDS-staged passes: | ab coarse bits | mb mid bits | fb fine bits |.
-// Two-pass split (c <= 16): mb = 0, fb = 7.  Three-pass split (c > 16): the cut is made on the window's EFFECTIVE bits -- the
-// top window of a scalar usually holds fewer than c - 1 bits, its digits then fill only the low end of the bucket range, and
-// with a fixed cut all of them would land in a handful of coarse bins and fine windows (= blocks of the later passes).  A
-// window of eff bits keeps as many fine windows as a full one has (2^(c-1-7), fewer buckets each: fb = eff - (c - 1 - 7), 0
-// if there are not even that many buckets), ab <= 8 of the bits above them are the coarse bins, mb the rest.
-struct WinSplit {
-  uint8_t ab[16], mb[16], fb[16];
-};
 
 
 // Ranking with few bins (<= 256, `bits` = log2 of their number): the 64 lanes of a wave then mostly hit the same LDS
@@ -227,18 +218,16 @@ __device__ __forceinline__ uint32_t lds_rank_add(uint32_t* lds, uint32_t bin, bo
   return base + rank;
 }
 
-// Window kk owns digits dig[kk * two_n ..) and block b the slice [b * chunk, (b+1) * chunk); L = number of bins;
-// bin = l - 1, or (l - 1) >> ws.fb[kk] with fine_windows set (the three-pass split counts its fine windows).
+// Window kk owns digits dig[kk * two_n ..) and block b the slice [b * chunk, (b+1) * chunk); L = number of bins; bin = l - 1.
 __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, const uint32_t* dig, uint64_t two_n,
-                                                       uint64_t chunk, uint32_t L, WinSplit ws, uint32_t fine_windows,
-                                                       uint32_t agg_bits)
+                                                       uint64_t chunk, uint32_t L, uint32_t agg_bits)
 #ifndef MSM_SORT_TU
     ;
 #else
 {
   extern __shared__ uint32_t lds_hist[];
   const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x;
-  const uint32_t shift = fine_windows ? ws.fb[kk] : 0u;
+  constexpr uint32_t shift = 0;
   const uint64_t hist_row = (uint64_t)kk * B + b;
   for (uint32_t l = threadIdx.x; l < L; l += SORT_THREADS) lds_hist[l] = 0;
   __syncthreads();
@@ -422,10 +411,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_vscan(uint32_t* v_start, const
 #endif
 
 // pass A.  grid (B, kc); block (b, kk) owns entries [b * chunk, (b + 1) * chunk) of window kk.  Coarse bin h of window kk
-// starts at v_start[kk * vs_stride + (h << mb)]; this block's share of it at + blk_off[(kk * B + b) * bo_stride + h].
+// starts at v_start[kk * Hn + h]; this block's share of it at + blk_off[(kk * B + b) * Hn + h].
 __global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t* dig2, uint32_t* idx2, const uint32_t* v_start,
                                                              const uint32_t* blk_off, const uint32_t* dig, uint64_t two_n,
-                                                             uint64_t chunk, uint32_t vs_stride, uint32_t bo_stride, WinSplit ws)
+                                                             uint64_t chunk, uint32_t Hn_all, WinSplit ws)
 #ifndef MSM_SORT_TU
     ;
 #else
@@ -433,8 +422,8 @@ __global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t
   __shared__ uint2 stage[RXA_TILE];
   __shared__ uint32_t t_cnt[256], t_start[256], g_base[256], lds_wave[RX_THREADS / 64];
   const uint32_t b = blockIdx.x, kk = blockIdx.y, B = gridDim.x, tid = threadIdx.x;
-  const uint32_t hbits = ws.ab[kk], mb = ws.mb[kk], Hn = 1u << hbits, low_bits = ws.fb[kk] + mb;
-  if (tid < Hn) g_base[tid] = v_start[(uint64_t)kk * vs_stride + ((uint64_t)tid << mb)] + blk_off[((uint64_t)kk * B + b) * bo_stride + tid];
+  const uint32_t hbits = ws.ab[kk], Hn = 1u << hbits, low_bits = ws.fb[kk];
+  if (tid < Hn) g_base[tid] = v_start[(uint64_t)kk * Hn_all + tid] + blk_off[((uint64_t)kk * B + b) * Hn_all + tid];
   const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
   const uint32_t* d = dig + (uint64_t)kk * two_n;
   const uint32_t lo_mask = (1u << low_bits) - 1;
@@ -482,10 +471,8 @@ __global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t
 }
 #endif
 
-// pass B.  One block per fine window: block v = kk * Lp + f owns the 2^fb buckets from f << fb of window kk (heaviest -- the
-// top window's few coarse bins on the two-pass path -- first: v = V - 1 - blockIdx.x).  Records: (bucket's low fb bits) + 1 |
-// sign << 31, entry index.  A window with fb = 0 has one bucket per fine window and possibly very few of them (a top window
-// of a handful of bits): ranking is the identity there, and all Lp blocks of the window copy an equal slice of its records.
+// pass B.  One block per coarse bin: block v = kk * Lp + f owns the 2^fb buckets from f << fb of window kk (heaviest -- the
+// top window's few coarse bins -- first: v = V - 1 - blockIdx.x).  Records: (bucket's low fb bits) + 1 | sign << 31, entry index.
 __global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, const uint32_t* cursor, const uint32_t* v_start,
                                                            const uint32_t* dig2, const uint32_t* idx2, uint32_t Lp, uint32_t L,
                                                            WinSplit ws)
@@ -500,21 +487,6 @@ __global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, con
   const uint32_t v = gridDim.x - 1 - blockIdx.x, tid = threadIdx.x;
   const uint32_t kk = v / Lp, f = v - kk * Lp;
   const uint32_t fbits = ws.fb[kk], NB = 1u << fbits;
-  if (fbits == 0) {
-    const uint32_t nfw = 1u << (ws.ab[kk] + ws.mb[kk]);          // fine windows (= buckets) in use
-    const uint32_t* vs = v_start + (uint64_t)kk * Lp;
-    const uint64_t wbeg = vs[0], wlen = (uint64_t)vs[nfw] - wbeg;
-    const uint64_t beg = wbeg + wlen * f / Lp, end = wbeg + wlen * (f + 1) / Lp;
-    for (uint64_t j = beg + tid; j < end; j += RXB_THREADS) {
-      uint32_t lo = 0, hi = nfw;                                  // bucket of record j: last fine window starting at or before it
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (vs[mid] <= j) lo = mid; else hi = mid;
-      }
-      slots[cursor[(uint64_t)kk * L + lo] + (uint32_t)(j - vs[lo])] = (idx2[j] << 1) | (dig2[j] >> 31);
-    }
-    return;
-  }
   const uint64_t beg = v_start[v], end = v_start[v + 1];
   if (beg == end) return;
   if (tid < NB) g_cur[tid] = cursor[(uint64_t)kk * L + ((uint64_t)f << fbits) + tid];
@@ -557,213 +529,354 @@ __global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, con
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// Three-pass split for windows of more than 2^15 buckets (c > 16), where one window's counters no longer fit the LDS.
-//   k_hist (shift = fb)    : per block the histogram over the 2^(c-1-fb) groups of 2^fb buckets ("fine windows")
-//   k_colscan, k_vscan     : totals per fine window -> v2_start (these are also the starts of the mid and coarse bins)
-//   k_coarse_offsets3      : per (window, block, coarse bin) the block's first position in the bin
-//   k_radix_coarse         : pass A by the top ab bits -> (dig2, idx2), records keep mb + fb low bits
-//   k_radix_mid            : pass M, one block per coarse bin, by the next mb bits -> (dig3, idx3), records keep fb bits
-//   k_fine_hist            : bucket sizes, one block per fine window (the scans of the padded slot offsets need them)
-//   k_radix_fine           : pass B as above, payloads to their padded slots
+// Bin split for windows of more than 2^15 buckets (c > 16), where one window's counters no longer fit the LDS: two
+// LDS-staged passes over 8-byte records (round 5; rounds 3-4 ran three passes over pairs of 4-byte arrays plus a histogram
+// pass before and a chunk-ordering pass behind them).  The bucket index l - 1 of window kk is cut on its EFFECTIVE bits
+// into | ab coarse | fb fine | (WinSplit; ab <= 11, fb <= 12):
+//   k_digits / k_te_digits : digits, and per slice of the points the histogram of the coarse bins (fused: msm_kernels.h)
+//   k_colscan, k_vscan     : per (window, bin) the prefix over the slices; the bin starts
+//   k_bin_split  (pass A)  : slice (b, kk) ranks 16 k-entry tiles by coarse bin in the LDS and copies them out as runs of
+//                            records (fine bits + 1 | sign << 31, entry index) -- one 8-byte store stream
+//   k_bin_count            : one block per bin: the bucket sizes (the scans of the padded slots need them)
+//   k_bin_pairs  (pass B)  : one block per bin walks its records in tiles of 4 k and emits the PAIRS round 1 of the tree adds,
+//                            tile by tile, each with the element index its sum belongs to (`dest`).  A bin's records are in
+//                            point order, so a tile -- and with it every run of 64 consecutive pairs -- gathers from one
+//                            ~0.5 GB range of the point rows: the locality the scattered row reads of round 1 need
+//                            (tools/ubench_gather2.hip: 30 G lines/s inside 1 GB per wave instruction, 13 beyond), which
+//                            rounds 3-4 bought with a separate k_chunk_order pass over the bucket-sorted slots.  The list
+//                            leaves as full sequential lines; nothing is scattered by the sort itself any more.
+//   k_bin_slots  (pass B') : the plain form for small inputs -- payloads to their padded slots, bucket order
+// A window of at most 10 effective bits (a short top window) is bucket-sorted by pass A alone (fb = 0): all blocks of
+// pass B then share it by position.
 // ---------------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) k_coarse_offsets3(uint32_t* blk_off, const uint32_t* block_hist, uint32_t B, uint32_t Lp,
-                                                         uint32_t kc, WinSplit ws)
-#ifndef MSM_SORT_TU
-    ;
-#else
-{
-  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (uint64_t)kc * B * 256) return;
-  const uint32_t h = (uint32_t)(id & 255u);
-  const uint64_t row = id >> 8;   // kk * B + b
-  const uint32_t kk = (uint32_t)(row / B);
-  const uint32_t mb = ws.mb[kk];
-  uint32_t sum = 0;
-  if (h < (1u << ws.ab[kk])) {
-    const uint32_t* src = block_hist + row * Lp + ((uint64_t)h << mb);
-    for (uint32_t i = 0; i < (1u << mb); i++) sum += src[i];
-  }
-  blk_off[id] = sum;
-}
+constexpr int BS_THREADS = 1024;
+#ifndef MSM_BS_ITEMS
+#define MSM_BS_ITEMS 16
 #endif
+constexpr int BS_ITEMS = MSM_BS_ITEMS, BS_TILE = BS_THREADS * BS_ITEMS;   // pass A: 16 384 records of 8 bytes staged per tile (128 KB)
+constexpr uint32_t BS_MAX_AB = 11, BS_MAX_FB = 12;
+inline size_t bin_split_lds(uint32_t hb) { return (size_t)BS_TILE * 8 + (size_t)3 * hb * 4 + 64 * 4; }
 
-// pass M.  grid (256, kc): block (h, kk) owns coarse bin h of window kk = the fine windows [h << mb, (h + 1) << mb).
-// A window without mid bits (mb = 0) keeps its order: all 256 blocks copy an equal slice of its records.
-__global__ void __launch_bounds__(RXB_THREADS) k_radix_mid(uint32_t* dig3, uint32_t* idx3, const uint32_t* v2_start,
-                                                          const uint32_t* dig2, const uint32_t* idx2, uint32_t Lp, WinSplit ws)
+// pass A.  grid (SB, kc); block (b, kk) owns entries [b * chunk, (b + 1) * chunk) of window kk.  Coarse bin h of window kk
+// starts at bin_start[kk * hb + h]; this slice's share of it slice_off[(kk * SB + b) * hb + h] further.
+__global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint32_t* bin_start, const uint32_t* slice_off,
+                                                          const uint32_t* dig, uint64_t two_n, uint64_t chunk, uint32_t hb, WinSplit ws)
 #ifndef MSM_SORT_TU
     ;
 #else
 {
-  constexpr uint32_t NBMAX = 128;
-  __shared__ uint2 stage[RXB_TILE];
-  __shared__ uint8_t stage_b[RXB_TILE];
-  __shared__ uint32_t t_cnt[NBMAX], t_start[NBMAX], g_cur[NBMAX], lds_wave[RXB_THREADS / 64];
-  const uint32_t kk = blockIdx.y, h = gridDim.x - 1 - blockIdx.x, tid = threadIdx.x;   // high bins (sparse in a short top window) last
-  const uint32_t mb = ws.mb[kk], NB = 1u << mb, fb = ws.fb[kk];
+  extern __shared__ uint32_t lds_bs[];
+  uint2* stage = reinterpret_cast<uint2*>(lds_bs);       // BS_TILE records
+  uint32_t* t_cnt = lds_bs + 2 * BS_TILE;
+  uint32_t* t_start = t_cnt + hb;
+  uint32_t* g_base = t_start + hb;
+  uint32_t* lds_wave = g_base + hb;                       // 64 words
+  const uint32_t b = blockIdx.x, kk = blockIdx.y, SB = gridDim.x, tid = threadIdx.x;
+  const uint32_t ab = ws.ab[kk], fb = ws.fb[kk], HN = 1u << ab;
+  const uint32_t rank_bits = ab <= 8 ? (ab ? ab : 1u) : 0u;   // few bins: lanes that share one find each other by ballot
+  for (uint32_t h = tid; h < HN; h += BS_THREADS)
+    g_base[h] = bin_start[(uint64_t)kk * hb + h] + slice_off[((uint64_t)kk * SB + b) * hb + h];
+  const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
+  const uint32_t* d = dig + (uint64_t)kk * two_n;
   const uint32_t fmask = (1u << fb) - 1;
-  if (mb == 0) {
-    const uint32_t* vs = v2_start + (uint64_t)kk * Lp;
-    const uint64_t wbeg = vs[0], wlen = (uint64_t)vs[1u << ws.ab[kk]] - wbeg;
-    const uint64_t beg = wbeg + wlen * h / gridDim.x, end = wbeg + wlen * (h + 1) / gridDim.x;
-    for (uint64_t j = beg + tid; j < end; j += RXB_THREADS) {
-      const uint32_t d = dig2[j], l = d & 0xFFFFu;   // every record of the range is an entry (l >= 1)
-      dig3[j] = (((l - 1) & fmask) + 1) | (d & 0x80000000u);
-      idx3[j] = idx2[j];
-    }
-    return;
-  }
-  if (h >= (1u << ws.ab[kk])) return;
-  const uint32_t* vs = v2_start + (uint64_t)kk * Lp + ((uint64_t)h << mb);
-  const uint64_t beg = vs[0], end = vs[NB];
-  if (beg == end) return;
-  if (tid < NB) g_cur[tid] = vs[tid];
-  for (uint64_t t0 = beg; t0 < end; t0 += RXB_TILE) {
-    if (tid < NB) t_cnt[tid] = 0;
+  for (uint64_t t0 = beg; t0 < end; t0 += BS_TILE) {
+    for (uint32_t h = tid; h < HN; h += BS_THREADS) t_cnt[h] = 0;
     __syncthreads();
-    uint32_t dv[RXB_ITEMS], iv[RXB_ITEMS], rk[RXB_ITEMS];
+    uint32_t v[BS_ITEMS], rk[BS_ITEMS];
+    const uint32_t left = (uint32_t)min<uint64_t>(end - t0, BS_TILE);
+    const uint32_t* dt = d + t0;
 #pragma unroll
-    for (int i = 0; i < RXB_ITEMS; i++) {
-      const uint64_t j = t0 + (uint64_t)i * RXB_THREADS + tid;
-      dv[i] = j < end ? dig2[j] : 0u;
-      iv[i] = j < end ? idx2[j] : 0u;
+    for (int i = 0; i < BS_ITEMS; i++) {
+      const uint32_t j = (uint32_t)i * BS_THREADS + tid;
+      v[i] = j < left ? dt[j] : 0u;
     }
 #pragma unroll
-    for (int i = 0; i < RXB_ITEMS; i++) {
-      const uint32_t l = dv[i] & 0xFFFFu;
-      rk[i] = lds_rank_add(t_cnt, l ? (l - 1) >> fb : 0u, l != 0, mb);
+    for (int i = 0; i < BS_ITEMS; i++) {
+      const uint32_t l = v[i] & 0x7FFFFFFFu;
+      rk[i] = lds_rank_add(t_cnt, l ? (l - 1) >> fb : 0u, l != 0, rank_bits);
     }
     __syncthreads();
-    rx_scan_bins(t_start, t_cnt, NB, lds_wave);
+    {   // exclusive scan of the HN <= 2048 tile counters: two per thread
+      const uint32_t c0 = 2 * tid < HN ? t_cnt[2 * tid] : 0u, c1 = 2 * tid + 1 < HN ? t_cnt[2 * tid + 1] : 0u;
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan(c0 + c1, lds_wave, tot);
+      if (2 * tid < HN) t_start[2 * tid] = ex;
+      if (2 * tid + 1 < HN) t_start[2 * tid + 1] = ex + c0;
+      if (tid == 0) lds_wave[63] = tot;
+    }
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RXB_ITEMS; i++) {
-      const uint32_t l = dv[i] & 0xFFFFu;
+    for (int i = 0; i < BS_ITEMS; i++) {
+      const uint32_t l = v[i] & 0x7FFFFFFFu;
       if (l) {
-        const uint32_t m = (l - 1) >> fb, p = t_start[m] + rk[i];
-        stage[p] = make_uint2((((l - 1) & fmask) + 1) | (dv[i] & 0x80000000u), iv[i]);
-        stage_b[p] = (uint8_t)m;
+        const uint32_t h = (l - 1) >> fb;
+        // record: fine bits + 1 (<= 2^12; 0 never occurs) | coarse bin << 16 (stripped on the way out) | sign << 31
+        stage[t_start[h] + rk[i]] = make_uint2((((l - 1) & fmask) + 1) | (h << 16) | (v[i] & 0x80000000u),
+                                               (uint32_t)(t0 + (uint64_t)i * BS_THREADS + tid));
       }
     }
     __syncthreads();
-    const uint32_t n_tile = t_start[NB - 1] + t_cnt[NB - 1];
-    for (uint32_t i = tid; i < n_tile; i += RXB_THREADS) {
-      const uint32_t bk = stage_b[i];
-      const uint32_t pos = g_cur[bk] + (i - t_start[bk]);
+    const uint32_t n_tile = lds_wave[63];
+    for (uint32_t i = tid; i < n_tile; i += BS_THREADS) {
       const uint2 r = stage[i];
-      dig3[pos] = r.x;
-      idx3[pos] = r.y;
+      const uint32_t h = (r.x >> 16) & 0x7FFu;
+      rec[g_base[h] + (i - t_start[h])] = make_uint2(r.x & 0x8000FFFFu, r.y);
     }
     __syncthreads();
-    if (tid < NB) g_cur[tid] += t_cnt[tid];
+    for (uint32_t h = tid; h < HN; h += BS_THREADS) g_base[h] += t_cnt[h];
   }
 }
 #endif
 
-// bucket sizes of fine window v = kk * Lp + f (2^fb buckets from f << fb) from its records; `counts` is zeroed before
-// (a short top window does not reach the upper buckets)
-__global__ void __launch_bounds__(256) k_fine_hist(uint32_t* counts, const uint32_t* v2_start, const uint32_t* dig3, uint32_t Lp,
-                                                   uint32_t L, WinSplit ws)
+// bucket sizes of bin v = kk * hb + h (the 2^fb buckets from h << fb of window kk) from its records; `counts` is zeroed before
+__global__ void __launch_bounds__(256) k_bin_count(uint32_t* counts, const uint32_t* bin_start, const uint2* rec, uint32_t hb, uint32_t L,
+                                                   WinSplit ws)
 #ifndef MSM_SORT_TU
     ;
 #else
 {
-  __shared__ uint32_t hist[256];
+  extern __shared__ uint32_t lds_bc[];
   const uint32_t v = blockIdx.x, tid = threadIdx.x;
-  const uint32_t kk = v / Lp, f = v - kk * Lp, fb = ws.fb[kk], NB = 1u << fb;
-  const uint64_t beg = v2_start[v], end = v2_start[v + 1];
+  const uint32_t kk = v / hb, h = v - kk * hb, fb = ws.fb[kk], NB = 1u << fb;
+  if (h >= (1u << ws.ab[kk])) return;
+  const uint64_t beg = bin_start[v], end = bin_start[v + 1];
   if (beg == end) return;
-  uint32_t* out = counts + (uint64_t)kk * L + ((uint64_t)f << fb);
+  uint32_t* out = counts + (uint64_t)kk * L + ((uint64_t)h << fb);
   if (fb == 0) {   // one bucket
     if (tid == 0) out[0] = (uint32_t)(end - beg);
     return;
   }
-  hist[tid] = 0;
+  for (uint32_t j = tid; j < NB; j += 256) lds_bc[j] = 0;
   __syncthreads();
-  for (uint64_t j = beg + tid; j < end; j += 256) {
-    const uint32_t l = dig3[j] & 0xFFFFu;
-    if (l) atomicAdd(&hist[l - 1], 1u);
+  const uint32_t rank_bits = fb <= 6 ? fb : 0u;
+  for (uint64_t j0 = beg; j0 < end; j0 += 256) {   // whole waves stay in the loop (lds_rank_add ballots)
+    const uint64_t j = j0 + tid;
+    const uint32_t l = j < end ? rec[j].x & 0xFFFFu : 0u;
+    (void)lds_rank_add(lds_bc, l ? l - 1 : 0u, l != 0, rank_bits);
   }
   __syncthreads();
-  if (tid < NB) out[tid] = hist[tid];
+  for (uint32_t j = tid; j < NB; j += 256) out[j] = lds_bc[j];
 }
 #endif
 
-// ---------------------------------------------------------------------------------------------
-// k_chunk_order: round 1 of the tree gathers its operands from the point rows, and scattered 128-byte line reads run 2.3x
-// slower once the 64 lanes of one load instruction spread over more than ~1 GB of the table (tools/ubench_gather2.hip:
-// 30 G lines/s inside 1 GB windows, 20 inside 2 GB, 13 over 16 GB, however the table is allocated).  A bucket's payloads
-// are in point order, so at c = 16 a wave's 64 pairs cover 1/32 of the table -- but 1/4 at c = 19 and all of it at c = 22.
-// This pass restores the locality for big windows without touching the sort: every block of CO_PAIRS consecutive pairs of
-// the bucket-sorted slots (~100 buckets at c = 22) is stably partitioned by the 1 GB chunk of the table its first operand
-// lives in.  Round 1 then walks the pairs in that order -- consecutive lanes read inside one chunk -- and writes each sum
-// to the element index the pair had before (oidx), so round 2 still finds a bucket's elements side by side.  Pairs of
-// pads (both operands missing) go last.
-// ---------------------------------------------------------------------------------------------
+// pass B.  One block per bin v = kk * hb + h (heaviest -- a short top window's -- first: v = V - 1 - blockIdx.x).  `cursor` holds
+// the padded slot offset of every bucket of the group and, at [nb], the total; a bucket of n entries owns roundup(n, G) / 2
+// consecutive pairs of round 1, i.e. consecutive elements of its output.
+constexpr int BP_THREADS = 512, BP_ITEMS = 8, BP_TILE = BP_THREADS * BP_ITEMS;   // 4 096 records per tile
+inline size_t bin_pairs_lds(uint32_t nbmax) { return (size_t)5 * nbmax * 4 + 64 * 4 + (size_t)((BP_TILE + nbmax) / 2 + 1) * 12; }
+inline size_t bin_slots_lds(uint32_t nbmax) { return (size_t)3 * nbmax * 4 + 64 * 4 + (size_t)BP_TILE * 6; }
 
-constexpr int CO_THREADS = 256, CO_PPT = CO_PAIRS / CO_THREADS;   // 16 consecutive pairs per thread
-#ifndef MSM_CO_MAX_KEYS
-#define MSM_CO_MAX_KEYS 65
-#endif
-constexpr int CO_MAX_KEYS = MSM_CO_MAX_KEYS;                      // up to 64 chunks + the pads
+// exclusive scan over the NB per-bucket values val(b): thread t owns the buckets [t * per, (t + 1) * per); calls
+// put(b, prefix) in order; returns the total
+template <class Val, class Put>
+__device__ __forceinline__ uint32_t bp_bucket_scan(uint32_t NB, uint32_t* lds_wave, Val val, Put put) {
+  const uint32_t per = (NB + BP_THREADS - 1) / BP_THREADS, b0 = threadIdx.x * per;
+  uint32_t sum = 0;
+  for (uint32_t j = 0; j < per; j++)
+    if (b0 + j < NB) sum += val(b0 + j);
+  uint32_t tot;
+  uint32_t ex = block_excl_scan(sum, lds_wave, tot);
+  for (uint32_t j = 0; j < per; j++)
+    if (b0 + j < NB) {
+      const uint32_t x = val(b0 + j);
+      put(b0 + j, ex);
+      ex += x;
+    }
+  return tot;
+}
 
-__global__ void __launch_bounds__(CO_THREADS) k_chunk_order(uint2* pairs_out, uint16_t* oidx, const uint2* pairs_in, uint64_t n_pairs,
-                                                            uint32_t row_shift, uint32_t nkeys)
+__global__ void __launch_bounds__(BP_THREADS) k_bin_pairs(uint2* pairs, uint32_t* dest, const uint2* rec, const uint32_t* bin_start,
+                                                          const uint32_t* cursor, uint32_t hb, uint32_t L, uint32_t nbmax, WinSplit ws)
 #ifndef MSM_SORT_TU
     ;
 #else
 {
-  __shared__ uint2 stage[CO_PAIRS];
-  __shared__ uint16_t stage_o[CO_PAIRS];
-  __shared__ uint16_t cnt[CO_MAX_KEYS * CO_THREADS];   // [key][thread]
-  __shared__ uint32_t lds_wave[CO_THREADS / 64];
-  const uint32_t tid = threadIdx.x;
-  const uint64_t base = (uint64_t)blockIdx.x * CO_PAIRS;
-  const uint32_t n_valid = (uint32_t)min<uint64_t>(CO_PAIRS, n_pairs - base);
-  for (uint32_t i = tid; i < nkeys * CO_THREADS; i += CO_THREADS) cnt[i] = 0;
-  uint2 pr[CO_PPT];
-  uint32_t key[CO_PPT];
-#pragma unroll
-  for (int q = 0; q < CO_PPT / 2; q++) {   // 16 pairs = 8 x 16 bytes per thread
-    const uint32_t j = tid * CO_PPT + 2 * q;
-    uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (j + 1 < n_valid) v = *reinterpret_cast<const uint4*>(pairs_in + base + j);
-    else if (j < n_valid) { const uint2 u = pairs_in[base + j]; v.x = u.x; v.y = u.y; }
-    pr[2 * q] = make_uint2(v.x, v.y);
-    pr[2 * q + 1] = make_uint2(v.z, v.w);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < CO_PPT; j++) {
-    // first operand present: its chunk; else the second one's; both missing: the last key
-    const uint32_t pa = pr[j].x != 0xFFFFFFFFu ? pr[j].x : pr[j].y;
-    key[j] = pa != 0xFFFFFFFFu ? min((pa >> 2) >> row_shift, nkeys - 2) : nkeys - 1;
-    cnt[key[j] * CO_THREADS + tid]++;
-  }
-  __syncthreads();
-  // exclusive scan of the flattened [key][thread] counters: thread t owns the nkeys consecutive entries from t * nkeys
-  {
-    uint32_t sum = 0;
-    for (uint32_t i = 0; i < nkeys; i++) sum += cnt[tid * nkeys + i];
-    uint32_t tot;
-    uint32_t ex = block_excl_scan(sum, lds_wave, tot);
-    for (uint32_t i = 0; i < nkeys; i++) {
-      const uint32_t c = cnt[tid * nkeys + i];
-      cnt[tid * nkeys + i] = (uint16_t)ex;
-      ex += c;
+  extern __shared__ uint32_t lds_bp[];
+  const uint32_t st_cap = (BP_TILE + nbmax) / 2 + 1;   // pairs one tile can emit
+  uint2* st_pair = reinterpret_cast<uint2*>(lds_bp);
+  uint32_t* st_dest = lds_bp + 2 * st_cap;
+  uint32_t* t_cnt = st_dest + st_cap;  // entries of the tile per bucket
+  uint32_t* p_start = t_cnt + nbmax;   // first pair of the bucket in the tile's output | "had a pending entry" << 31
+  uint32_t* t_delta = p_start + nbmax; // element index of the pair staged at p = t_delta + p
+  uint32_t* pend = t_delta + nbmax;    // the odd entry a bucket carries into the next tile (SLOT_EMPTY: none)
+  uint32_t* g_next = pend + nbmax;     // next element of the bucket
+  uint32_t* lds_wave = g_next + nbmax; // 64 words
+  const uint32_t v = gridDim.x - 1 - blockIdx.x, tid = threadIdx.x;
+  const uint32_t kk = v / hb, h = v - kk * hb;
+  const uint32_t ab = ws.ab[kk], fb = ws.fb[kk], NB = 1u << fb, HN = 1u << ab;
+  const uint32_t* cur = cursor + (uint64_t)kk * L;
+  if (fb == 0) {
+    // the window is bucket-sorted already (bucket = bin): its hb blocks share its pairs by position, in bucket order
+    const uint32_t* bs = bin_start + (uint64_t)kk * hb;
+    const uint64_t d0 = cur[0] >> 1, d1 = cur[HN] >> 1, len = d1 - d0;
+    const uint64_t beg = d0 + len * h / hb, end = d0 + len * (h + 1) / hb;
+    for (uint64_t dd = beg + tid; dd < end; dd += BP_THREADS) {
+      uint32_t lo = 0, hi = HN;                                    // last bucket starting at or before element dd
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((cur[mid] >> 1) <= dd) lo = mid; else hi = mid;
+      }
+      const uint32_t q = (uint32_t)(dd - (cur[lo] >> 1)), nent = bs[lo + 1] - bs[lo];
+      const uint64_t r0 = (uint64_t)bs[lo] + 2ull * q;
+      uint2 pr = make_uint2(SLOT_EMPTY, SLOT_EMPTY);
+      if (2 * q < nent) { const uint2 r = rec[r0]; pr.x = (r.y << 1) | (r.x >> 31); }
+      if (2 * q + 1 < nent) { const uint2 r = rec[r0 + 1]; pr.y = (r.y << 1) | (r.x >> 31); }
+      pairs[dd] = pr;
+      dest[dd] = (uint32_t)dd;
     }
+    return;
   }
-  __syncthreads();
+  if (h >= HN) return;
+  const uint32_t* curb = cur + ((uint64_t)h << fb);               // this bin's buckets
+  const uint64_t beg = bin_start[v], end = bin_start[v + 1];
+  if (beg == end) return;                                          // no entries, hence no slots and no pairs
+  for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) {
+    pend[bk] = SLOT_EMPTY;
+    g_next[bk] = curb[bk] >> 1;
+  }
+  uint64_t out_pos = curb[0] >> 1;                                 // the bin's pairs are consecutive in the list
+  const uint32_t rank_bits = fb <= 6 ? fb : 0u;
+  for (uint64_t t0 = beg; t0 < end; t0 += BP_TILE) {
+    for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) t_cnt[bk] = 0;
+    __syncthreads();
+    uint2 r[BP_ITEMS];
+    uint32_t rk[BP_ITEMS];
 #pragma unroll
-  for (int j = 0; j < CO_PPT; j++) {
-    const uint32_t p = cnt[key[j] * CO_THREADS + tid]++;
-    stage[p] = pr[j];
-    stage_o[p] = (uint16_t)(tid * CO_PPT + j);
+    for (int i = 0; i < BP_ITEMS; i++) {
+      const uint64_t j = t0 + (uint64_t)i * BP_THREADS + tid;
+      r[i] = j < end ? rec[j] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < BP_ITEMS; i++) {
+      const uint32_t l = r[i].x & 0xFFFFu;
+      rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0, rank_bits);
+    }
+    __syncthreads();
+    // per bucket: m = pending + the tile's entries -> m / 2 pairs now, m & 1 entries pending
+    const uint32_t n_pairs = bp_bucket_scan(
+        NB, lds_wave, [&](uint32_t bk) { return ((pend[bk] != SLOT_EMPTY ? 1u : 0u) + t_cnt[bk]) >> 1; },
+        [&](uint32_t bk, uint32_t ex) {
+          const uint32_t has = pend[bk] != SLOT_EMPTY ? 1u : 0u, m = has + t_cnt[bk], np = m >> 1;
+          p_start[bk] = ex | (has << 31);
+          t_delta[bk] = g_next[bk] - ex;
+          g_next[bk] += np;
+          if (has && np) {                 // the pending entry opens the bucket's first pair of this tile
+            st_pair[ex].x = pend[bk];
+            st_dest[ex] = t_delta[bk] + ex;
+            pend[bk] = SLOT_EMPTY;
+          }
+        });
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BP_ITEMS; i++) {
+      const uint32_t l = r[i].x & 0xFFFFu;
+      if (l) {
+        const uint32_t bk = l - 1, ps = p_start[bk], has = ps >> 31, m = has + t_cnt[bk], sq = rk[i] + has;
+        const uint32_t payload = (r[i].y << 1) | (r[i].x >> 31);
+        if ((m & 1u) && sq == m - 1) pend[bk] = payload;           // the odd one out waits for the next tile
+        else {
+          const uint32_t p = (ps & 0x7FFFFFFFu) + (sq >> 1);
+          if (sq & 1u) st_pair[p].y = payload;
+          else { st_pair[p].x = payload; st_dest[p] = t_delta[bk] + p; }
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < n_pairs; p += BP_THREADS) {
+      pairs[out_pos + p] = st_pair[p];
+      dest[out_pos + p] = st_dest[p];
+    }
+    out_pos += n_pairs;
+    __syncthreads();
   }
-  __syncthreads();
-  for (uint32_t i = tid; i < n_valid; i += CO_THREADS) {
-    pairs_out[base + i] = stage[i];
-    oidx[base + i] = stage_o[i];
+  // what every bucket still owes: its pending entry paired with nothing, then pairs of pads (their sums are identities
+  // that the index-free rounds behind round 1 read)
+  (void)bp_bucket_scan(
+      NB, lds_wave, [&](uint32_t bk) { return (curb[bk + 1] >> 1) - g_next[bk]; },
+      [&](uint32_t bk, uint32_t ex) {
+        const uint32_t rem = (curb[bk + 1] >> 1) - g_next[bk];
+        for (uint32_t j = 0; j < rem; j++) {
+          pairs[out_pos + ex + j] = make_uint2(j == 0 ? pend[bk] : SLOT_EMPTY, SLOT_EMPTY);
+          dest[out_pos + ex + j] = g_next[bk] + j;
+        }
+      });
+}
+#endif
+
+// pass B': payloads (entry << 1 | sign) to their padded slots, bucket order (slots are pre-filled with SLOT_EMPTY)
+__global__ void __launch_bounds__(BP_THREADS) k_bin_slots(uint32_t* slots, const uint2* rec, const uint32_t* bin_start,
+                                                          const uint32_t* cursor, uint32_t hb, uint32_t L, uint32_t nbmax, WinSplit ws)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
+  extern __shared__ uint32_t lds_bp[];
+  uint32_t* t_cnt = lds_bp;
+  uint32_t* t_start = t_cnt + nbmax;
+  uint32_t* g_cur = t_start + nbmax;
+  uint32_t* lds_wave = g_cur + nbmax;
+  uint32_t* stage = lds_wave + 64;
+  uint16_t* stage_b = reinterpret_cast<uint16_t*>(stage + BP_TILE);
+  const uint32_t v = gridDim.x - 1 - blockIdx.x, tid = threadIdx.x;
+  const uint32_t kk = v / hb, h = v - kk * hb;
+  const uint32_t ab = ws.ab[kk], fb = ws.fb[kk], NB = 1u << fb, HN = 1u << ab;
+  const uint32_t* cur = cursor + (uint64_t)kk * L;
+  if (fb == 0) {
+    const uint32_t* bs = bin_start + (uint64_t)kk * hb;
+    const uint64_t wbeg = bs[0], wlen = (uint64_t)bs[HN] - wbeg;
+    const uint64_t beg = wbeg + wlen * h / hb, end = wbeg + wlen * (h + 1) / hb;
+    for (uint64_t j = beg + tid; j < end; j += BP_THREADS) {
+      uint32_t lo = 0, hi = HN;                                    // bucket of record j: last bin starting at or before it
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (bs[mid] <= j) lo = mid; else hi = mid;
+      }
+      const uint2 r = rec[j];
+      slots[cur[lo] + (uint32_t)(j - bs[lo])] = (r.y << 1) | (r.x >> 31);
+    }
+    return;
+  }
+  if (h >= HN) return;
+  const uint64_t beg = bin_start[v], end = bin_start[v + 1];
+  if (beg == end) return;
+  for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) g_cur[bk] = cur[((uint64_t)h << fb) + bk];
+  const uint32_t rank_bits = fb <= 6 ? fb : 0u;
+  for (uint64_t t0 = beg; t0 < end; t0 += BP_TILE) {
+    for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) t_cnt[bk] = 0;
+    __syncthreads();
+    uint2 r[BP_ITEMS];
+    uint32_t rk[BP_ITEMS];
+#pragma unroll
+    for (int i = 0; i < BP_ITEMS; i++) {
+      const uint64_t j = t0 + (uint64_t)i * BP_THREADS + tid;
+      r[i] = j < end ? rec[j] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < BP_ITEMS; i++) {
+      const uint32_t l = r[i].x & 0xFFFFu;
+      rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0, rank_bits);
+    }
+    __syncthreads();
+    const uint32_t n_tile = bp_bucket_scan(NB, lds_wave, [&](uint32_t bk) { return t_cnt[bk]; },
+                                           [&](uint32_t bk, uint32_t ex) { t_start[bk] = ex; });
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BP_ITEMS; i++) {
+      const uint32_t l = r[i].x & 0xFFFFu;
+      if (l) {
+        const uint32_t p = t_start[l - 1] + rk[i];
+        stage[p] = (r[i].y << 1) | (r[i].x >> 31);
+        stage_b[p] = (uint16_t)(l - 1);
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_tile; i += BP_THREADS) {
+      const uint32_t bk = stage_b[i];
+      slots[g_cur[bk] + (i - t_start[bk])] = stage[i];
+    }
+    __syncthreads();
+    for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) g_cur[bk] += t_cnt[bk];
   }
 }
 #endif

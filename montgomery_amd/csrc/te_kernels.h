@@ -223,34 +223,52 @@ __global__ void __launch_bounds__(256) k_te_points_from_wire(uint32_t* rows, con
 // ---------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256) k_te_digits(uint32_t* dig, const uint32_t* scalars, uint32_t n, int c, int k_total, int k_lo,
-                                                   int k_cnt, int strict, uint32_t* err)
+                                                   int k_cnt, int strict, uint32_t* err, uint32_t pps, uint32_t* slice_hist,
+                                                   uint32_t hb, WinSplit ws)
 #ifndef MSM_TE_TU
     ;
 #else
 {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t s[8];
-  {
-    const uint4* p4 = reinterpret_cast<const uint4*>(scalars + (uint64_t)i * 8);
-    uint4 a = p4[0], b = p4[1];
-    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  // slices and the fused histogram of the coarse bins: as k_digits (msm_kernels.h)
+  extern __shared__ uint32_t lds_dig_hist[];
+  uint32_t* lds_hist = slice_hist ? lds_dig_hist : nullptr;
+  if (lds_hist) {
+    for (uint32_t j = threadIdx.x; j < (uint32_t)k_cnt * hb; j += blockDim.x) lds_hist[j] = 0;
+    __syncthreads();
   }
-  uint32_t q[8];
+  const uint64_t p_end = min((uint64_t)(blockIdx.x + 1) * pps, (uint64_t)n);
+  for (uint64_t i64 = (uint64_t)blockIdx.x * pps + threadIdx.x; i64 < p_end; i64 += blockDim.x) {
+    const uint32_t i = (uint32_t)i64;
+    uint32_t s[8];
+    {
+      const uint4* p4 = reinterpret_cast<const uint4*>(scalars + (uint64_t)i * 8);
+      uint4 a = p4[0], b = p4[1];
+      s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    }
+    uint32_t q[8];
 #pragma unroll
-  for (int j = 0; j < 8; j++) q[j] = FRED_Q[j];
-  if (words8_ge(s, q)) {   // scalars >= q are reduced (2^256 < 56 q), or refused under msm_opts.strict
-    if (strict) atomicOr(err, 4u);
-    for (int it = 0; it < 64 && words8_ge(s, q); it++) bn_addsub<8, 8>(s, q, true);
+    for (int j = 0; j < 8; j++) q[j] = FRED_Q[j];
+    if (words8_ge(s, q)) {   // scalars >= q are reduced (2^256 < 56 q), or refused under msm_opts.strict
+      if (strict) atomicOr(err, 4u);
+      for (int it = 0; it < 64 && words8_ge(s, q); it++) bn_addsub<8, 8>(s, q, true);
+    }
+    const uint32_t L = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int k = 0; k < k_total; k++) {
+      uint32_t l = bn_bits<8>(s, k * c, c) + carry;
+      if (l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
+      int kk = k - k_lo;
+      if (kk >= 0 && kk < k_cnt) {
+        dig[(uint64_t)kk * n + i] = l | (carry << 31);
+        digit_note(lds_hist, hb, ws, kk, l);
+      }
+    }
   }
-  const uint32_t L = 1u << (c - 1);
-  uint32_t carry = 0;
-  for (int k = 0; k < k_total; k++) {
-    uint32_t l = bn_bits<8>(s, k * c, c) + carry;
-    if (l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
-    int kk = k - k_lo;
-    if (kk >= 0 && kk < k_cnt) {
-      dig[(uint64_t)kk * n + i] = l | (carry << 31);
+  if (lds_hist) {
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < (uint32_t)k_cnt * hb; j += blockDim.x) {
+      const uint32_t kk = j / hb, h = j - kk * hb;
+      slice_hist[((uint64_t)kk * gridDim.x + blockIdx.x) * hb + h] = lds_hist[j];
     }
   }
 }
