@@ -205,14 +205,21 @@ MSM_DEV bool words8_ge(const uint32_t (&a)[8], const uint32_t* q) {
 // counts, per window, the coarse bins ((l - 1) >> ws.fb[kk]) of the digits it writes -- in the LDS, `hb` counters per window -- and
 // leaves them in slice_hist[(kk * gridDim.x + b) * hb + bin]: the digits are in registers here, a separate histogram pass would
 // read all of them again.
-MSM_DEV void digit_note(uint32_t* lds_hist, uint32_t hb, const WinSplit& ws, int kk, uint32_t l) {
-  if (lds_hist && l) atomicAdd(&lds_hist[(uint32_t)kk * hb + ((l - 1) >> ws.fb[kk])], 1u);
+// fbp: the fine bits of the group's windows, four bits each (WinSplit::fb packed: a register shift instead of a load from the
+// kernel arguments per digit)
+MSM_DEV void digit_note(uint32_t* lds_hist, uint32_t hb, uint64_t fbp, int kk, uint32_t l) {
+  if (lds_hist && l) atomicAdd(&lds_hist[(uint32_t)kk * hb + ((l - 1) >> ((uint32_t)(fbp >> (4 * kk)) & 15u))], 1u);
+}
+inline uint64_t pack_fine_bits(const WinSplit& ws) {
+  uint64_t v = 0;
+  for (int kk = 0; kk < 16; kk++) v |= (uint64_t)(ws.fb[kk] & 15u) << (4 * kk);
+  return v;
 }
 
 template <class CV>
-__global__ void __launch_bounds__(256) k_digits(uint32_t* dig, const uint32_t* scalars, uint32_t n, int c, int k_total,
+__global__ void __launch_bounds__(1024) k_digits(uint32_t* dig, const uint32_t* scalars, uint32_t n, int c, int k_total,
                                                 int k_lo, int k_cnt, int glv_flags, int strict, uint32_t* err, uint32_t pps,
-                                                uint32_t* slice_hist, uint32_t hb, WinSplit ws) {
+                                                uint32_t* slice_hist, uint32_t hb, uint64_t fbp) {
   extern __shared__ uint32_t lds_dig_hist[];
   uint32_t* lds_hist = slice_hist ? lds_dig_hist : nullptr;
   if (lds_hist) {
@@ -252,28 +259,29 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* dig, const uint32_t* s
       if (!top && l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
       int kk = k - k_lo;
       if (kk >= 0 && kk < k_cnt) {
-        dig[(uint64_t)kk * two_n + 2ull * i] = l | (carry << 31);
-        dig[(uint64_t)kk * two_n + 2ull * i + 1] = 0u;
-        digit_note(lds_hist, hb, ws, kk, l);
+        *reinterpret_cast<uint2*>(dig + (uint64_t)kk * two_n + 2ull * i) = make_uint2(l | (carry << 31), 0u);
+        digit_note(lds_hist, hb, fbp, kk, l);
       }
     }
     continue;
   }
   GlvHalf h[2];
   glv_decompose<typename CV::G>(h[0], h[1], s);
-#pragma unroll
-  for (int hh = 0; hh < 2; hh++) {
-    uint32_t carry = 0;
-    for (int k = 0; k < k_total; k++) {
-      const bool top = fold && k == k_total - 1;
-      uint32_t l = bn_bits<4>(h[hh].mag, k * c, top ? c + 1 : c) + carry;
-      if (!top && l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
-      int kk = k - k_lo;
-      if (kk >= 0 && kk < k_cnt) {
-        uint32_t neg = carry ^ (h[hh].neg ? 1u : 0u);
-        dig[(uint64_t)kk * two_n + 2ull * i + hh] = l | (neg << 31);
-        digit_note(lds_hist, hb, ws, kk, l);
-      }
+  // both halves of a window leave as ONE 8-byte store (entries 2 i and 2 i + 1 are neighbours): 4-byte stores a dword apart
+  // ran the kernel at half the streaming rate
+  uint32_t carry0 = 0, carry1 = 0;
+  for (int k = 0; k < k_total; k++) {
+    const bool top = fold && k == k_total - 1;
+    uint32_t l0 = bn_bits<4>(h[0].mag, k * c, top ? c + 1 : c) + carry0;
+    uint32_t l1 = bn_bits<4>(h[1].mag, k * c, top ? c + 1 : c) + carry1;
+    if (!top && l0 > L) { l0 = 2 * L - l0; carry0 = 1; } else { carry0 = 0; }
+    if (!top && l1 > L) { l1 = 2 * L - l1; carry1 = 1; } else { carry1 = 0; }
+    const int kk = k - k_lo;
+    if (kk >= 0 && kk < k_cnt) {
+      const uint32_t neg0 = carry0 ^ (h[0].neg ? 1u : 0u), neg1 = carry1 ^ (h[1].neg ? 1u : 0u);
+      *reinterpret_cast<uint2*>(dig + (uint64_t)kk * two_n + 2ull * i) = make_uint2(l0 | (neg0 << 31), l1 | (neg1 << 31));
+      digit_note(lds_hist, hb, fbp, kk, l0);
+      digit_note(lds_hist, hb, fbp, kk, l1);
     }
   }
   }

@@ -79,7 +79,9 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
       const int eff = std::max(1, top ? std::min(cbits, pl.bits - (k_lo + kk) * pl.c) : std::min(cbits, pl.c - 1));
       // up to 10 bits: pass A sorts the window outright; else 2^10 coarse bins (16-entry runs of a 16 k tile), 2^11 if the
       // fine part would otherwise exceed 2^12 buckets per bin
-      const int abk = eff <= 10 ? eff : std::max(10, eff - (int)BS_MAX_FB);
+      long long ab_big = 10;
+      MSM_KNOB(ab_big, "MSM_BIN_AB", 1);
+      const int abk = eff <= (int)ab_big ? eff : std::max((int)ab_big, eff - (int)BS_MAX_FB);
       if (abk > (int)BS_MAX_AB) throw MsmFail{MSM_ERR_INTERNAL, "window too wide for the bin split"};
       ws.ab[kk] = (uint8_t)abk;
       ws.fb[kk] = (uint8_t)(eff - abk);
@@ -123,17 +125,19 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     const uint32_t per = bin_split ? (uint32_t)pps : 256u;
     uint32_t* hist = bin_split ? (uint32_t*)w.block_hist.p : nullptr;
     const size_t lds = bin_split ? (size_t)kc * hb * 4 : 0;
+    // (a slice per block leaves four blocks per CU: 1024 threads each keep the SIMDs full, 256 left them at four waves)
+    const uint32_t threads = bin_split ? 1024u : 256u;
     if (te)
-      hipLaunchKernelGGL(te::k_te_digits, dim3(grid), dim3(256), lds, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K,
-                         k_lo, kc, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, ws);
+      hipLaunchKernelGGL(te::k_te_digits, dim3(grid), dim3(threads), lds, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K,
+                         k_lo, kc, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, pack_fine_bits(ws));
     else
-      W_LAUNCH(ctx, k_digits, dim3(grid), dim3(256), lds, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K, k_lo, kc,
-                         (pl.no_glv ? 0 : 1) | (pl.fold ? 2 : 0), pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, ws);
+      W_LAUNCH(ctx, k_digits, dim3(grid), dim3(threads), lds, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K, k_lo, kc,
+                         (pl.no_glv ? 0 : 1) | (pl.fold ? 2 : 0), pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, pack_fine_bits(ws));
   }
   HIPCHK(hipEventRecord(w.ev[1], s));
   if (!bin_split) {
     hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.block_hist.p,
-                       (const uint32_t*)w.dig.p, two_n, chunk, L, 0u);
+                       (const uint32_t*)w.dig.p, two_n, chunk, L);
     hipLaunchKernelGGL(k_colscan, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, (uint32_t*)w.block_hist.p,
                        (uint32_t*)w.counts.p, sortB, L, (uint32_t)kc);
   } else {
@@ -229,7 +233,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     } else if (one_level) {
       hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.slots.p,
                          (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n,
-                         chunk, L, 0u);
+                         chunk, L);
     } else {
       hipLaunchKernelGGL(k_bin_slots, dim3(V), dim3(BP_THREADS), bin_slots_lds(nbmax), s, (uint32_t*)w.slots.p,
                          (const uint2*)w.rec.p, (const uint32_t*)d_bin_start, (const uint32_t*)w.cursor.p, hb, L, nbmax, ws);

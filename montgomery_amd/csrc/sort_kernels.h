@@ -196,31 +196,31 @@ constexpr int SORT_THREADS = 1024;
 
 
 
-// Ranking with few bins (<= 256, `bits` = log2 of their number): the 64 lanes of a wave then mostly hit the same LDS
-// counters and per-lane atomics serialise (round 1 measured the 128-bin pass slower than the 32768-bin one for exactly
-// this reason).  Here the lanes of a wave that share a bin find each other with one ballot per bin bit, the lowest of
-// them adds the group's size with ONE atomic, and every lane gets (old counter + its rank inside the group).
-// bits == 0: plain per-lane atomic.  Must be called by all lanes of the wave (valid = has an entry).
-__device__ __forceinline__ uint32_t lds_rank_add(uint32_t* lds, uint32_t bin, bool valid, uint32_t bits) {
-  if (bits == 0) return valid ? atomicAdd(&lds[bin], 1u) : 0u;
-  uint64_t peers = __ballot(valid);
-  for (uint32_t b = 0; b < bits; b++) {
-    const bool bit = (bin >> b) & 1u;
-    const uint64_t m = __ballot(bit);
-    peers &= bit ? m : ~m;
+// Ranking a key into its LDS counter: one returning ds_add per lane.  Measured (tools/ubench_lds_rank.hip,
+// profiles/r05_ubench_lds_rank.txt): 3.7 keys per clock and CU on random keys over 2^8 or 2^10 counters, 1.8 over 8 -- the
+// match-by-ballot form of rounds 1-4 (one ballot per bin bit, one atomic per group of equal lanes) reaches 0.6-0.7 and 1.1, so it
+// lost everywhere on uniform digits.  What it did buy is a bound on skewed inputs, where many lanes of a wave share ONE bin and
+// their atomics serialise: that case is kept as a wave-uniform side branch -- if at least 16 lanes hold the first lane's bin,
+// those lanes are ranked with one ballot and one atomic.  Must be called by all lanes of the wave (valid = has an entry).
+__device__ __forceinline__ uint32_t lds_rank_add(uint32_t* lds, uint32_t bin, bool valid) {
+  const uint32_t first = __builtin_amdgcn_readfirstlane(bin);
+  const uint64_t same = __ballot(valid && bin == first);
+  if (__popcll(same) >= 16) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)same) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&lds[first], (uint32_t)__popcll(same));
+    base = __shfl(base, leader, 64);
+    const uint32_t r = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+    if ((same >> lane) & 1ull) return r;
+    return valid ? atomicAdd(&lds[bin], 1u) : 0u;
   }
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-  uint32_t base = 0;
-  if (valid && rank == 0) base = atomicAdd(&lds[bin], (uint32_t)__popcll(peers));
-  const int leader = valid ? __ffsll((long long)peers) - 1 : 0;
-  base = __shfl(base, leader, 64);
-  return base + rank;
+  return valid ? atomicAdd(&lds[bin], 1u) : 0u;
 }
 
 // Window kk owns digits dig[kk * two_n ..) and block b the slice [b * chunk, (b+1) * chunk); L = number of bins; bin = l - 1.
 __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, const uint32_t* dig, uint64_t two_n,
-                                                       uint64_t chunk, uint32_t L, uint32_t agg_bits)
+                                                       uint64_t chunk, uint32_t L)
 #ifndef MSM_SORT_TU
     ;
 #else
@@ -235,14 +235,14 @@ __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, con
   const uint32_t* d = dig + (uint64_t)kk * two_n;
   // 16-byte loads, two per thread and trip, while the slice allows it (one dword per thread and trip left the kernel
   // waiting on single 256-byte wave loads: 1.2 ms per window group at 2^26, 1.75 TB/s); whole waves stay in both loops
-  // (lds_rank_add ballots)
+  // (lds_rank_add looks at the whole wave)
   uint64_t j0 = beg;
   if (end > beg) {
     // up to three entries in front of the first 16-byte boundary (odd N, odd slice starts)
     const uint64_t head = min<uint64_t>(end - beg, (16u - (uint32_t)(reinterpret_cast<uintptr_t>(d + beg) & 15u)) % 16u / 4u);
-    if (head) {   // uniform: all lanes of the block take part (lds_rank_add ballots)
+    if (head) {   // uniform: all lanes of the block take part (lds_rank_add looks at the whole wave)
       const uint32_t l = threadIdx.x < head ? d[beg + threadIdx.x] & 0x7FFFFFFFu : 0u;
-      (void)lds_rank_add(lds_hist, l ? (l - 1) >> shift : 0u, l != 0, agg_bits);
+      (void)lds_rank_add(lds_hist, l ? (l - 1) >> shift : 0u, l != 0);
       j0 = beg + head;
     }
   }
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, con
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const uint32_t l = w[i] & 0x7FFFFFFFu;
-        (void)lds_rank_add(lds_hist, l ? (l - 1) >> shift : 0u, l != 0, agg_bits);
+        (void)lds_rank_add(lds_hist, l ? (l - 1) >> shift : 0u, l != 0);
       }
     }
     j0 += nvec * 4;
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_hist(uint32_t* block_hist, con
   for (; j0 < end; j0 += SORT_THREADS) {
     const uint64_t j = j0 + threadIdx.x;
     const uint32_t l = j < end ? d[j] & 0x7FFFFFFFu : 0u;
-    (void)lds_rank_add(lds_hist, l ? (l - 1) >> shift : 0u, l != 0, agg_bits);
+    (void)lds_rank_add(lds_hist, l ? (l - 1) >> shift : 0u, l != 0);
   }
   __syncthreads();
   uint32_t* out = block_hist + hist_row * L;
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) k_colscan(uint32_t* block_hist, uint32_t*
 
 __global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(uint32_t* slots, const uint32_t* cursor,
                                                               const uint32_t* block_hist, const uint32_t* dig,
-                                                              uint64_t two_n, uint64_t chunk, uint32_t L, uint32_t agg_bits)
+                                                              uint64_t two_n, uint64_t chunk, uint32_t L)
 #ifndef MSM_SORT_TU
     ;
 #else
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(uint32_t* slots, c
     const uint64_t j = j0 + threadIdx.x;
     const uint32_t v = j < end ? d[j] : 0u;
     const uint32_t l = v & 0x7FFFFFFFu;
-    const uint32_t pos = lds_rank_add(lds_pos, l ? l - 1 : 0u, l != 0, agg_bits);
+    const uint32_t pos = lds_rank_add(lds_pos, l ? l - 1 : 0u, l != 0);
     if (l) slots[pos] = ((uint32_t)j << 1) | (v >> 31);
   }
 }
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(RX_THREADS, RXA_WAVES) k_radix_coarse(uint32_t
 #pragma unroll
     for (int i = 0; i < RXA_ITEMS; i++) {
       const uint32_t l = v[i] & 0x7FFFFFFFu;
-      rk[i] = lds_rank_add(t_cnt, l ? (l - 1) >> low_bits : 0u, l != 0, hbits ? hbits : 1u);   // 0 bits would mean per-lane atomics
+      rk[i] = lds_rank_add(t_cnt, l ? (l - 1) >> low_bits : 0u, l != 0);
       __builtin_amdgcn_sched_barrier(0);   // one ranking at a time: interleaved, the seven of them cost 16 more registers
     }
     __syncthreads();
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, con
 #pragma unroll
     for (int i = 0; i < RXB_ITEMS; i++) {
       const uint32_t l = dv[i] & 0xFFFFu;
-      rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0, fbits);
+      rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0);
     }
     __syncthreads();
     rx_scan_bins(t_start, t_cnt, NB, lds_wave);
@@ -550,11 +550,40 @@ __global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, con
 // pass B then share it by position.
 // ---------------------------------------------------------------------------------------------
 
-constexpr int BS_THREADS = 1024;
+// exclusive scan over NB per-bin values val(b) by a block of THREADS: thread t owns the bins [t * per, (t + 1) * per); calls
+// put(b, prefix) in order; returns the total
+template <int THREADS, class Val, class Put>
+__device__ __forceinline__ uint32_t bucket_scan(uint32_t NB, uint32_t* lds_wave, Val val, Put put) {
+  const uint32_t per = (NB + THREADS - 1) / THREADS, b0 = threadIdx.x * per;
+  uint32_t sum = 0;
+  for (uint32_t j = 0; j < per; j++)
+    if (b0 + j < NB) sum += val(b0 + j);
+  uint32_t tot;
+  uint32_t ex = block_excl_scan(sum, lds_wave, tot);
+  for (uint32_t j = 0; j < per; j++)
+    if (b0 + j < NB) {
+      const uint32_t x = val(b0 + j);
+      put(b0 + j, ex);
+      ex += x;
+    }
+  return tot;
+}
+
+// pass A geometry, measured at 2^26 (tools/ab_kernels.sh, profiles/r05_experiments.txt item 2): 1024 threads x 16 records = tiles of
+// 16 384 records (128 KB staged, one workgroup per CU) 2.08 ms per window group; x 12 with the next tile's digits requested before
+// the staging 2.14; 512 threads x 16 or x 24 with two workgroups per CU 2.4 / 2.13.  The pass is bound by its writes: runs of ~16
+// records of 8 bytes start anywhere in a 128-byte line, so every run boundary writes one 64-byte unit twice (WRITE_SIZE 4.4 GB for
+// 3.2 GB of records).  Fewer, longer runs (2^9 bins: 1.7 ms) cost the second pass more than they save here (2.2 against 1.3 ms).
+#ifndef MSM_BS_THREADS
+#define MSM_BS_THREADS 1024
+#endif
 #ifndef MSM_BS_ITEMS
 #define MSM_BS_ITEMS 16
 #endif
-constexpr int BS_ITEMS = MSM_BS_ITEMS, BS_TILE = BS_THREADS * BS_ITEMS;   // pass A: 16 384 records of 8 bytes staged per tile (128 KB)
+#ifndef MSM_BS_PREFETCH
+#define MSM_BS_PREFETCH 0
+#endif
+constexpr int BS_THREADS = MSM_BS_THREADS, BS_ITEMS = MSM_BS_ITEMS, BS_TILE = BS_THREADS * BS_ITEMS;
 constexpr uint32_t BS_MAX_AB = 11, BS_MAX_FB = 12;
 inline size_t bin_split_lds(uint32_t hb) { return (size_t)BS_TILE * 8 + (size_t)3 * hb * 4 + 64 * 4; }
 
@@ -574,37 +603,37 @@ __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint
   uint32_t* lds_wave = g_base + hb;                       // 64 words
   const uint32_t b = blockIdx.x, kk = blockIdx.y, SB = gridDim.x, tid = threadIdx.x;
   const uint32_t ab = ws.ab[kk], fb = ws.fb[kk], HN = 1u << ab;
-  const uint32_t rank_bits = ab <= 8 ? (ab ? ab : 1u) : 0u;   // few bins: lanes that share one find each other by ballot
   for (uint32_t h = tid; h < HN; h += BS_THREADS)
     g_base[h] = bin_start[(uint64_t)kk * hb + h] + slice_off[((uint64_t)kk * SB + b) * hb + h];
   const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
   const uint32_t* d = dig + (uint64_t)kk * two_n;
   const uint32_t fmask = (1u << fb) - 1;
-  for (uint64_t t0 = beg; t0 < end; t0 += BS_TILE) {
-    for (uint32_t h = tid; h < HN; h += BS_THREADS) t_cnt[h] = 0;
-    __syncthreads();
-    uint32_t v[BS_ITEMS], rk[BS_ITEMS];
-    const uint32_t left = (uint32_t)min<uint64_t>(end - t0, BS_TILE);
+  uint32_t v[BS_ITEMS], nv[BS_ITEMS];
+  auto load_tile = [&](uint32_t (&dst)[BS_ITEMS], uint64_t t0) {
+    const uint32_t left = t0 < end ? (uint32_t)min<uint64_t>(end - t0, BS_TILE) : 0u;
     const uint32_t* dt = d + t0;
 #pragma unroll
     for (int i = 0; i < BS_ITEMS; i++) {
       const uint32_t j = (uint32_t)i * BS_THREADS + tid;
-      v[i] = j < left ? dt[j] : 0u;
+      dst[i] = j < left ? dt[j] : 0u;
     }
+  };
+  load_tile(v, beg);
+  for (uint64_t t0 = beg; t0 < end; t0 += BS_TILE) {
+    for (uint32_t h = tid; h < HN; h += BS_THREADS) t_cnt[h] = 0;
+    __syncthreads();
+    uint32_t rk[BS_ITEMS];
 #pragma unroll
     for (int i = 0; i < BS_ITEMS; i++) {
       const uint32_t l = v[i] & 0x7FFFFFFFu;
-      rk[i] = lds_rank_add(t_cnt, l ? (l - 1) >> fb : 0u, l != 0, rank_bits);
+      rk[i] = lds_rank_add(t_cnt, l ? (l - 1) >> fb : 0u, l != 0);
     }
+#if MSM_BS_PREFETCH
+    load_tile(nv, t0 + BS_TILE);   // in flight during the scan, the staging and the copy-out
+#endif
     __syncthreads();
-    {   // exclusive scan of the HN <= 2048 tile counters: two per thread
-      const uint32_t c0 = 2 * tid < HN ? t_cnt[2 * tid] : 0u, c1 = 2 * tid + 1 < HN ? t_cnt[2 * tid + 1] : 0u;
-      uint32_t tot;
-      const uint32_t ex = block_excl_scan(c0 + c1, lds_wave, tot);
-      if (2 * tid < HN) t_start[2 * tid] = ex;
-      if (2 * tid + 1 < HN) t_start[2 * tid + 1] = ex + c0;
-      if (tid == 0) lds_wave[63] = tot;
-    }
+    const uint32_t n_tile = bucket_scan<BS_THREADS>(HN, lds_wave, [&](uint32_t h) { return t_cnt[h]; },
+                                                    [&](uint32_t h, uint32_t ex) { t_start[h] = ex; });
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < BS_ITEMS; i++) {
@@ -617,7 +646,6 @@ __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint
       }
     }
     __syncthreads();
-    const uint32_t n_tile = lds_wave[63];
     for (uint32_t i = tid; i < n_tile; i += BS_THREADS) {
       const uint2 r = stage[i];
       const uint32_t h = (r.x >> 16) & 0x7FFu;
@@ -625,6 +653,12 @@ __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint
     }
     __syncthreads();
     for (uint32_t h = tid; h < HN; h += BS_THREADS) g_base[h] += t_cnt[h];
+#if MSM_BS_PREFETCH
+#pragma unroll
+    for (int i = 0; i < BS_ITEMS; i++) v[i] = nv[i];
+#else
+    load_tile(v, t0 + BS_TILE);
+#endif
   }
 }
 #endif
@@ -649,11 +683,10 @@ __global__ void __launch_bounds__(256) k_bin_count(uint32_t* counts, const uint3
   }
   for (uint32_t j = tid; j < NB; j += 256) lds_bc[j] = 0;
   __syncthreads();
-  const uint32_t rank_bits = fb <= 6 ? fb : 0u;
-  for (uint64_t j0 = beg; j0 < end; j0 += 256) {   // whole waves stay in the loop (lds_rank_add ballots)
+  for (uint64_t j0 = beg; j0 < end; j0 += 256) {   // whole waves stay in the loop (lds_rank_add looks at the whole wave)
     const uint64_t j = j0 + tid;
     const uint32_t l = j < end ? rec[j].x & 0xFFFFu : 0u;
-    (void)lds_rank_add(lds_bc, l ? l - 1 : 0u, l != 0, rank_bits);
+    (void)lds_rank_add(lds_bc, l ? l - 1 : 0u, l != 0);
   }
   __syncthreads();
   for (uint32_t j = tid; j < NB; j += 256) out[j] = lds_bc[j];
@@ -663,28 +696,15 @@ __global__ void __launch_bounds__(256) k_bin_count(uint32_t* counts, const uint3
 // pass B.  One block per bin v = kk * hb + h (heaviest -- a short top window's -- first: v = V - 1 - blockIdx.x).  `cursor` holds
 // the padded slot offset of every bucket of the group and, at [nb], the total; a bucket of n entries owns roundup(n, G) / 2
 // consecutive pairs of round 1, i.e. consecutive elements of its output.
-constexpr int BP_THREADS = 512, BP_ITEMS = 8, BP_TILE = BP_THREADS * BP_ITEMS;   // 4 096 records per tile
+#ifndef MSM_BP_PREFETCH
+#define MSM_BP_PREFETCH 1
+#endif
+#ifndef MSM_BP_ITEMS
+#define MSM_BP_ITEMS 8
+#endif
+constexpr int BP_THREADS = 512, BP_ITEMS = MSM_BP_ITEMS, BP_TILE = BP_THREADS * BP_ITEMS;   // 4 096 records per tile
 inline size_t bin_pairs_lds(uint32_t nbmax) { return (size_t)5 * nbmax * 4 + 64 * 4 + (size_t)((BP_TILE + nbmax) / 2 + 1) * 12; }
 inline size_t bin_slots_lds(uint32_t nbmax) { return (size_t)3 * nbmax * 4 + 64 * 4 + (size_t)BP_TILE * 6; }
-
-// exclusive scan over the NB per-bucket values val(b): thread t owns the buckets [t * per, (t + 1) * per); calls
-// put(b, prefix) in order; returns the total
-template <class Val, class Put>
-__device__ __forceinline__ uint32_t bp_bucket_scan(uint32_t NB, uint32_t* lds_wave, Val val, Put put) {
-  const uint32_t per = (NB + BP_THREADS - 1) / BP_THREADS, b0 = threadIdx.x * per;
-  uint32_t sum = 0;
-  for (uint32_t j = 0; j < per; j++)
-    if (b0 + j < NB) sum += val(b0 + j);
-  uint32_t tot;
-  uint32_t ex = block_excl_scan(sum, lds_wave, tot);
-  for (uint32_t j = 0; j < per; j++)
-    if (b0 + j < NB) {
-      const uint32_t x = val(b0 + j);
-      put(b0 + j, ex);
-      ex += x;
-    }
-  return tot;
-}
 
 __global__ void __launch_bounds__(BP_THREADS) k_bin_pairs(uint2* pairs, uint32_t* dest, const uint2* rec, const uint32_t* bin_start,
                                                           const uint32_t* cursor, uint32_t hb, uint32_t L, uint32_t nbmax, WinSplit ws)
@@ -736,25 +756,30 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_pairs(uint2* pairs, uint32_t
     g_next[bk] = curb[bk] >> 1;
   }
   uint64_t out_pos = curb[0] >> 1;                                 // the bin's pairs are consecutive in the list
-  const uint32_t rank_bits = fb <= 6 ? fb : 0u;
-  for (uint64_t t0 = beg; t0 < end; t0 += BP_TILE) {
-    for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) t_cnt[bk] = 0;
-    __syncthreads();
-    uint2 r[BP_ITEMS];
-    uint32_t rk[BP_ITEMS];
+  uint2 r[BP_ITEMS], nr[BP_ITEMS];
+  auto load_tile = [&](uint2 (&dst)[BP_ITEMS], uint64_t t0) {
 #pragma unroll
     for (int i = 0; i < BP_ITEMS; i++) {
       const uint64_t j = t0 + (uint64_t)i * BP_THREADS + tid;
-      r[i] = j < end ? rec[j] : make_uint2(0u, 0u);
+      dst[i] = j < end ? rec[j] : make_uint2(0u, 0u);
     }
+  };
+  load_tile(r, beg);
+  for (uint64_t t0 = beg; t0 < end; t0 += BP_TILE) {
+    for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) t_cnt[bk] = 0;
+    __syncthreads();
+    uint32_t rk[BP_ITEMS];
 #pragma unroll
     for (int i = 0; i < BP_ITEMS; i++) {
       const uint32_t l = r[i].x & 0xFFFFu;
-      rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0, rank_bits);
+      rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0);
     }
+#if MSM_BP_PREFETCH
+    load_tile(nr, t0 + BP_TILE);   // the next tile's records are in flight while this one is paired and copied out
+#endif
     __syncthreads();
     // per bucket: m = pending + the tile's entries -> m / 2 pairs now, m & 1 entries pending
-    const uint32_t n_pairs = bp_bucket_scan(
+    const uint32_t n_pairs = bucket_scan<BP_THREADS>(
         NB, lds_wave, [&](uint32_t bk) { return ((pend[bk] != SLOT_EMPTY ? 1u : 0u) + t_cnt[bk]) >> 1; },
         [&](uint32_t bk, uint32_t ex) {
           const uint32_t has = pend[bk] != SLOT_EMPTY ? 1u : 0u, m = has + t_cnt[bk], np = m >> 1;
@@ -789,10 +814,16 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_pairs(uint2* pairs, uint32_t
     }
     out_pos += n_pairs;
     __syncthreads();
+#if MSM_BP_PREFETCH
+#pragma unroll
+    for (int i = 0; i < BP_ITEMS; i++) r[i] = nr[i];
+#else
+    load_tile(r, t0 + BP_TILE);
+#endif
   }
   // what every bucket still owes: its pending entry paired with nothing, then pairs of pads (their sums are identities
   // that the index-free rounds behind round 1 read)
-  (void)bp_bucket_scan(
+  (void)bucket_scan<BP_THREADS>(
       NB, lds_wave, [&](uint32_t bk) { return (curb[bk + 1] >> 1) - g_next[bk]; },
       [&](uint32_t bk, uint32_t ex) {
         const uint32_t rem = (curb[bk + 1] >> 1) - g_next[bk];
@@ -841,7 +872,6 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_slots(uint32_t* slots, const
   const uint64_t beg = bin_start[v], end = bin_start[v + 1];
   if (beg == end) return;
   for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) g_cur[bk] = cur[((uint64_t)h << fb) + bk];
-  const uint32_t rank_bits = fb <= 6 ? fb : 0u;
   for (uint64_t t0 = beg; t0 < end; t0 += BP_TILE) {
     for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) t_cnt[bk] = 0;
     __syncthreads();
@@ -855,10 +885,10 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_slots(uint32_t* slots, const
 #pragma unroll
     for (int i = 0; i < BP_ITEMS; i++) {
       const uint32_t l = r[i].x & 0xFFFFu;
-      rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0, rank_bits);
+      rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0);
     }
     __syncthreads();
-    const uint32_t n_tile = bp_bucket_scan(NB, lds_wave, [&](uint32_t bk) { return t_cnt[bk]; },
+    const uint32_t n_tile = bucket_scan<BP_THREADS>(NB, lds_wave, [&](uint32_t bk) { return t_cnt[bk]; },
                                            [&](uint32_t bk, uint32_t ex) { t_start[bk] = ex; });
     __syncthreads();
 #pragma unroll

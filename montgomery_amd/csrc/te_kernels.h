@@ -222,9 +222,9 @@ __global__ void __launch_bounds__(256) k_te_points_from_wire(uint32_t* rows, con
 // k_te_digits: signed window digits of full-width scalars (no GLV), src/msm-basic.ts:72-91
 // ---------------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) k_te_digits(uint32_t* dig, const uint32_t* scalars, uint32_t n, int c, int k_total, int k_lo,
+__global__ void __launch_bounds__(1024) k_te_digits(uint32_t* dig, const uint32_t* scalars, uint32_t n, int c, int k_total, int k_lo,
                                                    int k_cnt, int strict, uint32_t* err, uint32_t pps, uint32_t* slice_hist,
-                                                   uint32_t hb, WinSplit ws)
+                                                   uint32_t hb, uint64_t fbp)
 #ifndef MSM_TE_TU
     ;
 #else
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256) k_te_digits(uint32_t* dig, const uint32_t
       int kk = k - k_lo;
       if (kk >= 0 && kk < k_cnt) {
         dig[(uint64_t)kk * n + i] = l | (carry << 31);
-        digit_note(lds_hist, hb, ws, kk, l);
+        digit_note(lds_hist, hb, fbp, kk, l);
       }
     }
   }
