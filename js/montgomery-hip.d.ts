@@ -35,12 +35,37 @@ export interface Parallel {
 
 /** opaque stand-in for a wasm pointer of the reference (`Field.getPointer(size)`) */
 export type ValuePtr = { size: number; value: AffineResult | null };
+/** The fine operator table of the reference's wasm exports (src/field-msm.ts:86-123, 190-243) over Buffers of n field elements
+ * (sizeInBytes each, little-endian, Montgomery form) instead of pointers into wasm memory: one kernel launch per call. */
+export interface FieldOps {
+  getPointer(size: number): ValuePtr;
+  getPointers(n: number, size: number): ValuePtr[];
+  sizeInBytes: number;
+  multiply(a: Buffer, b: Buffer): Buffer;
+  square(a: Buffer): Buffer;
+  add(a: Buffer, b: Buffer): Buffer;
+  subtract(a: Buffer, b: Buffer): Buffer;
+  inverse(a: Buffer): Buffer;
+  /** src/wasm/inverse.ts:220-271: Montgomery's trick, perLane elements per inversion */
+  batchInverse(xs: Buffer, perLane?: number): Buffer;
+  toMontgomery(a: Buffer): Buffer;
+  fromMontgomery(a: Buffer): Buffer;
+  fromBigints(vals: bigint[]): Buffer;
+  toBigints(buf: Buffer): bigint[];
+}
 export interface Curve {
   params: CurveParams;
   Parallel: Parallel;
   /** the reference's way from `result` to bigints (scripts/msm-weierstrass.ts:89-91); values are already affine here */
-  Field: { getPointer(size: number): ValuePtr; getPointers(n: number, size: number): ValuePtr[] };
-  Affine: { size: number; toBigint(ptr: ValuePtr | AffineResult): AffineResult };
+  Field: FieldOps;
+  /** src/scalar-glv.ts:105-128: s = (-1)^neg0 s0 + (-1)^neg1 s1 lambda mod q (Weierstrass curves with an endomorphism) */
+  Scalar: { decompose(scalars: bigint[] | Buffer): { s0: bigint; s1: bigint; neg0: boolean; neg1: boolean }[] };
+  Affine: {
+    size: number;
+    toBigint(ptr: ValuePtr | AffineResult): AffineResult;
+    /** batchAddNew, src/curve-affine.ts:376-522: n pairs (null = identity) -> n sums through one launch of the tree kernel */
+    batchAdd(G: ({ x: bigint; y: bigint } | null)[], H: ({ x: bigint; y: bigint } | null)[]): ({ x: bigint; y: bigint } | null)[];
+  };
   Projective: { size: number; toAffine(scratch: unknown, affinePtr: ValuePtr, result: AffineResult): void };
   /** twisted Edwards call sites (scripts/msm-twisted-edwards.ts:87, scripts/zprize23/submission.ts:33-34) */
   Curve: { toBigint(result: AffineResult | ValuePtr): { X: bigint; Y: bigint; Z: bigint; T: bigint } };

@@ -132,9 +132,48 @@ function createCurve(params, curveId, coordBytes, device, wireBytes) {
   // There `result` points at a projective point in wasm memory; here the library has already normalised it, so the three
   // calls only hand the value through: pointers are small objects, toAffine stores, toBigint returns {x, y, isZero}.
   const newPtr = (size) => ({ size, value: null });
-  const Field = { getPointer: newPtr, getPointers(n, size) { return Array.from({ length: n }, () => newPtr(size)); } };
+  // The fine operator table (the reference's wasm exports, src/field-msm.ts:86-123,190-243): element-wise over Buffers of
+  // n field elements (coordBytes each, little-endian, MONTGOMERY form like the reference's field elements in wasm memory)
+  // instead of pointers into wasm memory; every call is one kernel launch over all n elements.  fromBigints / toBigints are
+  // fromPackedBytes + toMontgomery and their inverse (src/field-msm.ts:108-115).
+  const fieldOp = (op) => (a, b) => hip.fieldOp(ctx, op, a, b);
+  const Field = {
+    getPointer: newPtr, getPointers(n, size) { return Array.from({ length: n }, () => newPtr(size)); },
+    sizeInBytes: coordBytes,
+    multiply: fieldOp(hip.OP_MUL), square: fieldOp(hip.OP_SQR), add: fieldOp(hip.OP_ADD), subtract: fieldOp(hip.OP_SUB),
+    inverse: fieldOp(hip.OP_INV), toMontgomery: fieldOp(hip.OP_TO_MONT), fromMontgomery: fieldOp(hip.OP_FROM_MONT),
+    batchInverse(xs, perLane) { return hip.batchInverse(ctx, xs, perLane || 64); },   // src/wasm/inverse.ts:220-271
+    fromBigints(vals) { return hip.fieldOp(ctx, hip.OP_TO_MONT, Buffer.concat(vals.map((v) => bigintToLeBytes(BigInt(v), coordBytes)))); },
+    toBigints(buf) {
+      const plain = hip.fieldOp(ctx, hip.OP_FROM_MONT, buf), out = [];
+      for (let i = 0; i < plain.length; i += coordBytes) out.push(leBytesToBigint(plain.slice(i, i + coordBytes)));
+      return out;
+    },
+  };
+  // Scalar.decompose (src/scalar-glv.ts:105-128, src/wasm/glv.ts:68-169): s = (-1)^neg0 s0 + (-1)^neg1 s1 lambda mod q
+  const Scalar = {
+    decompose(scalars) {
+      const sb = Buffer.isBuffer(scalars) ? scalars : Buffer.concat(scalars.map((v) => bigintToLeBytes(BigInt(v), 32)));
+      const raw = hip.glvDecompose(ctx, sb), out = [];
+      for (let i = 0; i < raw.length; i += 40)
+        out.push({ s0: leBytesToBigint(raw.slice(i, i + 16)), s1: leBytesToBigint(raw.slice(i + 16, i + 32)),
+                   neg0: raw.readUInt32LE(i + 32) !== 0, neg1: raw.readUInt32LE(i + 36) !== 0 });
+      return out;
+    },
+  };
   const toBigint = (ptr) => { const r = (ptr && ptr.value) || ptr; return { x: r.x, y: r.y, isZero: !!r.isZero }; };
-  const Affine = { size: 2 * wireBytes + 4, toBigint };                                   // src/curve-affine.ts:77, 220-233
+  // Affine.batchAdd (batchAddNew, src/curve-affine.ts:376-522): n pairs of affine points {x, y} | null (identity) -> n sums,
+  // all through one launch of the tree kernel with its shared inversions; every kind of pair (P + P, P - P, identities) is handled
+  const encPoint = (P) => (P ? Buffer.concat([bigintToLeBytes(BigInt(P.x), coordBytes), bigintToLeBytes(BigInt(P.y), coordBytes)]) : Buffer.alloc(pointBytes));
+  const batchAdd = (G, H) => {
+    const out = hip.batchAdd(ctx, Buffer.concat(G.map(encPoint)), Buffer.concat(H.map(encPoint))), sums = [];
+    for (let i = 0; i < out.length; i += pointBytes) {
+      const x = leBytesToBigint(out.slice(i, i + coordBytes)), y = leBytesToBigint(out.slice(i + coordBytes, i + pointBytes));
+      sums.push(x === BigInt(0) && y === BigInt(0) ? null : { x, y });
+    }
+    return sums;
+  };
+  const Affine = { size: 2 * wireBytes + 4, toBigint, batchAdd };                         // src/curve-affine.ts:77, 220-233, 376-522
   const Projective = { size: 3 * wireBytes + 4, toAffine(_scratch, affinePtr, result) { affinePtr.value = toBigint(result); } };   // src/curve-projective.ts:335-349
   // twisted Edwards callers: `Curve.Curve.toBigint(result)` -> extended bigint point, `Curve.Bigint.toAffine(P)` -> {x, y}
   // (scripts/msm-twisted-edwards.ts:87, scripts/zprize23/submission.ts:33-34)
@@ -144,7 +183,7 @@ function createCurve(params, curveId, coordBytes, device, wireBytes) {
     return ((s0 % P_MOD) + P_MOD) % P_MOD; };
   const Curve = { toBigint(result) { const r = toBigint(result); return { X: r.x, Y: r.y, Z: BigInt(1), T: (r.x * r.y) % P_MOD }; } };
   const Bigint = { toAffine(P) { const zi = modInv(P.Z); return { x: (P.X * zi) % P_MOD, y: (P.Y * zi) % P_MOD }; } };
-  return { params, Parallel, Field, Affine, Projective, Curve, Bigint, close() { hip.destroyContext(ctx); } };
+  return { params, Parallel, Field, Scalar, Affine, Projective, Curve, Bigint, close() { hip.destroyContext(ctx); } };
 }
 
 const weierstrassIds = { "bls12-377": hip.CURVE_BLS12_377_G1, "bls12-381": hip.CURVE_BLS12_381_G1, "pallas": hip.CURVE_PALLAS };

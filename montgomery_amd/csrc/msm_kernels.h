@@ -257,6 +257,7 @@ __global__ void __launch_bounds__(1024) k_digits(uint32_t* dig, const uint32_t* 
       const bool top = fold && k == k_total - 1;
       uint32_t l = bn_bits<8>(s, k * c, top ? c + 1 : c) + carry;
       if (!top && l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
+      if (top && l > 2 * L) { atomicOr(err, 8u); l = 2 * L; }   // (see below: a folded top window must stay within its buckets)
       int kk = k - k_lo;
       if (kk >= 0 && kk < k_cnt) {
         *reinterpret_cast<uint2*>(dig + (uint64_t)kk * two_n + 2ull * i) = make_uint2(l | (carry << 31), 0u);
@@ -276,6 +277,10 @@ __global__ void __launch_bounds__(1024) k_digits(uint32_t* dig, const uint32_t* 
     uint32_t l1 = bn_bits<4>(h[1].mag, k * c, top ? c + 1 : c) + carry1;
     if (!top && l0 > L) { l0 = 2 * L - l0; carry0 = 1; } else { carry0 = 0; }
     if (!top && l1 > L) { l1 = 2 * L - l1; carry1 = 1; } else { carry1 = 0; }
+    // the folded top window is not recoded: its value stays within its 2^c buckets only while the GLV halves stay below
+    // 2^glv_max_bits -- a half that ever exceeded the bound would index past the window's buckets, so it is flagged (the call
+    // fails with MSM_ERR_INTERNAL) and clamped instead
+    if (top && (l0 > 2 * L || l1 > 2 * L)) { atomicOr(err, 8u); l0 = min(l0, 2 * L); l1 = min(l1, 2 * L); }
     const int kk = k - k_lo;
     if (kk >= 0 && kk < k_cnt) {
       const uint32_t neg0 = carry0 ^ (h[0].neg ? 1u : 0u), neg1 = carry1 ^ (h[1].neg ? 1u : 0u);

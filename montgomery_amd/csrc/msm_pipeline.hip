@@ -254,6 +254,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     HIPCHK(hipMemcpyAsync(ctx->h_info, ctx->errflag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (pl.strict && (ctx->h_info[0] & 4u)) throw MsmFail{MSM_ERR_SCALAR, "a scalar is >= the group order q (msm_opts.strict)"};
+    if (ctx->h_info[0] & 8u) throw MsmFail{MSM_ERR_INTERNAL, "a digit of the folded top window exceeds its bucket range (GLV bound violated)"};
   }
   float upload_ms = -1;
   if (pipe) upload_ms = pipe->finish();   // joins the staging threads; their last copy is done

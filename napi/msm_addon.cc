@@ -13,6 +13,11 @@
 //          msmDevice(h, dbuf, n, c, noGlv, unsafe) -> as msm: the scalars already sit in HBM (the reference keeps them in the
 //          memory its kernels compute in, src/parallel.ts:119-133, scripts/msm-weierstrass.ts:29-32),
 //          plan(h, n, c) -> {c, K}, generatePoints(h, n, seed) -> n, generateScalars(h, n, seed[, dbuf]) -> Buffer | n
+//          the fine operator table of the reference's wasm exports (src/field-msm.ts:86-123,190-243, src/scalar-glv.ts:41-51,105-128)
+//          over Buffers instead of wasm pointers: fieldOp(h, op, a, b) -> Buffer (msm_test_fp: multiply / square / add / subtract /
+//          inverse / toMontgomery / fromMontgomery on n = a.length / coordBytes elements), batchInverse(h, xs, perLane) -> Buffer,
+//          glvDecompose(h, scalars) -> Buffer of n x 40 bytes (|s0|, |s1|: 16 bytes each, neg0, neg1: 4 bytes each),
+//          batchAdd(h, G, H) -> Buffer of n affine sums (wire points, (0, 0) = identity)
 // The addon is built against include/msm_hip.h and checks at load that the library it found was too (msm_abi_version).
 #include <node_api.h>
 #include <stdio.h>
@@ -441,6 +446,126 @@ static napi_value PointsetOp(napi_env env, napi_callback_info info, int destroy)
 static napi_value PointsetSelect(napi_env env, napi_callback_info info) { return PointsetOp(env, info, 0); }
 static napi_value PointsetDestroy(napi_env env, napi_callback_info info) { return PointsetOp(env, info, 1); }
 
+/* ---- the fine operator table: element-wise field / GLV / curve operators over Buffers -------------------------------- */
+
+static int buffer_arg(napi_env env, napi_value v, uint8_t** data, size_t* len) {
+  bool is_buf = false;
+  if (napi_is_buffer(env, v, &is_buf) != napi_ok || !is_buf) {
+    napi_throw_type_error(env, NULL, "expected a Buffer");
+    return 0;
+  }
+  void* p = NULL;
+  if (napi_get_buffer_info(env, v, &p, len) != napi_ok) return 0;
+  *data = (uint8_t*)p;
+  return 1;
+}
+
+static napi_value FieldOp(napi_env env, napi_callback_info info) {  // Field.multiply / square / add / subtract / inverse ..., src/field-msm.ts:86-123
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  js_ctx* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  int32_t op = 0;
+  NAPI_OK(napi_get_value_int32(env, argv[1], &op));
+  uint8_t *a = NULL, *b = NULL;
+  size_t la = 0, lb = 0;
+  if (!buffer_arg(env, argv[2], &a, &la)) return NULL;
+  if (argc > 3) {
+    napi_valuetype t;
+    NAPI_OK(napi_typeof(env, argv[3], &t));
+    if (t != napi_undefined && t != napi_null && !buffer_arg(env, argv[3], &b, &lb)) return NULL;
+  }
+  if (!b) { b = a; lb = la; }   /* one-operand operators read the second array too: hand them the first */
+  if (la % h->coord_bytes || la != lb) {
+    napi_throw_error(env, NULL, "fieldOp: operands must be equally long arrays of whole field elements");
+    return NULL;
+  }
+  if (op < MSM_OP_MUL || op > MSM_OP_INV_WORDSLICED) {
+    napi_throw_error(env, NULL, "fieldOp: unknown operator");
+    return NULL;
+  }
+  const uint64_t n = la / h->coord_bytes;
+  napi_value out;
+  void* po = NULL;
+  NAPI_OK(napi_create_buffer(env, la, &po, &out));
+  if (n) {
+    int rc = msm_test_fp(h->ctx, op, a, b, (uint8_t*)po, n);
+    if (rc != MSM_OK) return throw_msm(env, h->ctx, rc, "fieldOp");
+  }
+  return out;
+}
+
+static napi_value BatchInverse(napi_env env, napi_callback_info info) {  // batchInverse, src/wasm/inverse.ts:220-271
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  js_ctx* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  uint8_t* xs = NULL;
+  size_t len = 0;
+  if (!buffer_arg(env, argv[1], &xs, &len)) return NULL;
+  uint32_t per_lane = 0;
+  NAPI_OK(napi_get_value_uint32(env, argv[2], &per_lane));
+  if (len % h->coord_bytes || per_lane == 0) {
+    napi_throw_error(env, NULL, "batchInverse: an array of whole field elements and a batch length >= 1");
+    return NULL;
+  }
+  napi_value out;
+  void* po = NULL;
+  NAPI_OK(napi_create_buffer(env, len, &po, &out));
+  if (len) {
+    int rc = msm_test_batch_inverse(h->ctx, xs, (uint8_t*)po, len / h->coord_bytes, per_lane);
+    if (rc != MSM_OK) return throw_msm(env, h->ctx, rc, "batchInverse");
+  }
+  return out;
+}
+
+static napi_value GlvDecompose(napi_env env, napi_callback_info info) {  // Scalar.decompose, src/scalar-glv.ts:105-128
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  js_ctx* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  uint8_t* sc = NULL;
+  size_t len = 0;
+  if (!buffer_arg(env, argv[1], &sc, &len)) return NULL;
+  if (len % 32) {
+    napi_throw_error(env, NULL, "glvDecompose: scalars are 32 bytes each");
+    return NULL;
+  }
+  const uint64_t n = len / 32;
+  napi_value out;
+  void* po = NULL;
+  NAPI_OK(napi_create_buffer(env, n * 40, &po, &out));
+  if (n) {
+    int rc = msm_test_glv(h->ctx, sc, (uint8_t*)po, n);
+    if (rc != MSM_OK) return throw_msm(env, h->ctx, rc, "glvDecompose");
+  }
+  return out;
+}
+
+static napi_value BatchAdd(napi_env env, napi_callback_info info) {  // Affine.batchAdd, src/curve-affine.ts:376-522
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  js_ctx* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  uint8_t *g = NULL, *hh = NULL;
+  size_t lg = 0, lh = 0;
+  if (!buffer_arg(env, argv[1], &g, &lg) || !buffer_arg(env, argv[2], &hh, &lh)) return NULL;
+  if (lg % h->point_bytes || lg != lh || lg == 0) {
+    napi_throw_error(env, NULL, "batchAdd: two equally long, non-empty arrays of whole wire points");
+    return NULL;
+  }
+  napi_value out;
+  void* po = NULL;
+  NAPI_OK(napi_create_buffer(env, lg, &po, &out));
+  int rc = msm_test_batch_add(h->ctx, g, hh, (uint8_t*)po, lg / h->point_bytes);
+  if (rc != MSM_OK) return throw_msm(env, h->ctx, rc, "batchAdd");
+  return out;
+}
+
 NAPI_MODULE_INIT() {
   // the library found at run time must come from the header this addon was compiled against: same symbol names, other
   // struct layouts would otherwise be read wrongly without a word
@@ -452,13 +577,21 @@ NAPI_MODULE_INIT() {
       {"createContext", CreateContext}, {"destroyContext", DestroyContext}, {"setPoints", SetPoints}, {"msm", Msm}, {"plan", Plan},
       {"generatePoints", GeneratePoints}, {"generateScalars", GenerateScalars},
       {"deviceAlloc", DeviceAlloc}, {"deviceUpload", DeviceUpload}, {"deviceFree", DeviceFree}, {"msmDevice", MsmDevice},
-      {"pointsetCreate", PointsetCreate}, {"pointsetSelect", PointsetSelect}, {"pointsetDestroy", PointsetDestroy}};
+      {"pointsetCreate", PointsetCreate}, {"pointsetSelect", PointsetSelect}, {"pointsetDestroy", PointsetDestroy},
+      {"fieldOp", FieldOp}, {"batchInverse", BatchInverse}, {"glvDecompose", GlvDecompose}, {"batchAdd", BatchAdd}};
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;
     if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
     if (napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) return NULL;
   }
   napi_value v;
+  struct { const char* name; int32_t val; } ops[] = {{"OP_MUL", MSM_OP_MUL}, {"OP_SQR", MSM_OP_SQR}, {"OP_ADD", MSM_OP_ADD}, {"OP_SUB", MSM_OP_SUB},
+      {"OP_INV", MSM_OP_INV}, {"OP_TO_MONT", MSM_OP_TO_MONT}, {"OP_FROM_MONT", MSM_OP_FROM_MONT}, {"OP_INV_FERMAT", MSM_OP_INV_FERMAT},
+      {"OP_INV_KALISKI", MSM_OP_INV_KALISKI}, {"OP_INV_WORDSLICED", MSM_OP_INV_WORDSLICED}};
+  for (size_t i = 0; i < sizeof ops / sizeof ops[0]; i++) {
+    napi_create_int32(env, ops[i].val, &v);
+    napi_set_named_property(env, exports, ops[i].name, v);
+  }
   napi_create_int32(env, MSM_ABI_VERSION, &v);
   napi_set_named_property(env, exports, "ABI_VERSION", v);
   napi_create_int32(env, MSM_CURVE_BLS12_377_G1, &v);

@@ -329,6 +329,12 @@ def test_msm_2p26_known_discrete_logs(gpu_ctx, c_oracle):
     dev, s = gpu_ctx.generate_scalars(n, seed=6262, to_host=True, raw=True)
     res, info = gpu_ctx.run_device(dev, n)
     k = c_oracle.dot_mod(a, s, n, C.q)
+    # the generated points themselves against the oracle: 1 024 of them spread over the whole table (a prime stride), so the
+    # known-discrete-log check below does not rest on the generator kernels it shares its field arithmetic with
+    G = (C.gx, C.gy)
+    for j in range(1024):
+        i = (j * 65537 * 1021 + 12345) % n
+        assert gpu_ctx.get_point(i) == O.aff_scale(int.from_bytes(a[32 * i:32 * i + 32], "little"), G, P_MOD), i
     del a, s
     assert info["c"] == 21 and info["K"] == 6      # since round 4: six windows of 21 bits, the carry bit folded into the top one
     assert res.as_tuple() == O.aff_scale(k, (C.gx, C.gy), P_MOD), info
@@ -353,6 +359,30 @@ def test_msm_2p26_known_discrete_logs(gpu_ctx, c_oracle):
     share = n // 8
     groups = b"".join(gpu_ctx.window_sums(dev + 32 * g * share, share, 0, 8, on_device=True, point_lo=g * share)[0] for g in range(8))
     assert combine_groups_host(groups, 8, 8, 16, _lib.CURVE_BLS12_377_G1) == res.as_tuple()
+
+
+def test_default_plan_at_2p22_is_seven_folded_18_bit_windows(gpu_ctx, c_oracle):
+    """2^22 <= n < 2^23 picks seven 18-bit windows with the carry bit folded into the top one (pick_window): the plan must be
+    the one the library PICKS here, not only one a test forces; same element as the 16-bit plan and as the known discrete logs."""
+    n = 1 << 22
+    assert gpu_ctx.plan(n) == (18, 7) and gpu_ctx.plan((1 << 23) - 1) == (18, 7) and gpu_ctx.plan(1 << 23) == (16, 8)
+    a = gpu_ctx.generate_points(n, seed=2222, want_scalars=True, raw=True)
+    dev, s = gpu_ctx.generate_scalars(n, seed=4444, to_host=True, raw=True)
+    res, info = gpu_ctx.run_device(dev, n)
+    assert info["c"] == 18 and info["K"] == 7, info
+    assert res.as_tuple() == O.aff_scale(c_oracle.dot_mod(a, s, n, C.q), (C.gx, C.gy), P_MOD), info
+    res16, info16 = gpu_ctx.run_device(dev, n, c=16)
+    assert info16["K"] == 8 and res16.as_tuple() == res.as_tuple()
+
+
+def test_glv_halves_stay_below_the_bound_a_folded_plan_relies_on(gpu_ctx):
+    """Plan::fold leaves the top window unrecoded: its digit stays inside the window's 2^c buckets only while both GLV halves
+    are below 2^126 (BLS12-377: Scalar.maxBits, src/wasm/glv.ts:216-226).  Extreme and random scalars through k_test_glv."""
+    extremes = [0, 1, 2, C.q - 1, C.q - 2, C.q // 2, C.q // 2 + 1, C.lam, C.lam - 1, C.lam + 1, C.q - C.lam, (1 << 252) - 1, (1 << 251),
+                (C.q - 1) // 3, 2 * (C.q - 1) // 3]
+    scalars = [v % C.q for v in extremes] + O.prng_ints("gpu/glv/bound", 50000, C.q)
+    for (s0, s1, _n0, _n1) in gpu_ctx.test_glv(O.scalars_to_bytes(scalars)):
+        assert s0 < (1 << 126) and s1 < (1 << 126)
 
 
 def test_msm_large_linearity(gpu_ctx):

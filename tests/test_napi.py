@@ -27,7 +27,7 @@ def test_addon_loads_and_exports(addon):
     assert out.returncode == 0, out.stderr
     names = out.stdout.strip().split(",")
     for n in ("createContext", "destroyContext", "setPoints", "msm", "plan", "deviceAlloc", "deviceUpload", "deviceFree", "msmDevice",
-              "ABI_VERSION"):
+              "fieldOp", "batchInverse", "glvDecompose", "batchAdd", "OP_MUL", "OP_INV", "ABI_VERSION"):
         assert n in names
 
 
@@ -64,6 +64,19 @@ def test_js_benchmark_with_the_reference_protocol(addon):
     lines = out.stdout.splitlines()
     assert sum(1 for l in lines if l.rstrip().endswith("ms") and "... " in l and not l.startswith("msm (n=")) >= 6, out.stdout
     assert any(l.startswith("msm total... ") for l in lines)
+
+
+@pytest.mark.gpu
+def test_js_field_operator_table_replays_the_golden_vectors(addon):
+    """Field.multiply / square / add / subtract / inverse / batchInverse, Scalar.decompose and Affine.batchAdd through the N-API
+    boundary (the reference's fine wasm exports, src/field-msm.ts:190-243, src/scalar-glv.ts:105-128) against
+    tests/golden/fp377.json, glv377.json and point_add377.json."""
+    import json
+
+    out = subprocess.run([NODE, "js/test-field.js"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["ok"] and rep["fp_cases"] >= 30 and rep["glv_cases"] >= 60 and rep["batch_add_cases"] >= 5, rep
 
 
 @pytest.mark.gpu
