@@ -8,7 +8,7 @@ HIPFLAGS := -O3 -pthread -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unus
 BUILD := build
 CURVES := CvBls377 CvBls381 CvPallas
 CURVE_OBJS := $(CURVES:%=$(BUILD)/kernels_%.o)
-HOST_TUS := msm_plan msm_sort msm_tree msm_reduce msm_upload msm_pipeline msm_abi msm_test_abi msm_gen sort_kernels te_kernels
+HOST_TUS := msm_plan msm_sort msm_tree msm_reduce msm_upload msm_pipeline msm_tables msm_abi msm_test_abi msm_gen sort_kernels te_kernels
 HOST_OBJS := $(HOST_TUS:%=$(BUILD)/%.o)
 KHDRS := $(CSRC)/msm_kernels.h $(CSRC)/batch_add.h $(CSRC)/msm_gen_kernels.h $(CSRC)/kernel_inst.h $(CSRC)/field.h $(CSRC)/packed.h $(CSRC)/curve.h \
          $(CSRC)/glv.h $(CSRC)/constants_gen.h

@@ -51,8 +51,9 @@ enum {
  * binding built against another version of the header would misread memory silently: msm_abi_version() returns the version the
  * LIBRARY was built with, msm_abi_struct_bytes(0 / 1) its sizeof(msm_opts) / sizeof(msm_result).  The Python loader and the N-API
  * addon compare both at load time and refuse a mismatch.  History: 3 = round 3 (msm_generate_scalars writes to a caller-owned
- * buffer; msm_opts.point_lo / by_window); 4 = msm_result.n_pairs_algo. */
-#define MSM_ABI_VERSION 4
+ * buffer; msm_opts.point_lo / by_window); 4 = msm_result.n_pairs_algo; 5 = window tables (msm_opts.no_tables, msm_result.tables,
+ * msm_precompute / msm_tables_info / msm_set_tables_limit) and msm_reserve. */
+#define MSM_ABI_VERSION 5
 uint32_t msm_abi_version(void);
 uint32_t msm_abi_struct_bytes(int which);
 
@@ -83,6 +84,8 @@ typedef struct msm_opts {
                            on its n / G points, msm_combine_groups adds the G partial sums of every window */
   int32_t by_window;    /* multi-device contexts (msm_ctx_create_multi): != 0 shards an MSM by scalar window, every device then
                            needs all n scalars; default 0: by points, device d gets the scalars of its n / G points only */
+  int32_t no_tables;    /* != 0: do not use (and do not build) window tables for this call -- the plain path over the resident
+                           rows, K windows of buckets and a Horner step, as in rounds 1-4 (see msm_precompute) */
 } msm_opts;
 
 #define MSM_N_PHASES 8
@@ -105,6 +108,8 @@ typedef struct msm_result {
   uint64_t max_bucket;  /* largest bucket population seen */
   uint64_t n_pairs_algo; /* pair additions the bucket sums NEED: sum over the non-empty buckets of (population - 1); the
                             basis of roofline figures (n_pairs is ~2.5 % above it at 2^26) */
+  int32_t tables;        /* != 0: the call ran on window tables (K tables of the point set, one set of buckets per window group) */
+  int32_t reserved_;
 } msm_result;
 
 /* Context: binds one curve to one GPU (device index as seen by HIP). Replaces
@@ -127,6 +132,27 @@ const char* msm_last_error(const msm_ctx* ctx);
  * per call as in preparePointsAndScalars, src/msm-batched-affine.ts:350-421).
  * on_device != 0: `points` is a device pointer.  check_curve != 0: verify the curve equation. */
 int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, int check_curve);
+
+/* Window tables.  For a fixed point set (the bases of a prover: the reference's callers load their points once and run many
+ * MSMs over them, scripts/msm-weierstrass.ts:19-35) the library can keep K tables instead of one: table k holds 2^(c k) P_i for
+ * every point, so the digit of window k addresses a point that already carries the window's weight and all K windows share ONE
+ * set of 2^(c-1) buckets -- K times fewer buckets to finish and reduce, no Horner step, same group element.  The reference has
+ * no counterpart (its heap is 4 GiB); six tables of 2^26 BLS12-377 points are 103 GB of the 288 GB of HBM.
+ * msm_run builds them by itself on its first call over the WHOLE current point set with the default window (opts->c == 0)
+ * when they fit the limit (default: 10 % of the device memory -- 28 GB: point sets of up to 2^24 BLS12-377 points; what they
+ * buy shrinks from 6-10 % below 2^24 points to 1.5 % at 2^26, where they would take 96 GB), and uses them whenever the call's plan is the one they were built
+ * for; any other call -- another window size, a prefix or a range of the points, msm_window_sums, a device-list context --
+ * takes the plain path over table 0, which is always the plain row table.  msm_precompute builds them ahead of the first call
+ * (also for an explicit opts->c); it is not an error if they do not fit: the plain path stays.  msm_set_points drops them.
+ * msm_tables_info: window size and number of tables present (0, 0: none) and their bytes. */
+int msm_precompute(msm_ctx* ctx, uint64_t n, const msm_opts* opts);
+int msm_tables_info(const msm_ctx* ctx, int32_t* c_out, int32_t* K_out, uint64_t* bytes_out);
+int msm_set_tables_limit(msm_ctx* ctx, uint64_t bytes);   /* 0: never build tables */
+
+/* Everything a later msm_run(ctx, <device scalars>, n, opts) allocates or builds -- the per-call workspace (device memory costs
+ * ~40 ms per GB to get on this system: 3 s before the first 2^26 MSM) and the window tables -- taken out of that call: runs one
+ * MSM over internally generated scalars and discards the result. */
+int msm_reserve(msm_ctx* ctx, uint64_t n, const msm_opts* opts);
 
 /* Point-set handles (the reference's `pointPtr`s are independent allocations, src/parallel.ts:97-116): a context starts
  * with point set 0; msm_pointset_create adds an empty one and makes it current, msm_pointset_select switches.

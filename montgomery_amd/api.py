@@ -144,6 +144,7 @@ def _result_to_dict(res: MsmResult) -> Dict:
         "n_pairs": int(res.n_pairs),
         "n_pairs_algo": int(res.n_pairs_algo),
         "max_bucket": int(res.max_bucket),
+        "tables": bool(res.tables),
         "phase_ms": {name: float(res.phase_ms[i]) for i, name in enumerate(_lib.PHASE_NAMES)},
     }
 
@@ -296,19 +297,20 @@ class MsmContext:
         return cc.value, kk.value
 
     def run(self, scalars: BytesLike, c: Optional[int] = None, unsafe: bool = False, no_glv: bool = False,
-            by_window: bool = False) -> Tuple[AffineResult, Dict]:
+            by_window: bool = False, no_tables: bool = False) -> Tuple[AffineResult, Dict]:
         if len(scalars) % 32:
             raise MsmError(_lib.MSM_ERR_ARG, f"scalar buffer length {len(scalars)} is not a multiple of 32")
         n = len(scalars) // 32
         # a ctypes array is handed over as it is (no 2 GB copies at 2^26), anything else is copied once
         buf = scalars if isinstance(scalars, C.Array) else (C.c_uint8 * max(len(scalars), 1)).from_buffer_copy(bytes(scalars) or b"\0")
-        return self._run(buf, n, 0, c, unsafe, no_glv=no_glv, by_window=by_window)
+        return self._run(buf, n, 0, c, unsafe, no_glv=no_glv, by_window=by_window, no_tables=no_tables)
 
     def run_device(self, dev_ptr: int, n: int, c: Optional[int] = None, unsafe: bool = False, serial: bool = False,
-                   no_glv: bool = False, by_window: bool = False, point_lo: int = 0) -> Tuple[AffineResult, Dict]:
+                   no_glv: bool = False, by_window: bool = False, point_lo: int = 0, no_tables: bool = False) -> Tuple[AffineResult, Dict]:
         """by_window: a device-list context shards by scalar window instead of by points.  point_lo: the MSM covers the
-        resident points [point_lo, point_lo + n) (scalar i belongs to point point_lo + i)."""
-        return self._run(C.c_void_p(dev_ptr), n, 1, c, unsafe, serial, no_glv, by_window, point_lo)
+        resident points [point_lo, point_lo + n) (scalar i belongs to point point_lo + i).  no_tables: the plain path even
+        where window tables exist or would be built (msm_opts.no_tables)."""
+        return self._run(C.c_void_p(dev_ptr), n, 1, c, unsafe, serial, no_glv, by_window, point_lo, no_tables)
 
     def run_placed(self, dev_ptrs: Sequence[int], n: int, c: Optional[int] = None) -> Tuple[AffineResult, Dict]:
         """Device-list context, scalars already placed: dev_ptrs[d] on devices[d] holds the scalars of that device's share
@@ -322,9 +324,9 @@ class MsmContext:
         return out, _result_to_dict(res)
 
     def _run(self, ptr, n: int, on_device: int, c: Optional[int], unsafe: bool, serial: bool = False,
-             no_glv: bool = False, by_window: bool = False, point_lo: int = 0) -> Tuple[AffineResult, Dict]:
+             no_glv: bool = False, by_window: bool = False, point_lo: int = 0, no_tables: bool = False) -> Tuple[AffineResult, Dict]:
         opts = MsmOpts(c=c or 0, unsafe=int(unsafe), serial=int(serial), no_glv=int(no_glv), by_window=int(by_window),
-                       point_lo=point_lo)
+                       point_lo=point_lo, no_tables=int(no_tables))
         res = MsmResult()
         self._check(self._lib.msm_run(self._h, ptr, n, on_device, C.byref(opts), C.byref(res)))
         nb = self.coord_bytes
@@ -334,6 +336,28 @@ class MsmContext:
             isZero=bool(res.is_infinity),
         )
         return out, _result_to_dict(res)
+
+    # -- window tables (msm_precompute, include/msm_hip.h) ------------------------------------
+    def precompute(self, n: Optional[int] = None, c: Optional[int] = None, no_glv: bool = False) -> Tuple[int, int, int]:
+        """Builds the window tables of the current point set for the plan msm_run(n, c) would use (no-op if present or if they
+        do not fit the limit).  Returns tables_info()."""
+        opts = MsmOpts(c=c or 0, no_glv=int(no_glv))
+        self._check(self._lib.msm_precompute(self._h, self.n_points if n is None else n, C.byref(opts)))
+        return self.tables_info()
+
+    def tables_info(self) -> Tuple[int, int, int]:
+        """(window bits, number of tables, bytes) of the current point set's window tables; (0, 0, 0): none."""
+        c, k, b = C.c_int32(), C.c_int32(), C.c_uint64()
+        self._check(self._lib.msm_tables_info(self._h, C.byref(c), C.byref(k), C.byref(b)))
+        return c.value, k.value, b.value
+
+    def set_tables_limit(self, nbytes: int) -> None:
+        self._check(self._lib.msm_set_tables_limit(self._h, nbytes))
+
+    def reserve(self, n: int, c: Optional[int] = None) -> None:
+        """Everything a later run_device(n, c) would allocate or build, now (msm_reserve)."""
+        opts = MsmOpts(c=c or 0)
+        self._check(self._lib.msm_reserve(self._h, n, C.byref(opts)))
 
     def window_sums(self, scalars: Union[BytesLike, int], n: int, k_lo: int, k_hi: int, c: Optional[int] = None,
                     on_device: bool = False, point_lo: int = 0, by_window: bool = False) -> Tuple[bytes, Dict]:

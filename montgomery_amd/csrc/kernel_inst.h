@@ -7,6 +7,7 @@
 #define MSM_COMMA ,
 #define MSM_CURVE_KERNELS(X, CV)                                                                                          \
   X(msm::k_points_from_wire<CV>, (uint32_t*, const uint32_t*, uint64_t, int, uint32_t*))                                 \
+  X(msm::k_table_next<CV>, (uint32_t*, const uint32_t*, uint64_t, int))                                                   \
   X(msm::k_digits<CV>, (uint32_t*, const uint32_t*, uint32_t, int, int, int, int, int, int, uint32_t*, uint32_t, uint32_t*, uint32_t, \
                        uint64_t))                   \
   X(msm::k_batch_add<CV MSM_COMMA msm::MODE_GATHER>, (msm::BatchArgs))                                                   \

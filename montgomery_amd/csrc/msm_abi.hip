@@ -41,6 +41,7 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     // leave room for the resident points (144 B/point at 2^26 = 9.7 GB) and fragmentation
     ctx->ws_budget = (uint64_t)(free_b * 0.55);
+    ctx->tables_limit = (uint64_t)(total_b * 0.10);   // window tables of one point set (msm_set_tables_limit): up to 2^24 points
     ctx->ensure(ctx->errflag, 16);
     sort_kernel_attributes();
   } catch (const HipFail& f) {
@@ -104,6 +105,7 @@ static int set_points_one(msm_ctx* ctx, const void* points, uint64_t n, int on_d
   try {
     HIPCHK(hipSetDevice(ctx->device));
     ctx->n_points = 0;
+    ctx->tab_c = ctx->tab_K = 0;   // window tables belong to the points they were built from
     ctx->ensure(ctx->rows, std::max<uint64_t>(n, 1) * row_words * 4);
     const uint32_t* d_wire = (const uint32_t*)points;
     if (!on_device && n) {
@@ -153,7 +155,10 @@ int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, 
 
 int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_out, int32_t* K_out) {
   Plan pl;   // plain arithmetic: nothing here can throw
-  int rc = make_plan(ctx, n, opts, pl);
+  bool tables_wanted = false;
+  // (a context with resident points answers for msm_run over them, window tables included; msm_window_sums and shards of
+  // the points always run the plain plan, which is also what a context without points reports)
+  int rc = ctx && n && n == ctx->n_points ? make_run_plan(const_cast<msm_ctx*>(ctx), n, opts, false, pl, tables_wanted) : make_plan(ctx, n, opts, pl);
   if (rc) return rc;
   if (c_out) *c_out = pl.c;
   if (K_out) *K_out = pl.K;
@@ -255,7 +260,8 @@ static int run_impl(msm_ctx* ctx, const void* scalars, const void* const* placed
     opts = &piped;
   }
   Plan pl;
-  if (make_plan(ctx, n, opts, pl)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);
+  bool tables_wanted = false;   // window tables (msm_tables.hip): the plan is then the one tables want
+  if (make_run_plan(ctx, n, opts, placed != nullptr, pl, tables_wanted)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);
   pl.merged = true;
   memset(out, 0, sizeof(*out));
   out->c = pl.c;
@@ -268,13 +274,17 @@ static int run_impl(msm_ctx* ctx, const void* scalars, const void* const* placed
   try {
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<uint32_t> words;
+    // window tables (msm_tables.hip): built here on the first default-plan call over the whole point set
+    pl.tables = tables_wanted && use_window_tables(ctx, n, opts, pl, /*may_build=*/true);
     any_window_sums(ctx, scalars, n, on_device, opts, 0, pl.K, pl, words, out, placed);
+    out->tables = pl.tables ? 1 : 0;
     HIPCHK(hipEventRecord(ctx->ev[10], ctx->stream));
+    const int slots = pl.tables ? 1 : pl.K;   // on tables slot 0 holds the whole sum, weights included: no Horner step
     if (ctx->is_te()) {
-      te_horner_to_affine(ctx, words, pl.K, pl.c, out);
+      te_horner_to_affine(ctx, words, slots, pl.c, out);
     } else {
-      std::vector<msm_host::Proj6> P(pl.K);
-      for (int k = 0; k < pl.K; k++) P[k] = partial_to_host(ctx, &words[(size_t)k * 36]);
+      std::vector<msm_host::Proj6> P(slots);
+      for (int k = 0; k < slots; k++) P[k] = partial_to_host(ctx, &words[(size_t)k * 36]);
       horner_to_affine(ctx->hc, P, pl.c, out);
     }
     HIPCHK(hipEventRecord(ctx->ev[11], ctx->stream));
@@ -301,6 +311,27 @@ int msm_run_placed(msm_ctx* ctx, const void* const* dev_scalars, uint64_t n, con
     if (!dev_scalars[d] && n * (uint64_t)(d + 1) / ndev > n * (uint64_t)d / ndev)
       return fail(ctx, MSM_ERR_ARG, "msm_run_placed: no scalars for device %d", d);
   return run_impl(ctx, nullptr, dev_scalars, n, 1, opts, out, "msm_run_placed");
+}
+
+int msm_reserve(msm_ctx* ctx, uint64_t n, const msm_opts* opts) {
+  if (!ctx) return MSM_ERR_ARG;
+  if ((opts ? opts->point_lo : 0) + n > ctx->n_points)
+    return fail(ctx, MSM_ERR_NO_POINTS, "msm_reserve: %llu points asked for, %llu resident", (unsigned long long)n, (unsigned long long)ctx->n_points);
+  if (n == 0) return MSM_OK;
+  void* dev = nullptr;
+  try {
+    // one MSM over generated scalars: every buffer the real call will need exists afterwards, and so do the window tables
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMalloc(&dev, n * 32));
+    int rc = msm_generate_scalars(ctx, n, 0x5eed, dev, nullptr);
+    msm_result r;
+    if (rc == MSM_OK) rc = msm_run(ctx, dev, n, 1, opts, &r);
+    (void)hipFree(dev);
+    return rc;
+  } catch (...) {
+    if (dev) (void)hipFree(dev);
+    return fail(ctx, MSM_ERR_HIP, "msm_reserve: device allocation failed");
+  }
 }
 
 int msm_get_points(msm_ctx* ctx, uint64_t first, uint64_t count, uint8_t* out_xy) {
@@ -359,8 +390,12 @@ static int pointset_select_one(msm_ctx* ctx, int32_t id) {
   if (id == ctx->cur_set) return MSM_OK;
   ctx->sets[ctx->cur_set].rows = ctx->rows;
   ctx->sets[ctx->cur_set].n = ctx->n_points;
+  ctx->sets[ctx->cur_set].tab_c = ctx->tab_c;
+  ctx->sets[ctx->cur_set].tab_K = ctx->tab_K;
   ctx->rows = ctx->sets[id].rows;
   ctx->n_points = ctx->sets[id].n;
+  ctx->tab_c = ctx->sets[id].tab_c;
+  ctx->tab_K = ctx->sets[id].tab_K;
   ctx->cur_set = id;
   return MSM_OK;
 }

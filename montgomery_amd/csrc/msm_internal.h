@@ -5,6 +5,7 @@
 //   msm_reduce.hip    bucket reduction, window sums, host tail (Horner, to-affine, combine)
 //   msm_upload.hip    staged and pipelined host -> device transfers
 //   msm_pipeline.hip  window groups on two streams, point ranges, multi-device fan-out
+//   msm_tables.hip    window tables (K resident tables 2^(c k) P: one set of buckets for all windows)
 //   msm_abi.hip       the C ABI of include/msm_hip.h (contexts, points, msm_run, msm_window_sums, handles)
 //   msm_test_abi.hip  the operator-level test entries (msm_test_*) and the input generators
 // Kernels live in kernels_curve.hip (one TU per curve), sort_kernels.hip and te_kernels.hip; host TUs see declarations.
@@ -186,7 +187,12 @@ struct msm_ctx {
     msmi::DevBuf rows;
     uint64_t n = 0;
     bool live = false;
+    int tab_c = 0, tab_K = 0;
   };
+  // Window tables of the CURRENT point set (msm_tables.hip): `rows` then holds tab_K tables of n_points rows each, table k =
+  // 2^(tab_c k) P (0: none, `rows` is the plain table).  Travel with the set through msm_pointset_select.
+  int tab_c = 0, tab_K = 0;
+  uint64_t tables_limit = 0;   // bytes the tables of one point set may take (msm_set_tables_limit; default: 40 % of the device)
   std::vector<PointSet> sets = std::vector<PointSet>(1);   // slot 0 = the default set
   int cur_set = 0;
   std::vector<void*> allocs;        // device buffers handed out by msm_device_alloc
@@ -302,11 +308,17 @@ struct Plan {
   bool no_glv;
   bool strict = false;   // msm_opts.strict: scalars >= q fail the call instead of being reduced
   bool lone = false;   // one window, one group: nothing else shares the GPU (see round_geom)
+  bool tables = false; // the call runs on window tables (msm_tables.hip): the windows of a group share one set of buckets, a
+                       // group hands back ONE sum that already carries the windows' weights
   bool merged = false; // a full MSM (msm_run): a window group may hand back sum_k 2^(c (k - k_first)) P_k in the slot of its
                        // first window instead of one P_k per slot (reduce_buckets); msm_window_sums never sets it
 };
 
-int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl);
+// for_tables: the window a run on window tables wants (bucket work no longer grows with the number of windows)
+int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl, bool for_tables = false);
+// the plan of msm_run(n, opts) -- on window tables where the call is eligible and they exist or would be built -- and whether
+// it is that plan (msm_tables.hip)
+int make_run_plan(msm_ctx* ctx, uint64_t n, const msm_opts* opts, bool placed, Plan& pl, bool& tables_wanted);
 
 struct GroupStats {
   uint64_t n_pairs = 0;
@@ -365,9 +377,14 @@ struct TreeOut {
   const uint32_t* off_fin = nullptr;
   const uint32_t* bucket_proj = nullptr;   // bucket sums from k_bucket_finish (projective / extended)
 };
-void accumulate_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const Plan& pl, int kc, uint64_t p_lo, const SortOut& so,
+// kc: windows of the group as the tree sees them (1 on window tables); row_off: first row of the point table the payloads count from
+void accumulate_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const Plan& pl, int kc, uint64_t row_off, const SortOut& so,
                              GroupStats& st, TreeOut& to);
 void sort_kernel_attributes();   // dynamic-LDS limits of the sort kernels (once per process and device)
+
+// ---- msm_tables.hip ---------------------------------------------------------------------------------------------
+// true if the MSM over the first n resident points under plan `pl` can run on window tables; builds them when `may_build`
+bool use_window_tables(msm_ctx* ctx, uint64_t n, const msm_opts* opts, const Plan& pl, bool may_build);
 
 // ---- msm_upload.hip ---------------------------------------------------------------------------------------------
 void ensure_staging(msm_ctx* ctx);

@@ -183,6 +183,53 @@ __global__ void __launch_bounds__(256) k_points_from_wire(uint32_t* rows, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_table_next: window tables.  Row i of table k holds 2^(c k) P_i (with its beta x line), so that the digit of window k
+// addresses a point that already carries the window's weight: all K windows of an MSM then share ONE set of buckets
+// (sum_k 2^(c k) sum_i d_ik P_i = sum_(i,k) d_ik T_k[i]) -- K times fewer buckets to finish and reduce, no Horner step.
+// The reference keeps no such tables (its memory is 4 GiB of wasm heap); 288 GB of HBM hold six of them for 2^26 points.
+// One launch makes table k from table k - 1: c projective doublings (dbl-1998-cmo-2, src/curve-projective.ts:202-253) and
+// one inversion per point.  Built once per point set and plan, like the beta x of k_points_from_wire.
+// ---------------------------------------------------------------------------------------------
+
+template <class CV>
+__global__ void __launch_bounds__(256) k_table_next(uint32_t* rows_out, const uint32_t* rows_in, uint64_t n, int c) {
+  using F = typename CV::F;
+  constexpr int NL = F::NL, NW = F::NW;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t xw[NW], yw[NW];
+  load_words12(xw, rows_in + i * ROW_WORDS);
+  load_words12(yw, rows_in + i * ROW_WORDS + NW);
+  uint32_t* out = rows_out + i * ROW_WORDS;
+  if (xw[NW - 1] == INF_WORD) {
+    store_row_identity<NW / 4>(out);
+    return;
+  }
+  Proj<F> P;
+  fe_unpack<F>(P.X, xw);
+  fe_unpack<F>(P.Y, yw);
+  fe_set_one<F>(P.Z);
+#pragma unroll 1
+  for (int j = 0; j < c; j++) proj_double<F>(P, P);
+  if (proj_is_zero<F>(P)) {   // a point of even order (outside the prime-order subgroup) doubled to the identity
+    store_row_identity<NW / 4>(out);
+    return;
+  }
+  Fe<F> zi, x, y, bx, beta;
+  fe_reduce_4p<F>(P.Z);
+  fe_inv<F>(zi, P.Z);
+  fe_mul<F>(x, P.X, zi);
+  fe_reduce_2p<F>(x);
+  fe_mul<F>(y, P.Y, zi);
+  fe_reduce_2p<F>(y);
+#pragma unroll
+  for (int l = 0; l < NL; l++) beta.l[l] = F::BETAL[l];
+  fe_mul<F>(bx, x, beta);
+  fe_reduce_2p<F>(bx);
+  store_row(out, x, y, bx);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_digits: scalars (N x 32 B LE) -> signed window digits of both GLV halves
 // ---------------------------------------------------------------------------------------------
 

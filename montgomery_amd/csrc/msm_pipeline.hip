@@ -56,8 +56,20 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   if (before_tree) (*before_tree)(s);
   HIPCHK(hipEventRecord(w.ev[5], s));   // the tree starts here (behind the partner group's sort, if there is one)
   TreeOut to;
-  accumulate_window_group(ctx, w, pl, kc, p_lo, so, st, to);
-  reduce_buckets(ctx, w, to.fin, to.fin_cap, to.off_fin, to.bucket_proj, pl.L, kc, h_partials_out, pl.merged, pl.c);
+  if (pl.tables) {
+    // one merged window over the tables k_lo .. k_hi - 1: its sum carries the windows' weights already.  It goes into the
+    // group's first slot, identities into the others.
+    accumulate_window_group(ctx, w, pl, 1, (uint64_t)k_lo * ctx->n_points, so, st, to);
+    reduce_buckets(ctx, w, to.fin, to.fin_cap, to.off_fin, to.bucket_proj, pl.L, 1, h_partials_out, pl.merged, pl.c);
+    const int pw = ctx->is_te() ? 32 : 36;
+    for (int kk = 1; kk < kc; kk++) {
+      if (ctx->is_te()) te_host_to_partial(ctx, ctx->hte.zero(), h_partials_out + (size_t)kk * pw);
+      else memset(h_partials_out + (size_t)kk * pw, 0, (size_t)pw * 4);
+    }
+  } else {
+    accumulate_window_group(ctx, w, pl, kc, p_lo, so, st, to);
+    reduce_buckets(ctx, w, to.fin, to.fin_cap, to.off_fin, to.bucket_proj, pl.L, kc, h_partials_out, pl.merged, pl.c);
+  }
   float ms;
   HIPCHK(hipEventElapsedTime(&ms, w.ev[0], w.ev[1])); st.ms_digits += ms;
   HIPCHK(hipEventElapsedTime(&ms, w.ev[1], w.ev[2])); st.ms_sort += ms;
@@ -178,7 +190,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   // does more than one group contribute to a window?  Then the sums of its ranges are added on the host below.
   bool split_points = false;
   for (const Group& g : groups) split_points |= g.p_n != n;
-  std::vector<std::vector<uint32_t>> split_part(split_points ? groups.size() : 0);
+  std::vector<std::vector<uint32_t>> split_part((split_points || pl.tables) ? groups.size() : 0);
   HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));   // staged scalars are in place before the group streams start
   if (!piece_end.empty()) {
@@ -205,7 +217,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       Plan pg = pl;
       // a launch that has the chip to itself -- the one-window shard, or every launch of a serialised call (msm_opts.serial,
       // the exclusive timing of the roofline) -- walks its pairs in four short batches instead of one long one (round_geom)
-      pg.lone = (groups.size() == 1 && kb - ka == 1) || (opts && opts->serial);
+      pg.lone = (groups.size() == 1 && (kb - ka == 1 || pl.tables)) || (opts && opts->serial);
       if (groups[gi].piece >= 0) pipe->wait_piece(groups[gi].piece, ctx->ws[slot].stream);
       // the partner group runs on the other workspace; its ev[2] closes its sort
       const int pair = (nthreads == 2 && want_pair_sync) ? groups[gi].pair : -1;
@@ -225,7 +237,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
         psync.abort();   // the partner must not wait for a group that will not arrive
         throw;
       }
-      if (split_points) split_part[gi] = part;
+      if (split_points || pl.tables) split_part[gi] = part;
       else memcpy(&words[(size_t)(ka - k_lo) * pw], part.data(), part.size() * 4);
     }
   };
@@ -258,7 +270,22 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   }
   float upload_ms = -1;
   if (pipe) upload_ms = pipe->finish();   // joins the staging threads; their last copy is done
-  if (split_points) {
+  if (pl.tables) {
+    // every group's first slot holds the sum of its windows WITH their weights: the call's sum is their plain sum, kept in
+    // slot 0 (identities elsewhere: the caller's Horner step over such slots would return the same element)
+    if (ctx->is_te()) {
+      msm_host::Ext6 acc = ctx->hte.zero();
+      for (size_t gi = 0; gi < groups.size(); gi++)
+        if (!split_part[gi].empty()) acc = ctx->hte.add(acc, te_partial_to_host(ctx, split_part[gi].data()));
+      for (int k = k_lo; k < k_hi; k++) te_host_to_partial(ctx, k == k_lo ? acc : ctx->hte.zero(), &words[(size_t)(k - k_lo) * pw]);
+    } else {
+      msm_host::Proj6 acc = ctx->hc.zero();
+      for (size_t gi = 0; gi < groups.size(); gi++)
+        if (!split_part[gi].empty()) acc = ctx->hc.add(acc, partial_to_host(ctx, split_part[gi].data()));
+      std::fill(words.begin(), words.end(), 0u);
+      host_to_partial(ctx, acc, words.data());
+    }
+  } else if (split_points) {
     // P_k = sum over the ranges of the points (groups of one or several windows each); an all-zero partial (Z = 0) is the
     // identity.  (Plan.merged: a group then carries sum_kk 2^(c kk) P_kk in its first slot and identities in the others --
     // slot-wise sums of such groups are still a valid set of slots for the Horner step.)

@@ -61,10 +61,21 @@ int pick_window(bool te, uint64_t n, int glv_max_bits) {
   return best;
 }
 
-int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl) {
+// On window tables all windows of a group share one set of buckets, so a wider window costs its 2^(c-1) buckets once instead
+// of K times and the optimum moves up.  BLS12-377 after GLV (127 bits: 18- and 21-bit windows fold the carry bit, no short top
+// window to skew the merged buckets), measured with tools/tables_csweep.py (profiles/r05_experiments.txt item 5): 16 bits below
+// 2^15 points, 18 from there (2^18 1.58 against 1.76 ms plain, 2^20 3.65 / 3.90, 2^22 11.0 / 11.9, 2^23 20.3 / 21.7), 21 from
+// 2^24 (36.7 / 40.1).  The other curves keep the plain choice (their 18-bit plan would end in a two-bit top window).
+static int pick_window_tables(bool te, uint64_t n, int glv_max_bits) {
+  if (!te && glv_max_bits == 126) return n >= (1ull << 24) ? 21 : n >= (1ull << 15) ? 18 : 16;
+  return pick_window(te, n, glv_max_bits);
+}
+
+int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl, bool for_tables) {
   const bool te = ctx && ctx->is_te();
   const int glv_bits = curve_info(ctx ? ctx->curve : MSM_CURVE_BLS12_377_G1).glv_max_bits;
-  int c = (opts && opts->c > 0) ? opts->c : pick_window(te, n, (opts && opts->no_glv) ? 0 : glv_bits);
+  const int glv_arg = (opts && opts->no_glv) ? 0 : glv_bits;
+  int c = (opts && opts->c > 0) ? opts->c : for_tables ? pick_window_tables(te, n, glv_arg) : pick_window(te, n, glv_arg);
   if (c < 2 || c > 24) return MSM_ERR_ARG;
   // b = Scalar.maxBits (126 after GLV, src/wasm/glv.ts:216-226) or Scalar.sizeInBits (251, src/msm-basic.ts:56)
   // b = Scalar.maxBits after GLV (src/wasm/glv.ts:216-226), or the bit length of q without it (src/msm-basic.ts:56)

@@ -28,12 +28,16 @@ void sort_kernel_attributes() {
 void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars, uint64_t n, const Plan& pl, int k_lo, int k_hi,
                        GroupStats& st, SortOut& so) {
   hipStream_t s = w.stream;
-  const int kc = k_hi - k_lo;
+  const int kc_d = k_hi - k_lo;             // windows the digit kernel slices
   const uint32_t L = pl.L;
-  const uint64_t nb = (uint64_t)kc * L;
   const bool te = ctx->is_te();
-  const uint64_t two_n = te ? n : 2 * n;   // entries per window: both GLV halves, or the plain scalar
-  const uint64_t n_entries = (uint64_t)kc * two_n;
+  const uint64_t two_n_d = te ? n : 2 * n;  // entries per digit window: both GLV halves, or the plain scalar
+  const uint64_t n_entries = (uint64_t)kc_d * two_n_d;
+  // On window tables the kc_d digit windows of the group are ONE window for everything behind the digit kernel: the digit
+  // array [kc_d][two_n_d] read as one run of entries, entry j = (window, point, half) naming row j of the tables.
+  const int kc = pl.tables ? 1 : kc_d;
+  const uint64_t two_n = pl.tables ? n_entries : two_n_d;
+  const uint64_t nb = (uint64_t)kc * L;
 
   // padding granule G = 2^g: about 1/8 of the mean bucket population (pads cost G/2 slots per bucket; what is
   // left after g regular rounds, ~8 elements per bucket, is finished without inversions by k_bucket_finish)
@@ -65,9 +69,13 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   const bool fits_lds = (size_t)L * 4 <= 128 * 1024;
   long long want_radix = (fits_lds && cbits > (int)RX_FINE_BITS && two_n >= (1ull << 22)) ? 1 : 0;   // measured: wins from N = 2^21 up
   MSM_KNOB(want_radix, "MSM_RADIX", 0);
-  const bool radix = fits_lds && want_radix && cbits > (int)RX_FINE_BITS && cbits - (int)RX_FINE_BITS <= 8;
-  const bool one_level = fits_lds && !radix;
-  const bool bin_split = !fits_lds;
+  // (the merged window of a run on window tables has kc = 1: the radix split would give its last pass one block per coarse bin,
+  // 2^(c-8) of them for the whole chip -- the bin split cuts it into 2^10 bins whatever the window is)
+  long long want_bins = (!fits_lds || (pl.tables && two_n >= (1ull << 22))) ? 1 : 0;
+  MSM_KNOB(want_bins, "MSM_BINS", 0);
+  const bool bin_split = !fits_lds || want_bins;
+  const bool radix = !bin_split && want_radix && cbits > (int)RX_FINE_BITS && cbits - (int)RX_FINE_BITS <= 8;
+  const bool one_level = !bin_split && !radix;
   WinSplit ws{};
   uint32_t hb = 1, nbmax = 1;   // bin split: coarse bins per window (stride of the bin tables), most buckets of one bin
   if (bin_split) {
@@ -76,7 +84,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
       // bits the digits of this window really have: the top window of a scalar is usually short (msm_kernels.h, WinSplit)
       // (a window below the top one holds signed digits of magnitude <= 2^(c - 1); the top one what is left of the scalar)
       const bool top = k_lo + kk == pl.K - 1;
-      const int eff = std::max(1, top ? std::min(cbits, pl.bits - (k_lo + kk) * pl.c) : std::min(cbits, pl.c - 1));
+      const int eff = pl.tables ? cbits : std::max(1, top ? std::min(cbits, pl.bits - (k_lo + kk) * pl.c) : std::min(cbits, pl.c - 1));
       // up to 10 bits: pass A sorts the window outright; else 2^10 coarse bins (16-entry runs of a 16 k tile), 2^11 if the
       // fine part would otherwise exceed 2^12 buckets per bin
       long long ab_big = 10;
@@ -101,10 +109,13 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     // the digit kernel histograms ALL windows of the group over its slice of the points: four slices per CU
     long long mult = 4;
     MSM_KNOB(mult, "MSM_SORTB_MULT", 1);
-    sortB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)mult * ctx->n_cu, n / 4096));
+    // (on tables every digit window contributes its own slices to the one merged window: the same number of slices in all,
+    // k_colscan walks them one after the other)
+    const uint64_t per_window = pl.tables ? std::max<uint64_t>(1, (uint64_t)mult * ctx->n_cu / kc_d) : (uint64_t)mult * ctx->n_cu;
+    sortB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per_window, n / 4096));
     pps = (n + sortB - 1) / sortB;
     chunk = (te ? 1 : 2) * pps;
-    ctx->ensure(w.block_hist, (size_t)kc * sortB * hb * 4 + 64);
+    ctx->ensure(w.block_hist, (size_t)kc_d * sortB * hb * 4 + 64);
   } else {
     // big inputs: finer slices also keep the round-1 gathers of neighbouring lanes inside one Infinity-Cache-sized
     // range of point rows (measured: 193 -> 183 ms at 2^26); small inputs: fewer, larger blocks (less fixed cost)
@@ -124,15 +135,17 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     const uint32_t grid = bin_split ? sortB : (uint32_t)((n + 255) / 256);
     const uint32_t per = bin_split ? (uint32_t)pps : 256u;
     uint32_t* hist = bin_split ? (uint32_t*)w.block_hist.p : nullptr;
-    const size_t lds = bin_split ? (size_t)kc * hb * 4 : 0;
+    const size_t lds = bin_split ? (size_t)kc_d * hb * 4 : 0;
+    WinSplit ws_d = ws;   // the digit kernel counts per DIGIT window: on tables all of them with the merged window's cut
+    if (pl.tables) for (int kk = 0; kk < 16; kk++) ws_d.fb[kk] = ws.fb[0];
     // (a slice per block leaves four blocks per CU: 1024 threads each keep the SIMDs full, 256 left them at four waves)
     const uint32_t threads = bin_split ? 1024u : 256u;
     if (te)
       hipLaunchKernelGGL(te::k_te_digits, dim3(grid), dim3(threads), lds, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K,
-                         k_lo, kc, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, pack_fine_bits(ws));
+                         k_lo, kc_d, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, pack_fine_bits(ws_d));
     else
-      W_LAUNCH(ctx, k_digits, dim3(grid), dim3(threads), lds, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K, k_lo, kc,
-                         (pl.no_glv ? 0 : 1) | (pl.fold ? 2 : 0), pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, pack_fine_bits(ws));
+      W_LAUNCH(ctx, k_digits, dim3(grid), dim3(threads), lds, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K, k_lo, kc_d,
+                         (pl.no_glv ? 0 : 1) | (pl.fold ? 2 : 0), pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, pack_fine_bits(ws_d));
   }
   HIPCHK(hipEventRecord(w.ev[1], s));
   if (!bin_split) {
@@ -146,11 +159,13 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     uint32_t* d_bin_tot = (uint32_t*)w.part.p;
     d_bin_start = d_bin_tot + V;
     ctx->ensure(w.rec, n_entries * 8);
-    hipLaunchKernelGGL(k_colscan, dim3((V + 255) / 256), dim3(256), 0, s, (uint32_t*)w.block_hist.p, d_bin_tot, sortB, hb,
-                       (uint32_t)kc);
+    // (on tables the slices of all kc_d digit windows are the slices of the one merged window, in the same row order)
+    hipLaunchKernelGGL(k_colscan, dim3((V + 255) / 256), dim3(256), 0, s, (uint32_t*)w.block_hist.p, d_bin_tot,
+                       pl.tables ? sortB * (uint32_t)kc_d : sortB, hb, (uint32_t)kc);
     hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_bin_start, (const uint32_t*)d_bin_tot, V);
-    hipLaunchKernelGGL(k_bin_split, dim3(sortB, kc), dim3(BS_THREADS), bin_split_lds(hb), s, (uint2*)w.rec.p,
-                       (const uint32_t*)d_bin_start, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n, chunk, hb, ws);
+    hipLaunchKernelGGL(k_bin_split, dim3(sortB, kc_d), dim3(BS_THREADS), bin_split_lds(hb), s, (uint2*)w.rec.p,
+                       (const uint32_t*)d_bin_start, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n_d, chunk, hb, ws,
+                       pl.tables ? 1u : 0u);
     HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));
     hipLaunchKernelGGL(k_bin_count, dim3(V), dim3(256), (size_t)nbmax * 4, s, (uint32_t*)w.counts.p, (const uint32_t*)d_bin_start,
                        (const uint2*)w.rec.p, hb, L, ws);
@@ -194,7 +209,8 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   {
     long long chunk_rows_log = 22;   // 2^22 rows of 256 bytes = 1 GB
     MSM_KNOB(chunk_rows_log, "MSM_CHUNK_LOG", 10);
-    long long want_chunks = (bin_split && !te && pl.c >= 18 && n > (1ull << chunk_rows_log)) ? 1 : 0;
+    const uint64_t table_rows = pl.tables ? (uint64_t)kc_d * n : n;
+    long long want_chunks = (bin_split && !te && pl.c >= 18 && table_rows > (1ull << chunk_rows_log)) ? 1 : 0;
     MSM_KNOB(want_chunks, "MSM_CHUNKED", 0);
     // (round 2 must be an index-free round to read the element records round 1 then writes: logG >= 2)
     chunked = bin_split && want_chunks && !te && logG >= 2 && total_slots >= 2;

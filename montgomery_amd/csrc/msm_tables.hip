@@ -1,0 +1,133 @@
+// Window tables: K resident tables of the point set, table k = 2^(c k) P, so that the K windows of an MSM share one set of
+// buckets (k_table_next, msm_kernels.h).  The reference has no counterpart (4 GiB of wasm memory); it is what 288 GB of HBM are
+// for: six tables of 2^26 points are 103 GB.  Built once per point set and plan -- by the first default-plan msm_run over the
+// whole set, or ahead of it by msm_precompute / msm_reserve -- the way k_points_from_wire precomputes beta x once per set.
+#include "msm_internal.h"
+
+using namespace msm;
+using namespace msmi;
+
+namespace msmi {
+
+static uint64_t table_bytes(const msm_ctx* ctx, uint64_t n, int K) {
+  const uint64_t row_words = ctx->is_te() ? (uint64_t)te::TE_ROW_WORDS : (uint64_t)ROW_WORDS;
+  return (uint64_t)K * std::max<uint64_t>(n, 1) * row_words * 4;
+}
+
+static void build_tables(msm_ctx* ctx, const Plan& pl) {
+  const uint64_t n = ctx->n_points;
+  const uint64_t row_words = ctx->is_te() ? (uint64_t)te::TE_ROW_WORDS : (uint64_t)ROW_WORDS;
+  const uint64_t bytes = table_bytes(ctx, n, pl.K);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->rows.cap < bytes) {
+    // a bigger buffer: table 0 (the plain rows) moves over, the old buffer goes back
+    DevBuf big;
+    ctx->ensure(big, bytes);
+    HIPCHK(hipMemcpyAsync(big.p, ctx->rows.p, n * row_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->release(ctx->rows);
+    ctx->rows = big;
+  }
+  uint32_t* rows = (uint32_t*)ctx->rows.p;
+  const uint32_t grid = (uint32_t)((n + 255) / 256);
+  for (int k = 1; k < pl.K; k++) {
+    uint32_t* out = rows + (uint64_t)k * n * row_words;
+    const uint32_t* in = rows + (uint64_t)(k - 1) * n * row_words;
+    if (ctx->is_te()) hipLaunchKernelGGL(te::k_te_table_next, dim3(grid), dim3(256), 0, ctx->stream, out, in, n, pl.c);
+    else W_LAUNCH(ctx, k_table_next, dim3(grid), dim3(256), 0, ctx->stream, out, in, n, pl.c);
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  ctx->tab_c = pl.c;
+  ctx->tab_K = pl.K;
+}
+
+// can this call run on window tables at all?
+static bool tables_eligible(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, bool placed) {
+  if (placed || (opts && (opts->no_tables || opts->point_lo))) return false;
+  if (!ctx->children.empty()) return false;           // a device list shards by points or windows over plain rows
+  return n == ctx->n_points && n >= 4096;
+}
+
+// A short top window would pile its entries on the lowest buckets of the merged window (a 2-bit top window: an eighth of all
+// entries in four buckets): tables are built by default only for plans whose top window is about as wide as the others.
+static bool plan_suits_tables(const Plan& pl) {
+  if (pl.K < 2) return false;
+  const int top_bits = pl.fold ? pl.c + 1 : pl.bits - (pl.K - 1) * pl.c;
+  return top_bits >= pl.c - 3;
+}
+
+int make_run_plan(msm_ctx* ctx, uint64_t n, const msm_opts* opts, bool placed, Plan& pl, bool& tables_wanted) {
+  tables_wanted = false;
+  if (tables_eligible(ctx, n, opts, placed)) {
+    // tables that exist decide: the call uses them if its plan is theirs (an explicit c, or the default plan they were built for)
+    if (ctx->tab_K) {
+      Plan pt;
+      msm_opts o;
+      if (opts) o = *opts; else memset(&o, 0, sizeof o);
+      if (!o.c) o.c = ctx->tab_c;
+      if (make_plan(ctx, n, &o, pt) == MSM_OK && pt.c == ctx->tab_c && pt.K == ctx->tab_K &&
+          (!(opts && opts->c) || opts->c == ctx->tab_c)) {
+        // (a default-plan call keeps using tables built by msm_precompute for another c only if that is also what it would pick)
+        Plan pd;
+        if ((opts && opts->c) || (make_plan(ctx, n, opts, pd, true) == MSM_OK && pd.c == ctx->tab_c)) {
+          pl = pt;
+          tables_wanted = true;
+          return MSM_OK;
+        }
+      }
+    }
+    // none yet (or others): a default-plan call on an endomorphism curve may build them if they fit the limit
+    if (!(opts && opts->c) && !(opts && opts->no_glv) && !ctx->is_te()) {
+      Plan pt;
+      if (make_plan(ctx, n, opts, pt, true) == MSM_OK && plan_suits_tables(pt) && table_bytes(ctx, n, pt.K) <= ctx->tables_limit) {
+        pl = pt;
+        tables_wanted = true;
+        return MSM_OK;
+      }
+    }
+  }
+  return make_plan(ctx, n, opts, pl);
+}
+
+bool use_window_tables(msm_ctx* ctx, uint64_t n, const msm_opts* opts, const Plan& pl, bool may_build) {
+  if (!tables_eligible(ctx, n, opts, false) || pl.K < 2) return false;
+  if (ctx->tab_c == pl.c && ctx->tab_K == pl.K) return true;
+  if (!may_build || table_bytes(ctx, n, pl.K) > ctx->tables_limit) return false;
+  build_tables(ctx, pl);
+  return true;
+}
+
+}  // namespace msmi
+
+extern "C" {
+
+int msm_precompute(msm_ctx* ctx, uint64_t n, const msm_opts* opts) {
+  if (!ctx) return MSM_ERR_ARG;
+  if (n != ctx->n_points) return fail(ctx, MSM_ERR_ARG, "msm_precompute: window tables cover the whole point set (%llu points resident)",
+                                      (unsigned long long)ctx->n_points);
+  Plan pl;
+  if (make_plan(ctx, n, opts, pl, /*for_tables=*/true)) return fail(ctx, MSM_ERR_ARG, "msm_precompute: bad window size");
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    (void)use_window_tables(ctx, n, opts, pl, /*may_build=*/true);   // not an error if they do not fit: the plain path stays
+    return MSM_OK;
+  } MSM_CATCH_ALL(ctx)
+}
+
+int msm_tables_info(const msm_ctx* ctx, int32_t* c_out, int32_t* K_out, uint64_t* bytes_out) {
+  if (!ctx) return MSM_ERR_ARG;
+  if (c_out) *c_out = ctx->tab_c;
+  if (K_out) *K_out = ctx->tab_K;
+  if (bytes_out) *bytes_out = ctx->tab_K ? table_bytes(ctx, ctx->n_points, ctx->tab_K) : 0;
+  return MSM_OK;
+}
+
+int msm_set_tables_limit(msm_ctx* ctx, uint64_t bytes) {
+  if (!ctx) return MSM_ERR_ARG;
+  ctx->tables_limit = bytes;
+  for (msm_ctx* c : ctx->children) c->tables_limit = bytes;
+  return MSM_OK;
+}
+
+}  // extern "C"

@@ -9,7 +9,7 @@ using namespace msmi;
 namespace msmi {
 
 // queues the tree on w.stream behind whatever is there; records w.ev[6] behind round 1 and w.ev[3] behind the last kernel
-void accumulate_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const Plan& pl, int kc, uint64_t p_lo, const SortOut& so,
+void accumulate_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const Plan& pl, int kc, uint64_t row_off, const SortOut& so,
                              GroupStats& st, TreeOut& to) {
   hipStream_t s = w.stream;
   const bool lone = pl.lone;
@@ -86,7 +86,7 @@ void accumulate_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const Plan& pl
       const uint64_t sstride = g.T + scratch_pad;
       if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * sstride * 4);
       BatchArgs a{};
-      a.points = (const uint32_t*)ctx->rows.p + p_lo * (te ? (uint64_t)te::TE_ROW_WORDS : (uint64_t)ROW_WORDS);
+      a.points = (const uint32_t*)ctx->rows.p + row_off * (te ? (uint64_t)te::TE_ROW_WORDS : (uint64_t)ROW_WORDS);
       a.slots = r == 1 ? round1_slots : (const uint32_t*)w.slots.p;
       a.dest = r == 1 ? round1_dest : nullptr;
       a.in = buf[cur ^ 1];

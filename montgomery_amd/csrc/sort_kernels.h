@@ -589,8 +589,11 @@ inline size_t bin_split_lds(uint32_t hb) { return (size_t)BS_TILE * 8 + (size_t)
 
 // pass A.  grid (SB, kc); block (b, kk) owns entries [b * chunk, (b + 1) * chunk) of window kk.  Coarse bin h of window kk
 // starts at bin_start[kk * hb + h]; this slice's share of it slice_off[(kk * SB + b) * hb + h] further.
+// merged (window tables: the kc digit windows of the group are ONE window of kc * two_n entries for the sort): every block
+// works for window 0, its slice is number kk * SB + b of that window, and entry indices count from the group's first digit.
 __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint32_t* bin_start, const uint32_t* slice_off,
-                                                          const uint32_t* dig, uint64_t two_n, uint64_t chunk, uint32_t hb, WinSplit ws)
+                                                          const uint32_t* dig, uint64_t two_n, uint64_t chunk, uint32_t hb, WinSplit ws,
+                                                          uint32_t merged)
 #ifndef MSM_SORT_TU
     ;
 #else
@@ -601,12 +604,14 @@ __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint
   uint32_t* t_start = t_cnt + hb;
   uint32_t* g_base = t_start + hb;
   uint32_t* lds_wave = g_base + hb;                       // 64 words
-  const uint32_t b = blockIdx.x, kk = blockIdx.y, SB = gridDim.x, tid = threadIdx.x;
+  const uint32_t b = blockIdx.x, seg = blockIdx.y, SB = gridDim.x, tid = threadIdx.x;
+  const uint32_t kk = merged ? 0u : seg;
   const uint32_t ab = ws.ab[kk], fb = ws.fb[kk], HN = 1u << ab;
   for (uint32_t h = tid; h < HN; h += BS_THREADS)
-    g_base[h] = bin_start[(uint64_t)kk * hb + h] + slice_off[((uint64_t)kk * SB + b) * hb + h];
+    g_base[h] = bin_start[(uint64_t)kk * hb + h] + slice_off[((uint64_t)seg * SB + b) * hb + h];
   const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
-  const uint32_t* d = dig + (uint64_t)kk * two_n;
+  const uint32_t* d = dig + (uint64_t)seg * two_n;
+  const uint32_t e_base = merged ? (uint32_t)((uint64_t)seg * two_n) : 0u;
   const uint32_t fmask = (1u << fb) - 1;
   uint32_t v[BS_ITEMS], nv[BS_ITEMS];
   auto load_tile = [&](uint32_t (&dst)[BS_ITEMS], uint64_t t0) {
@@ -642,7 +647,7 @@ __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint
         const uint32_t h = (l - 1) >> fb;
         // record: fine bits + 1 (<= 2^12; 0 never occurs) | coarse bin << 16 (stripped on the way out) | sign << 31
         stage[t_start[h] + rk[i]] = make_uint2((((l - 1) & fmask) + 1) | (h << 16) | (v[i] & 0x80000000u),
-                                               (uint32_t)(t0 + (uint64_t)i * BS_THREADS + tid));
+                                               e_base + (uint32_t)(t0 + (uint64_t)i * BS_THREADS + tid));
       }
     }
     __syncthreads();

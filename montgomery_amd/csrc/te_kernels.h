@@ -219,6 +219,50 @@ __global__ void __launch_bounds__(256) k_te_points_from_wire(uint32_t* rows, con
 #endif
 
 // ---------------------------------------------------------------------------------------------
+// k_te_table_next: window tables of the Edwards path (see k_table_next, msm_kernels.h): row i of table k = 2^(c k) P_i as
+// [x | y | xy | 2d xy]; c unified additions P + P (complete on this curve) and one inversion per point
+// ---------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_te_table_next(uint32_t* rows_out, const uint32_t* rows_in, uint64_t n, int c)
+#ifndef MSM_TE_TU
+    ;
+#else
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* row = rows_in + i * TE_ROW_WORDS;
+  uint32_t w[TW];
+  Ext P;
+  load_words8(w, row);      fe_unpack<FT>(P.X, w);
+  load_words8(w, row + 8);  fe_unpack<FT>(P.Y, w);
+  load_words8(w, row + 16); fe_unpack<FT>(P.T, w);
+  fe_set_one<FT>(P.Z);
+#pragma unroll 1
+  for (int j = 0; j < c; j++) {
+    Ext Q = P;
+    te_add(P, Q, Q);
+  }
+  Fe<FT> zi, x, y, t, kt, k;
+  fe_reduce_4p<FT>(P.Z);
+  fe_inv<FT>(zi, P.Z);   // Z != 0 for every point of a complete Edwards curve
+  fe_mul<FT>(x, P.X, zi);
+  fe_mul<FT>(y, P.Y, zi);
+  fe_mul<FT>(t, x, y);
+  TE_CONST(k, K2DL);
+  fe_mul<FT>(kt, t, k);
+  fe_reduce_2p<FT>(x);
+  fe_reduce_2p<FT>(y);
+  fe_reduce_2p<FT>(t);
+  fe_reduce_2p<FT>(kt);
+  uint32_t* out = rows_out + i * TE_ROW_WORDS;
+  fe_store<FT>(out, x);
+  fe_store<FT>(out + 8, y);
+  fe_store<FT>(out + 16, t);
+  fe_store<FT>(out + 24, kt);
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // k_te_digits: signed window digits of full-width scalars (no GLV), src/msm-basic.ts:72-91
 // ---------------------------------------------------------------------------------------------
 

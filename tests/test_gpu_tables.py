@@ -1,0 +1,124 @@
+"""Window tables (msm_precompute, include/msm_hip.h): K resident tables 2^(c k) P of a point set, all windows of an MSM in ONE set
+of buckets.  The result is a group element, so every run on tables must equal the plain path, the oracle and the golden vectors
+bit for bit.  Needs an MI355X: `-m gpu`."""
+import json
+import os
+
+import pytest
+
+from oracle import msm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+C = O.BLS12_377
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_golden_4096_points_on_tables(gpu_ctx):
+    """tests/golden/msm377_4096.json: the first default-plan call over the whole set builds the tables and runs on them."""
+    gold = json.load(open(os.path.join(GOLD, "msm377_4096.json")))
+    n = gold["n"]
+    pts, _ = O.random_points_bls377(gold["seed_points"], n)
+    sc = O.prng_ints(gold["seed_scalars"], n, C.q)
+    gpu_ctx.set_points(O.points_to_bytes(pts, 48), check_curve=True)
+    assert gpu_ctx.tables_info() == (0, 0, 0)
+    sb = O.scalars_to_bytes(sc)
+    res, info = gpu_ctx.run(sb)
+    assert info["tables"] and gpu_ctx.tables_info()[:2] == (info["c"], info["K"])
+    assert res.as_tuple() == (int(gold["result"][0], 16), int(gold["result"][1], 16))
+    plain, pinfo = gpu_ctx.run(sb, no_tables=True)
+    assert not pinfo["tables"] and plain.as_tuple() == res.as_tuple()
+    # a prefix of the points, or another window size, takes the plain path over table 0 -- which is still the plain row table
+    part, i2 = gpu_ctx.run(sb[: 32 * 1000])
+    assert not i2["tables"] and part.as_tuple() == O.msm_batched_affine(sc[:1000], pts[:1000], c=i2["c"])
+    other, i3 = gpu_ctx.run(sb, c=13)
+    assert not i3["tables"] and other.as_tuple() == res.as_tuple()
+    # new points drop the tables
+    gpu_ctx.set_points(O.points_to_bytes(pts[:64], 48))
+    assert gpu_ctx.tables_info() == (0, 0, 0)
+
+
+@pytest.mark.parametrize("lg", [13, 16, 20])
+def test_tables_against_known_discrete_logs(gpu_ctx, c_oracle, lg):
+    n = 1 << lg
+    a = gpu_ctx.generate_points(n, seed=5000 + lg, want_scalars=True, raw=True)
+    dev, s = gpu_ctx.generate_scalars(n, seed=6000 + lg, to_host=True, raw=True)
+    exp = O.aff_scale(c_oracle.dot_mod(a, s, n, C.q), (C.gx, C.gy), C.p)
+    res, info = gpu_ctx.run_device(dev, n)
+    assert info["tables"] and (info["c"], info["K"]) == gpu_ctx.plan(n), info
+    assert res.as_tuple() == exp
+    plain, pinfo = gpu_ctx.run_device(dev, n, no_tables=True)
+    assert not pinfo["tables"] and plain.as_tuple() == exp
+    ser, _ = gpu_ctx.run_device(dev, n, serial=True)
+    assert ser.as_tuple() == exp
+
+
+def test_explicit_window_sizes_and_degenerate_scalars(gpu_ctx):
+    """msm_precompute for an explicit c (folded 18- and 21-bit plans, the 16-bit one, a plan with a short top window); constant
+    scalars put all entries of a window group into one or two buckets of the merged window."""
+    n = 1 << 13
+    gpu_ctx.generate_points(n, seed=77)
+    dev, sb = gpu_ctx.generate_scalars(n, seed=78, to_host=True)
+    want, _ = gpu_ctx.run_device(dev, n, no_tables=True)
+    for c in (16, 18, 21, 13, 19):
+        cc, K, nbytes = gpu_ctx.precompute(n, c=c)
+        assert cc == c and nbytes == K * n * 256
+        got, info = gpu_ctx.run_device(dev, n, c=c)
+        assert info["tables"] and info["K"] == K and got.as_tuple() == want.as_tuple(), (c, info)
+        for val in (C.q - 1, 1, (1 << 252) - 1, 0):
+            const = O.scalars_to_bytes([val] * n)
+            a, ia = gpu_ctx.run(const, c=c)
+            b, ib = gpu_ctx.run(const, c=c, no_tables=True)
+            assert ia["tables"] and not ib["tables"] and a.as_tuple() == b.as_tuple(), (c, hex(val))
+    # the default call keeps the plain path while tables of another plan are resident ... unless they are the default's
+    d, info = gpu_ctx.run_device(dev, n)
+    assert d.as_tuple() == want.as_tuple()
+
+
+def test_limit_reserve_and_point_sets(gpu_ctx):
+    n = 1 << 12
+    gpu_ctx.generate_points(n, seed=31)
+    dev, _ = gpu_ctx.generate_scalars(n, seed=32)
+    gpu_ctx.set_tables_limit(0)
+    try:
+        r0, i0 = gpu_ctx.run_device(dev, n)
+        assert not i0["tables"] and gpu_ctx.tables_info() == (0, 0, 0)
+    finally:
+        gpu_ctx.set_tables_limit(28 << 30)
+    gpu_ctx.reserve(n)                      # msm_reserve: workspace AND tables exist before the first real call
+    c, K, nbytes = gpu_ctx.tables_info()
+    assert K >= 2 and nbytes == K * n * 256
+    r1, i1 = gpu_ctx.run_device(dev, n)
+    assert i1["tables"] and r1.as_tuple() == r0.as_tuple()
+    # tables travel with their point set
+    other = gpu_ctx.pointset_create()
+    gpu_ctx.generate_points(n, seed=33)
+    assert gpu_ctx.tables_info() == (0, 0, 0)
+    r2, i2 = gpu_ctx.run_device(dev, n)
+    assert i2["tables"] and r2.as_tuple() != r1.as_tuple()
+    gpu_ctx.pointset_select(0)
+    assert gpu_ctx.tables_info() == (c, K, nbytes)
+    assert gpu_ctx.run_device(dev, n)[0].as_tuple() == r1.as_tuple()
+    gpu_ctx.pointset_select(other)
+    assert gpu_ctx.run_device(dev, n)[0].as_tuple() == r2.as_tuple()
+    gpu_ctx.pointset_destroy(other)
+
+
+def test_edwards_and_other_curves_on_tables():
+    """The Edwards path builds tables only when asked to (msm_precompute); BLS12-381 and Pallas by default."""
+    from montgomery_amd import _lib
+    from montgomery_amd.api import MsmContext
+
+    for curve, te in ((_lib.CURVE_ED_ON_BLS12_377, True), (_lib.CURVE_BLS12_381_G1, False), (_lib.CURVE_PALLAS, False)):
+        ctx = MsmContext(curve)
+        n = 1 << 14
+        ctx.generate_points(n, seed=11)
+        dev, _ = ctx.generate_scalars(n, seed=12)
+        plain, ip = ctx.run_device(dev, n, no_tables=True)
+        if te:
+            assert not ctx.run_device(dev, n)[1]["tables"]
+            ctx.precompute()
+        got, it = ctx.run_device(dev, n)
+        key = (lambda r: (r.x, r.y)) if te else (lambda r: r.as_tuple())
+        assert it["tables"] and not ip["tables"] and key(got) == key(plain), curve
+        ctx.close()

@@ -2,7 +2,7 @@
 # quick GPU check of a work-in-progress build: parity tests, then a short headline run
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-timeout 900 python3 -m pytest tests -m gpu -x -q > gpurun_out/try_pytest.log 2>&1; echo "pytest rc=$?" 
+timeout 1200 python3 -m pytest tests -m gpu -q ${PYTEST_ARGS} > gpurun_out/try_pytest.log 2>&1; echo "pytest rc=$?"
 tail -15 gpurun_out/try_pytest.log
 timeout 600 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs ${BENCH_ARGS} > gpurun_out/try_bench.json 2> gpurun_out/try_bench.err; echo "bench rc=$?"
 tail -3 gpurun_out/try_bench.err
