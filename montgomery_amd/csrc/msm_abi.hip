@@ -244,21 +244,82 @@ int msm_combine_curve(int curve, const uint8_t* partials, int32_t K, int32_t c, 
   return msm_combine_groups(curve, partials, 1, K, c, out);
 }
 
+// msm_run over HOST scalars of a big input: the scalars cross PCIe behind the computation (PieceUpload, msm_upload.hip).  The
+// sort of a window needs every digit of its range, so the unit of overlap is a range of the points: the call runs as whole
+// MSMs over 1/16, 3/16 and the rest of the points (1/8, 3/8, rest below 2^25) as their scalars arrive -- each with the
+// window the library picks for ITS size (round 4 ran all ranges under one window picked for an eighth of the input: the last,
+// biggest range then missed the 21-bit plan) -- and adds the three results.  The link moves scalars ~4x as fast as the GPU
+// consumes them, so every range may be ~4x its predecessor and still be there in time.
+// (the reference's counterpart: scalarsFromBytes into shared wasm memory before the call, src/parallel.ts:119-133)
+static int run_piped(msm_ctx* ctx, const void* scalars, uint64_t n, const msm_opts* opts, msm_result* out, const char* who) {
+  memset(out, 0, sizeof(*out));
+  try {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipEventRecord(ctx->ev[8], ctx->stream));
+    const uint64_t gran = msm_ctx::STAGE_CHUNK / 32;   // scalars per staging chunk
+    const int big = n >= (1ull << 25);
+    std::vector<uint64_t> piece_end;
+    std::vector<int> shifts = {big ? 4 : 3, big ? 2 : 1};
+#ifdef MSM_TUNING
+    if (const char* e = getenv("MSM_PIPE_SH")) {   // experiment: "5,3,1" = ranges ending at n/32, n/8, n/2, n
+      shifts.clear();
+      for (const char* q = e; *q;) { shifts.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; }
+    }
+#endif
+    for (int sh : shifts) piece_end.push_back(((n >> sh) / gran) * gran);
+    piece_end.push_back(n);
+    ctx->ensure(ctx->scal, n * 32);   // before any workspace is sized from what the device has free
+    std::vector<size_t> ends;
+    for (uint64_t e : piece_end) ends.push_back((size_t)e * 32);
+    PieceUpload pipe(ctx, ctx->scal.p, scalars, n * 32, ends);
+    const uint32_t base_lo = opts ? opts->point_lo : 0;
+    msm_host::Proj6 acc = ctx->hc.zero();
+    uint64_t lo = 0;
+    for (size_t q = 0; q < piece_end.size(); q++) {
+      const uint64_t cnt = piece_end[q] - lo;
+      if (cnt == 0) continue;
+      pipe.wait_piece((int)q, ctx->stream);
+      HIPCHK(hipStreamSynchronize(ctx->stream));       // the range's scalars are in HBM
+      msm_opts o;
+      if (opts) o = *opts; else memset(&o, 0, sizeof o);
+      o.point_lo = base_lo + (uint32_t)lo;
+      Plan pq;
+      if (make_plan(ctx, cnt, &o, pq)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);
+      pq.merged = true;
+      std::vector<uint32_t> words;
+      msm_result st;
+      memset(&st, 0, sizeof st);
+      window_sums_impl(ctx, (const uint32_t*)ctx->scal.p + lo * 8, cnt, 1, &o, 0, pq.K, pq, words, &st, o.point_lo);
+      std::vector<msm_host::Proj6> P(pq.K);
+      for (int k = 0; k < pq.K; k++) P[k] = partial_to_host(ctx, &words[(size_t)k * 36]);
+      acc = ctx->hc.add(acc, horner_points(ctx->hc, P, pq.c));
+      for (int j = 0; j < MSM_N_PHASES; j++) out->phase_ms[j] += st.phase_ms[j];
+      out->n_pairs += st.n_pairs;
+      out->n_pairs_algo += st.n_pairs_algo;
+      out->rounds += st.rounds;
+      out->max_bucket = std::max(out->max_bucket, st.max_bucket);
+      out->c = pq.c;   // the plan of the last, biggest range
+      out->K = pq.K;
+      lo = piece_end[q];
+    }
+    out->phase_ms[MSM_T_UPLOAD] = pipe.finish();   // wall time of the background transfer
+    proj_to_result(ctx->hc, acc, out);
+    HIPCHK(hipEventRecord(ctx->ev[11], ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[11]));
+    out->phase_ms[MSM_T_TOTAL] = ms;
+  } MSM_CATCH_ALL(ctx)
+  return MSM_OK;
+}
+
 static int run_impl(msm_ctx* ctx, const void* scalars, const void* const* placed, uint64_t n, int on_device, const msm_opts* opts,
                     msm_result* out, const char* who) {
   if ((opts ? opts->point_lo : 0) + n > ctx->n_points)
     return fail(ctx, MSM_ERR_NO_POINTS, "%s: points [%llu, +%llu) but %llu resident points", who,
                 (unsigned long long)(opts ? opts->point_lo : 0), (unsigned long long)n, (unsigned long long)ctx->n_points);
-  // Host scalars of a big call arrive range by range of the points (PieceUpload) and every range runs with the call's window:
-  // the first ranges are a sixteenth and three sixteenths of the input, so the window is picked for an eighth of the input
-  // rather than for all of it (2^26: c = 16 for every range 164.8 ms, c = 22 180.6 -- a 2^22-point range under 2^21 buckets
-  // per window)
-  msm_opts piped;
-  if (!placed && !on_device && n >= (1ull << 24) && !(opts && opts->c) && !ctx->is_te()) {
-    if (opts) piped = *opts; else memset(&piped, 0, sizeof piped);
-    piped.c = pick_window(false, n / 8, (opts && opts->no_glv) ? 0 : curve_info(ctx->curve).glv_max_bits);
-    opts = &piped;
-  }
+  if (!placed && !on_device && n >= (1ull << 24) && ctx->children.empty() && !ctx->is_te() && !(opts && opts->c))
+    return run_piped(ctx, scalars, n, opts, out, who);
   Plan pl;
   bool tables_wanted = false;   // window tables (msm_tables.hip): the plan is then the one tables want
   if (make_run_plan(ctx, n, opts, placed != nullptr, pl, tables_wanted)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);

@@ -210,7 +210,7 @@ struct msm_ctx {
   bool staging_ready = false;      // pinned slots, copy streams and events all exist (ensure_staging)
   hipStream_t stage_stream[STAGE_THREADS] = {};
   hipEvent_t stage_ev[STAGE_THREADS][STAGE_SLOTS + 1] = {};
-  static constexpr int MAX_PIECES = 4;   // ranges of the points a host-scalar MSM is pipelined over (PieceUpload)
+  static constexpr int MAX_PIECES = 6;   // ranges of the points a host-scalar MSM is pipelined over (PieceUpload)
   hipEvent_t piece_ev[MAX_PIECES][STAGE_THREADS] = {};
   uint64_t ws_budget = 0;          // bytes the per-group workspaces may take in total
   uint64_t ws_limit = 0;           // msm_set_workspace_limit: the caller's cap on ws_budget (0 = automatic)
@@ -347,6 +347,8 @@ msm_host::Proj6 partial_to_host(const msm_ctx* ctx, const uint32_t* w);
 void host_to_partial(const msm_ctx*, const msm_host::Proj6& P, uint32_t* out36);
 void reduce_buckets(msm_ctx* ctx, msm_ctx::Workspace& w, const uint4* fin, uint64_t fin_cap, const uint32_t* off_fin,
                     const uint32_t* bucket_proj, uint32_t L, int kc, uint32_t* h_partials_out, bool merged = false, int stride = 0);
+msm_host::Proj6 horner_points(const msm_host::Curve6& C, const std::vector<msm_host::Proj6>& P, int c);
+void proj_to_result(const msm_host::Curve6& C, const msm_host::Proj6& acc, msm_result* out);
 void horner_to_affine(const msm_host::Curve6& C, const std::vector<msm_host::Proj6>& P, int c, msm_result* out);
 void te_horner_points(const msm_host::TeCurve6& C, const std::vector<msm_host::Ext6>& P, int c, msm_result* out);
 msm_host::Ext6 te_partial_to_host(const msm_ctx* ctx, const uint32_t* w);

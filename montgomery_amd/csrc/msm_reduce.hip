@@ -185,14 +185,19 @@ void plane_element_to_wire(const msm_ctx* ctx, const uint32_t* planes, uint64_t 
   }
 }
 
-// S = sum_k 2^(ck) P_k, then affine (src/msm-batched-affine.ts:322-333, src/curve-projective.ts:335-349)
-void horner_to_affine(const msm_host::Curve6& C, const std::vector<msm_host::Proj6>& P, int c, msm_result* out) {
+// S = sum_k 2^(ck) P_k (src/msm-batched-affine.ts:322-333)
+msm_host::Proj6 horner_points(const msm_host::Curve6& C, const std::vector<msm_host::Proj6>& P, int c) {
   int K = (int)P.size();
   msm_host::Proj6 acc = P[K - 1];
   for (int k = K - 2; k >= 0; k--) {
     for (int j = 0; j < c; j++) acc = C.dbl(acc);
     acc = C.add(acc, P[k]);
   }
+  return acc;
+}
+
+// projective -> the canonical affine result (src/curve-projective.ts:335-349)
+void proj_to_result(const msm_host::Curve6& C, const msm_host::Proj6& acc, msm_result* out) {
   memset(out->x, 0, 48);
   memset(out->y, 0, 48);
   if (C.is_zero(acc)) {
@@ -208,6 +213,10 @@ void horner_to_affine(const msm_host::Curve6& C, const std::vector<msm_host::Pro
   C.F.mul(y, y, one);
   fe6_to_bytes(out->x, x);
   fe6_to_bytes(out->y, y);
+}
+
+void horner_to_affine(const msm_host::Curve6& C, const std::vector<msm_host::Proj6>& P, int c, msm_result* out) {
+  proj_to_result(C, horner_points(C, P, c), out);
 }
 
 // twisted Edwards tail: S = sum_k 2^(ck) P_k with unified additions (src/msm-basic.ts:142-158), then x = X/Z, y = Y/Z
