@@ -344,7 +344,8 @@ def main():
         torch.cuda.set_device(0)
 
     from montgomery_amd.api import AffineResult, MsmContext
-    from montgomery_amd.distributed import choose_split, choose_window, point_shards, sharded_msm, sharded_msm_points, window_shards
+    from montgomery_amd.distributed import (choose_split, choose_window, point_shards, sharded_msm, sharded_msm_buckets, sharded_msm_points,
+                                            window_shards)
 
     n = 1 << args.log2n
     if args.curve == "ed377":
@@ -364,7 +365,7 @@ def main():
         of the points, the window split wants K divisible by the rank count; --c overrides both"""
         if args.c or not sharded:
             return ctx.plan(n, args.c or None)
-        return choose_window(lambda m, cc: ctx.plan(m, cc), n, world, how)
+        return choose_window(lambda m, cc: ctx.plan(m, cc, no_tables=True), n, world, how)
 
     if sharded:
         c, K = plan_for(split)
@@ -400,9 +401,15 @@ def main():
                                                  point_lo=first)
             return parts
 
+        def my_bucket_sums(r, w):   # all K windows over all points, this rank's range of every window's buckets
+            parts, box["info"] = ctx.window_sums(scal[i % n_sets].data_ptr(), n, 0, K, c=c, on_device=True, bucket_shard=(r, w))
+            return parts
+
         tm = {}
         if how == "points":
             out = sharded_msm_points(my_point_sums, n, K, c, device=ddev, curve=ctx.curve, timing=tm, exchange=exchange)
+        elif how == "buckets":
+            out = sharded_msm_buckets(my_bucket_sums, K, c, device=ddev, curve=ctx.curve, timing=tm, exchange=exchange)
         else:
             out = sharded_msm(my_window_sums, K, c, device=ddev, curve=ctx.curve, timing=tm, exchange=exchange)
         if box.get("info") is not None:
@@ -445,7 +452,7 @@ def main():
             dt = float(tmax.item())
             # outside the timed region: what every rank spent where, so that a scaling run explains itself
             mine = [x for x in infos if x]
-            summary = {"rank": rank, "shard": (list(point_shards(n, world)[rank]) if how == "points" else list(shards[rank])),
+            summary = {"rank": rank, "shard": (list(point_shards(n, world)[rank]) if how == "points" else [rank, world] if how == "buckets" else list(shards[rank])),
                        "steps_with_work": len(mine)}
             if mine:
                 summary["phase_ms"] = {k: sum(x["phase_ms"][k] for x in mine) / len(mine) for k in mine[0]["phase_ms"]}
@@ -467,13 +474,14 @@ def main():
     dt, step_ms, infos, last, last_set, ranks_info = timed_loop(split, c, K)
     other_splits = None
     if sharded and not args.no_other_splits:
-        other = "points" if split == "windows" else "windows"
-        o_c, o_K = plan_for(other)
-        o_dt, o_step_ms, _, o_last, o_set, o_ranks = timed_loop(other, o_c, o_K)
-        if rank == 0:
-            other_splits = [{"split": other, "window_bits": o_c, "windows": o_K,
-                             "value": n * args.steps / o_dt, "unit": "points/s", "ms_per_step": o_dt / args.steps * 1e3,
-                             **step_stats(o_step_ms), "verified": check(o_last, o_set) if verify else None, "ranks": o_ranks}]
+        other_splits = []
+        for other in [x for x in ("windows", "points", "buckets") if x != split]:
+            o_c, o_K = plan_for(other)
+            o_dt, o_step_ms, _, o_last, o_set, o_ranks = timed_loop(other, o_c, o_K)
+            if rank == 0:
+                other_splits.append({"split": other, "window_bits": o_c, "windows": o_K,
+                                     "value": n * args.steps / o_dt, "unit": "points/s", "ms_per_step": o_dt / args.steps * 1e3,
+                                     **step_stats(o_step_ms), "verified": check(o_last, o_set) if verify else None, "ranks": o_ranks})
 
     if rank == 0:
         infos = [x for x in infos if x]
@@ -576,6 +584,8 @@ def main():
                 "windows": K,
                 "parallelism": "single-gpu" if not sharded else (
                     f"window-shard x{world}, one RCCL all-gather of {K}x144 B" if split == "windows" else
+                    f"bucket-shard x{world} (all {K} windows on 1/{world} of every window's buckets per rank), one RCCL all-gather of {K}x144 B per rank"
+                    if split == "buckets" else
                     f"points-shard x{world} (all {K} windows on n/{world} points per rank), one RCCL all-gather of {K}x144 B per rank"),
                 "points": "P_i = a_i*G generated on GPU (resident)",
                 "scalars": f"uniform < q, fresh per step ({n_sets} distinct sets cycled), resident in HBM before the timed region",

@@ -52,7 +52,7 @@ enum {
  * LIBRARY was built with, msm_abi_struct_bytes(0 / 1) its sizeof(msm_opts) / sizeof(msm_result).  The Python loader and the N-API
  * addon compare both at load time and refuse a mismatch.  History: 3 = round 3 (msm_generate_scalars writes to a caller-owned
  * buffer; msm_opts.point_lo / by_window); 4 = msm_result.n_pairs_algo; 5 = window tables (msm_opts.no_tables, msm_result.tables,
- * msm_precompute / msm_tables_info / msm_set_tables_limit) and msm_reserve. */
+ * msm_precompute / msm_tables_info / msm_set_tables_limit), msm_reserve, msm_opts.bucket_shard / bucket_shards. */
 #define MSM_ABI_VERSION 5
 uint32_t msm_abi_version(void);
 uint32_t msm_abi_struct_bytes(int which);
@@ -86,6 +86,12 @@ typedef struct msm_opts {
                            needs all n scalars; default 0: by points, device d gets the scalars of its n / G points only */
   int32_t no_tables;    /* != 0: do not use (and do not build) window tables for this call -- the plain path over the resident
                            rows, K windows of buckets and a Horner step, as in rounds 1-4 (see msm_precompute) */
+  int32_t bucket_shard, bucket_shards;   /* bucket_shards = G > 1: the call covers only the buckets [L g / G, L (g + 1) / G) of every
+                           window, g = bucket_shard (L = buckets per window): the bucket-range shard of a multi-GPU run -- rank g
+                           slices ALL scalars into all K windows but sorts and adds an eighth of the entries, K stays the
+                           single-GPU plan's (the reference splits every window's buckets across its threads the same way,
+                           src/msm-common.ts:72-172).  The partial sums keep the buckets' true weights: the G results of
+                           msm_window_sums add up per window (msm_combine_groups), those of msm_run as points */
 } msm_opts;
 
 #define MSM_N_PHASES 8

@@ -39,7 +39,8 @@ EXPORTS = (
 
 class MsmOpts(C.Structure):
     _fields_ = [("c", C.c_int32), ("unsafe", C.c_int32), ("k_lo", C.c_int32), ("k_hi", C.c_int32), ("serial", C.c_int32),
-                ("no_glv", C.c_int32), ("strict", C.c_int32), ("point_lo", C.c_uint32), ("by_window", C.c_int32), ("no_tables", C.c_int32)]
+                ("no_glv", C.c_int32), ("strict", C.c_int32), ("point_lo", C.c_uint32), ("by_window", C.c_int32), ("no_tables", C.c_int32),
+                ("bucket_shard", C.c_int32), ("bucket_shards", C.c_int32)]
 
 
 class MsmResult(C.Structure):

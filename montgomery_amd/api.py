@@ -290,8 +290,10 @@ class MsmContext:
         return None if (x == 0 and y == 0) else (x, y)
 
     # -- msm ------------------------------------------------------------------------------
-    def plan(self, n: int, c: Optional[int] = None) -> Tuple[int, int]:
-        opts = MsmOpts(c=c or 0)
+    def plan(self, n: int, c: Optional[int] = None, no_tables: bool = False) -> Tuple[int, int]:
+        """(c, K) of msm_run over n points; over the whole resident point set that is the plan on window tables where they
+        exist or would be built -- no_tables: the plain plan (what msm_window_sums and shards of the points run)."""
+        opts = MsmOpts(c=c or 0, no_tables=int(no_tables))
         cc, kk = C.c_int32(), C.c_int32()
         self._check(self._lib.msm_plan(self._h, n, C.byref(opts), C.byref(cc), C.byref(kk)))
         return cc.value, kk.value
@@ -360,12 +362,15 @@ class MsmContext:
         self._check(self._lib.msm_reserve(self._h, n, C.byref(opts)))
 
     def window_sums(self, scalars: Union[BytesLike, int], n: int, k_lo: int, k_hi: int, c: Optional[int] = None,
-                    on_device: bool = False, point_lo: int = 0, by_window: bool = False) -> Tuple[bytes, Dict]:
+                    on_device: bool = False, point_lo: int = 0, by_window: bool = False,
+                    bucket_shard: Tuple[int, int] = (0, 0)) -> Tuple[bytes, Dict]:
         """Partition sums P_k, k in [k_lo, k_hi), over the resident points [point_lo, point_lo + n) (scalar i belongs to
         point point_lo + i): (k_hi - k_lo) x 144 bytes (X, Y, Z)."""
         if k_hi <= k_lo or k_lo < 0:   # (0, 0) would mean "all windows" to the C side and overrun the 144-byte buffer below
             raise MsmError(_lib.MSM_ERR_ARG, f"empty or negative window range [{k_lo}, {k_hi})")
-        opts = MsmOpts(c=c or 0, k_lo=k_lo, k_hi=k_hi, point_lo=point_lo, by_window=int(by_window))
+        # bucket_shard = (g, G): only the buckets [L g / G, L (g + 1) / G) of every window (msm_opts.bucket_shard)
+        opts = MsmOpts(c=c or 0, k_lo=k_lo, k_hi=k_hi, point_lo=point_lo, by_window=int(by_window),
+                       bucket_shard=bucket_shard[0], bucket_shards=bucket_shard[1])
         res = MsmResult()
         out = (C.c_uint8 * (144 * max(k_hi - k_lo, 1)))()
         if on_device:

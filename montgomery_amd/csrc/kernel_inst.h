@@ -9,7 +9,7 @@
   X(msm::k_points_from_wire<CV>, (uint32_t*, const uint32_t*, uint64_t, int, uint32_t*))                                 \
   X(msm::k_table_next<CV>, (uint32_t*, const uint32_t*, uint64_t, int))                                                   \
   X(msm::k_digits<CV>, (uint32_t*, const uint32_t*, uint32_t, int, int, int, int, int, int, uint32_t*, uint32_t, uint32_t*, uint32_t, \
-                       uint64_t))                   \
+                       uint64_t, uint32_t, uint32_t, uint32_t, uint32_t))                   \
   X(msm::k_batch_add<CV MSM_COMMA msm::MODE_GATHER>, (msm::BatchArgs))                                                   \
   X(msm::k_batch_add<CV MSM_COMMA msm::MODE_REGULAR>, (msm::BatchArgs))                                                  \
   X(msm::k_batch_add<CV MSM_COMMA msm::MODE_SEARCH>, (msm::BatchArgs))                                                   \

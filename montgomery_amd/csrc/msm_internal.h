@@ -308,6 +308,8 @@ struct Plan {
   bool no_glv;
   bool strict = false;   // msm_opts.strict: scalars >= q fail the call instead of being reduced
   bool lone = false;   // one window, one group: nothing else shares the GPU (see round_geom)
+  uint32_t b_lo = 0, b_n = 0xFFFFFFFFu;   // bucket-range shard (msm_opts.bucket_shard): bucket indices [b_lo, b_lo + b_n) only;
+  uint32_t bt_lo = 0, bt_n = 0xFFFFFFFFu; // the top window's range (its digits cover another span than the recoded windows')
   bool tables = false; // the call runs on window tables (msm_tables.hip): the windows of a group share one set of buckets, a
                        // group hands back ONE sum that already carries the windows' weights
   bool merged = false; // a full MSM (msm_run): a window group may hand back sum_k 2^(c (k - k_first)) P_k in the slot of its

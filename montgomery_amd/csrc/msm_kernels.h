@@ -252,6 +252,9 @@ MSM_DEV bool words8_ge(const uint32_t (&a)[8], const uint32_t* q) {
 // counts, per window, the coarse bins ((l - 1) >> ws.fb[kk]) of the digits it writes -- in the LDS, `hb` counters per window -- and
 // leaves them in slice_hist[(kk * gridDim.x + b) * hb + bin]: the digits are in registers here, a separate histogram pass would
 // read all of them again.
+// b_lo, b_n: the bucket-range shard of a multi-GPU run -- only digits whose bucket index l - 1 lies in [b_lo, b_lo + b_n) are
+// kept, the others become "no entry" (0) and are never sorted (the whole range: 0, 0xFFFFFFFF); bt_lo, bt_n: the same for the
+// TOP window, whose digits cover another range than the recoded ones (twice as many buckets when folded, fewer when short).
 // fbp: the fine bits of the group's windows, four bits each (WinSplit::fb packed: a register shift instead of a load from the
 // kernel arguments per digit)
 MSM_DEV void digit_note(uint32_t* lds_hist, uint32_t hb, uint64_t fbp, int kk, uint32_t l) {
@@ -266,7 +269,8 @@ inline uint64_t pack_fine_bits(const WinSplit& ws) {
 template <class CV>
 __global__ void __launch_bounds__(1024) k_digits(uint32_t* dig, const uint32_t* scalars, uint32_t n, int c, int k_total,
                                                 int k_lo, int k_cnt, int glv_flags, int strict, uint32_t* err, uint32_t pps,
-                                                uint32_t* slice_hist, uint32_t hb, uint64_t fbp) {
+                                                uint32_t* slice_hist, uint32_t hb, uint64_t fbp, uint32_t b_lo, uint32_t b_n, uint32_t bt_lo,
+                                                uint32_t bt_n) {
   extern __shared__ uint32_t lds_dig_hist[];
   uint32_t* lds_hist = slice_hist ? lds_dig_hist : nullptr;
   if (lds_hist) {
@@ -305,9 +309,11 @@ __global__ void __launch_bounds__(1024) k_digits(uint32_t* dig, const uint32_t* 
       uint32_t l = bn_bits<8>(s, k * c, top ? c + 1 : c) + carry;
       if (!top && l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
       if (top && l > 2 * L) { atomicOr(err, 8u); l = 2 * L; }   // (see below: a folded top window must stay within its buckets)
+      uint32_t sgn = carry;
+      if (l - 1 - (k == k_total - 1 ? bt_lo : b_lo) >= (k == k_total - 1 ? bt_n : b_n)) { l = 0; sgn = 0; }
       int kk = k - k_lo;
       if (kk >= 0 && kk < k_cnt) {
-        *reinterpret_cast<uint2*>(dig + (uint64_t)kk * two_n + 2ull * i) = make_uint2(l | (carry << 31), 0u);
+        *reinterpret_cast<uint2*>(dig + (uint64_t)kk * two_n + 2ull * i) = make_uint2(l | (sgn << 31), 0u);
         digit_note(lds_hist, hb, fbp, kk, l);
       }
     }
@@ -330,10 +336,14 @@ __global__ void __launch_bounds__(1024) k_digits(uint32_t* dig, const uint32_t* 
     if (top && (l0 > 2 * L || l1 > 2 * L)) { atomicOr(err, 8u); l0 = min(l0, 2 * L); l1 = min(l1, 2 * L); }
     const int kk = k - k_lo;
     if (kk >= 0 && kk < k_cnt) {
-      const uint32_t neg0 = carry0 ^ (h[0].neg ? 1u : 0u), neg1 = carry1 ^ (h[1].neg ? 1u : 0u);
-      *reinterpret_cast<uint2*>(dig + (uint64_t)kk * two_n + 2ull * i) = make_uint2(l0 | (neg0 << 31), l1 | (neg1 << 31));
-      digit_note(lds_hist, hb, fbp, kk, l0);
-      digit_note(lds_hist, hb, fbp, kk, l1);
+      uint32_t neg0 = carry0 ^ (h[0].neg ? 1u : 0u), neg1 = carry1 ^ (h[1].neg ? 1u : 0u);
+      uint32_t e0 = l0, e1 = l1;
+      const uint32_t f_lo = k == k_total - 1 ? bt_lo : b_lo, f_n = k == k_total - 1 ? bt_n : b_n;
+      if (e0 - 1 - f_lo >= f_n) { e0 = 0; neg0 = 0; }
+      if (e1 - 1 - f_lo >= f_n) { e1 = 0; neg1 = 0; }
+      *reinterpret_cast<uint2*>(dig + (uint64_t)kk * two_n + 2ull * i) = make_uint2(e0 | (neg0 << 31), e1 | (neg1 << 31));
+      digit_note(lds_hist, hb, fbp, kk, e0);
+      digit_note(lds_hist, hb, fbp, kk, e1);
     }
   }
   }

@@ -101,6 +101,23 @@ int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl, bo
     pl.L_log = c;
   }
   pl.L = 1u << pl.L_log;
+  pl.b_lo = pl.bt_lo = 0;
+  pl.b_n = pl.bt_n = 0xFFFFFFFFu;
+  if (opts && opts->bucket_shards > 1) {
+    // Rank g of G takes the g-th of G equal parts of the bucket range every window's digits really cover -- 2^(c-1) for a
+    // recoded window, the whole 2^c of a folded top window, 2^(bits left) for a short one -- so that all ranks sort and add the
+    // same number of entries.  The last part runs to the end of the window's buckets whatever the digits do.
+    if (opts->bucket_shard < 0 || opts->bucket_shard >= opts->bucket_shards) return MSM_ERR_ARG;
+    const uint32_t g = (uint32_t)opts->bucket_shard, G = (uint32_t)opts->bucket_shards;
+    auto cut = [&](uint64_t span, uint32_t& lo, uint32_t& cnt) {
+      lo = (uint32_t)(span * g / G);
+      const uint64_t hi = g + 1 == G ? (uint64_t)pl.L : span * (g + 1) / G;
+      cnt = (uint32_t)(hi - lo);
+    };
+    const int top_bits = pl.fold ? c : std::min(c - 1, pl.bits - (pl.K - 1) * c);
+    cut(pl.K > 1 ? 1ull << (c - 1) : 1ull << std::max(0, top_bits), pl.b_lo, pl.b_n);
+    cut(1ull << std::max(0, top_bits), pl.bt_lo, pl.bt_n);
+  }
   return MSM_OK;
 }
 

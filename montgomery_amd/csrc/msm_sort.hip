@@ -142,10 +142,10 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     const uint32_t threads = bin_split ? 1024u : 256u;
     if (te)
       hipLaunchKernelGGL(te::k_te_digits, dim3(grid), dim3(threads), lds, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K,
-                         k_lo, kc_d, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, pack_fine_bits(ws_d));
+                         k_lo, kc_d, pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, pack_fine_bits(ws_d), pl.b_lo, pl.b_n, pl.bt_lo, pl.bt_n);
     else
       W_LAUNCH(ctx, k_digits, dim3(grid), dim3(threads), lds, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K, k_lo, kc_d,
-                         (pl.no_glv ? 0 : 1) | (pl.fold ? 2 : 0), pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, pack_fine_bits(ws_d));
+                         (pl.no_glv ? 0 : 1) | (pl.fold ? 2 : 0), pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, pack_fine_bits(ws_d), pl.b_lo, pl.b_n, pl.bt_lo, pl.bt_n);
   }
   HIPCHK(hipEventRecord(w.ev[1], s));
   if (!bin_split) {

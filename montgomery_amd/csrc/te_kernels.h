@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256) k_te_table_next(uint32_t* rows_out, const
 
 __global__ void __launch_bounds__(1024) k_te_digits(uint32_t* dig, const uint32_t* scalars, uint32_t n, int c, int k_total, int k_lo,
                                                    int k_cnt, int strict, uint32_t* err, uint32_t pps, uint32_t* slice_hist,
-                                                   uint32_t hb, uint64_t fbp)
+                                                   uint32_t hb, uint64_t fbp, uint32_t b_lo, uint32_t b_n, uint32_t bt_lo, uint32_t bt_n)
 #ifndef MSM_TE_TU
     ;
 #else
@@ -303,8 +303,10 @@ __global__ void __launch_bounds__(1024) k_te_digits(uint32_t* dig, const uint32_
       if (l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
       int kk = k - k_lo;
       if (kk >= 0 && kk < k_cnt) {
-        dig[(uint64_t)kk * n + i] = l | (carry << 31);
-        digit_note(lds_hist, hb, fbp, kk, l);
+        uint32_t e = l, sgn = carry;
+        if (e - 1 - (k == k_total - 1 ? bt_lo : b_lo) >= (k == k_total - 1 ? bt_n : b_n)) { e = 0; sgn = 0; }   // bucket-range shard: see k_digits
+        dig[(uint64_t)kk * n + i] = e | (sgn << 31);
+        digit_note(lds_hist, hb, fbp, kk, e);
       }
     }
   }

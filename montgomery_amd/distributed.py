@@ -7,7 +7,12 @@ finishes with `msm_combine`.  Every rank needs all scalars.
 By points (`sharded_msm_points`): rank r runs ALL K windows on its share [n r / G, n (r + 1) / G) of the points -- it needs
 only that share of the scalars and decomposes only those -- the same single all-gather carries K x 144 bytes per rank
 and rank 0 adds the G sums of every window before the Horner step (`msm_combine_groups`).
-An element-wise reduce would be wrong in both forms: limb-wise addition is not the group law.
+By buckets (`sharded_msm_buckets`, round 5): rank r runs all K windows over ALL points but keeps only the digits that fall
+into its eighth of every window's buckets (`msm_opts.bucket_shard`) -- it slices all scalars and sorts and adds 1 / G of the
+entries, with the single-GPU plan (K = 6 at 2^26: the window split needs K = 8 so that eight ranks divide it).  The reference
+splits every window's buckets across its threads the same way (src/msm-common.ts:72-172).  Same exchange and the same
+`msm_combine_groups` as the points split: partial sums keep their buckets' true weights.
+An element-wise reduce would be wrong in all forms: limb-wise addition is not the group law.
 """
 from __future__ import annotations
 
@@ -59,7 +64,7 @@ def choose_window(plan: Callable[[int, Optional[int]], Tuple[int, int]], n: int,
       neither divide among 4 or 8 ranks nor pay for a shard of three windows, which has no second window group of its own
       size beside it (tools/shard_time.py at 2^26, 2 ranks: 84.1 ms with three 22-bit windows against 81 with four 16-bit
       ones): c = 16 (K = 8) whenever the ranks divide its windows, else the pick for a rank's share of the points."""
-    if world <= 1:
+    if world <= 1 or split == "buckets":   # a bucket-range shard keeps the single-GPU plan: every rank runs all of its windows
         return plan(n, None)
     if split != "points":
         c16, K16 = plan(n, 16)
@@ -168,6 +173,30 @@ def sharded_msm_points(point_sums: Callable[[int, int], bytes], n: int, K: int, 
     part = point_sums(first, count) if count else ident
     if len(part) != PARTIAL_BYTES * K:
         raise MsmError(_lib.MSM_ERR_ARG, "point_sums returned the wrong number of bytes")
+    g = ex.all_gather(part, timing)
+    if g is None:
+        return None
+    return True, combine_groups_host(g, ex.world, K, c, curve)
+
+
+def bucket_shard_of(rank: int, world: int, span: int, L: Optional[int] = None) -> Tuple[int, int]:
+    """[lo, hi) of the bucket indices (l - 1) rank `rank` keeps in a window whose digits cover `span` buckets of its L
+    (make_plan, msm_opts.bucket_shard): the g-th of G equal parts of the span; the last part runs to the end of the window."""
+    L = span if L is None else L
+    return span * rank // world, (L if rank + 1 == world else span * (rank + 1) // world)
+
+
+def sharded_msm_buckets(bucket_sums: Callable[[int, int], bytes], K: int, c: int, device="cpu", group=None,
+                        curve: int = _lib.CURVE_BLS12_377_G1, timing: Optional[dict] = None, exchange: Optional[ShardExchange] = None):
+    """One bucket-split MSM on the current process group.
+
+    bucket_sums(rank, world) -> K * 144 bytes: the K window sums over ALL points restricted to this rank's range of the
+    buckets (product: `MsmContext.window_sums(..., bucket_shard=(rank, world))`; the CPU tests inject a checker).
+    Returns (True, affine-or-None) on rank 0 and None elsewhere."""
+    ex = exchange or ShardExchange(PARTIAL_BYTES * K, device, group)
+    part = bucket_sums(ex.rank, ex.world)
+    if len(part) != PARTIAL_BYTES * K:
+        raise MsmError(_lib.MSM_ERR_ARG, "bucket_sums returned the wrong number of bytes")
     g = ex.all_gather(part, timing)
     if g is None:
         return None

@@ -17,8 +17,9 @@ def _free_port():
     return p
 
 
-def _oracle_window_sums(scalars, points, c, K, C=None):
-    """P_k for every window k as 144-byte (X, Y, Z) records, from the oracle's spec arithmetic."""
+def _oracle_window_sums(scalars, points, c, K, C=None, buckets=None):
+    """P_k for every window k as 144-byte (X, Y, Z) records, from the oracle's spec arithmetic.
+    buckets = (lo, hi): only the digits whose bucket index l - 1 lies in [lo, hi) (a bucket-range shard)."""
     from oracle import msm_oracle as O
 
     C = C or O.BLS12_377
@@ -28,7 +29,7 @@ def _oracle_window_sums(scalars, points, c, K, C=None):
         a0, a1, n0, n1 = O.glv_decompose(s, g)
         for a, neg, Q in ((a0, n0, P), (a1, n1, (C.beta * P[0] % C.p, P[1]))):
             for k, (l, dneg) in enumerate(O.signed_digits(a, c, K)):
-                if l:
+                if l and (buckets is None or buckets[0] <= l - 1 < buckets[1]):
                     T = O.aff_scale(l, Q, C.p)
                     sums[k] = O.aff_add(sums[k], O.aff_neg(T, C.p) if neg ^ dneg else T, C.p)
     out = []
@@ -44,13 +45,23 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
 
-    from montgomery_amd.distributed import sharded_msm, sharded_msm_points
+    from montgomery_amd.distributed import bucket_shard_of, sharded_msm, sharded_msm_buckets, sharded_msm_points
     from oracle import msm_oracle as O
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         C = O.BLS12_377
         results = []
+        # bucket split: every rank sums ALL windows over ALL points, restricted to its range of the buckets
+        for name, n, c in (("ba", 40, 5), ("bb", 3, 9)):   # 2^4 = 16 buckets over 2 or 3 ranks: uneven ranges
+            pts, _ = O.random_points_bls377("dist/" + name, n)
+            sc = O.prng_ints("dist/s/" + name, n, C.q)
+            K = -(-127 // c)
+            out = sharded_msm_buckets(lambda r, w: b"".join(_oracle_window_sums(sc, pts, c, K, buckets=bucket_shard_of(r, w, 1 << (c - 1)))), K, c)
+            if rank == 0:
+                results.append((out[1], O.msm_batched_affine(sc, pts, c=c)))
+            else:
+                assert out is None
         # points split: every rank sums ALL windows over its share of the points; rank 0 adds the groups per window
         for name, n, c in (("pa", 23, 9), ("pb", 1, 13)):   # n = 1: rank 0 has no points at all
             pts, _ = O.random_points_bls377("dist/" + name, n)
@@ -169,7 +180,7 @@ def test_sharded_msm_gloo(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert len(results) == 5
+    assert len(results) == 7
     for got, exp in results:
         assert got == exp
 
@@ -197,6 +208,15 @@ def test_point_shards_partition_and_group_combine():
     assert combine_groups_host(parts, 3, K, c) == O.msm_batched_affine(sc, pts, c=c)
 
 
+def test_bucket_shards_partition():
+    from montgomery_amd.distributed import bucket_shard_of
+
+    for L in (16, 1 << 15, 1 << 21):
+        for world in (1, 2, 3, 8):
+            sh = [bucket_shard_of(r, world, L) for r in range(world)]
+            assert sh[0][0] == 0 and sh[-1][1] == L and all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
+
+
 def test_choose_window_for_shards():
     """The window of a sharded MSM: by points the pick for a rank's share of the points; by windows a K the ranks divide
     (the single-GPU pick at 2^26, c = 22 / K = 6, would leave two of eight ranks idle)."""
@@ -215,3 +235,5 @@ def test_choose_window_for_shards():
     assert choose_window(plan, n, 8, "points") == (16, 8)               # 2^23 points per rank
     assert choose_window(plan, n, 3, "windows") == (21, 6)              # 8 does not divide by 3: the pick for a rank's share
     assert choose_window(plan, 1 << 20, 8, "windows") == (16, 8)
+    for world in (2, 3, 8):
+        assert choose_window(plan, n, world, "buckets") == (21, 6)        # a bucket-range shard keeps the single-GPU plan

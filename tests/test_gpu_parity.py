@@ -359,6 +359,9 @@ def test_msm_2p26_known_discrete_logs(gpu_ctx, c_oracle):
     share = n // 8
     groups = b"".join(gpu_ctx.window_sums(dev + 32 * g * share, share, 0, 8, on_device=True, point_lo=g * share)[0] for g in range(8))
     assert combine_groups_host(groups, 8, 8, 16, _lib.CURVE_BLS12_377_G1) == res.as_tuple()
+    # and eight bucket-range shards (`--split buckets`): the single-GPU plan, every rank an eighth of every window's buckets
+    groups = b"".join(gpu_ctx.window_sums(dev, n, 0, 6, on_device=True, bucket_shard=(g, 8))[0] for g in range(8))
+    assert combine_groups_host(groups, 8, 6, 21, _lib.CURVE_BLS12_377_G1) == res.as_tuple()
 
 
 def test_default_plan_at_2p22_is_seven_folded_18_bit_windows(gpu_ctx, c_oracle):
@@ -383,6 +386,23 @@ def test_glv_halves_stay_below_the_bound_a_folded_plan_relies_on(gpu_ctx):
     scalars = [v % C.q for v in extremes] + O.prng_ints("gpu/glv/bound", 50000, C.q)
     for (s0, s1, _n0, _n1) in gpu_ctx.test_glv(O.scalars_to_bytes(scalars)):
         assert s0 < (1 << 126) and s1 < (1 << 126)
+
+
+@pytest.mark.parametrize("lg,c", [(12, None), (16, None), (18, 21), (20, 18), (22, None)])
+def test_bucket_range_shards(gpu_ctx, lg, c):
+    """msm_opts.bucket_shard: G shards, each all windows over all points but 1 / G of every window's buckets, add up per window
+    (msm_combine_groups) to the whole MSM -- G = 2, 3 (uneven ranges) and 8, plain and folded plans, every sort path."""
+    from montgomery_amd import _lib
+    from montgomery_amd.distributed import combine_groups_host
+
+    n = 1 << lg
+    gpu_ctx.generate_points(n, seed=900 + lg)
+    dev, _ = gpu_ctx.generate_scalars(n, seed=901 + lg)
+    cc, K = gpu_ctx.plan(n, c, no_tables=True)
+    want, _ = gpu_ctx.run_device(dev, n, c=cc, no_tables=True)
+    for G in (2, 3, 8):
+        parts = b"".join(gpu_ctx.window_sums(dev, n, 0, K, c=cc, on_device=True, bucket_shard=(g, G))[0] for g in range(G))
+        assert combine_groups_host(parts, G, K, cc, _lib.CURVE_BLS12_377_G1) == want.as_tuple(), (lg, cc, G)
 
 
 def test_msm_large_linearity(gpu_ctx):
