@@ -68,7 +68,10 @@ typedef struct msm_opts {
                            (b + 1 = (K - 1) c + 1; BLS12-377: c = 18, 21) is folded into the window below -- K - 1 windows,
                            window k still weighs 2^(c k).  msm_plan / msm_result.K report the K in use; every rank of a
                            sharded run gets the same one from the same c */
-  int32_t unsafe;       /* accepted for API parity with msmUnsafe; the GPU path always handles edge cases */
+  int32_t unsafe;       /* accepted for API parity with msmUnsafe (src/curve-affine.ts:463-522) and ignored: there is one tree
+                           kernel and it always handles the edge cases -- the equal-x detection the unsafe variant would drop is
+                           19 of its 3 171 instructions per pair addition (0.6 %), and the identity operands it also ignores are
+                           structural here (bucket padding) */
   int32_t k_lo, k_hi;   /* window shard [k_lo, k_hi) for msm_window_sums; 0,0 = all windows */
   int32_t serial;       /* != 0: run the window groups one after the other on one stream (no overlap): phase_ms then
                            hold exclusive kernel times -- used for roofline measurements.  Every tree launch then has the
@@ -207,7 +210,11 @@ int msm_combine_curve(int curve, const uint8_t* partials, int32_t K, int32_t c, 
  * msm_window_sums wrote them); P_k = sum over the groups, then as msm_combine_curve. */
 int msm_combine_groups(int curve, const uint8_t* partials, int32_t G, int32_t K, int32_t c, msm_result* out);
 
-/* Window plan for n points: the c the library would pick (opts->c forces one) and the resulting K (see msm_opts.c). */
+/* Window plan for n points: the c the library would pick (opts->c forces one) and the resulting K (see msm_opts.c).  It is the
+ * plan of msm_run over DEVICE-RESIDENT scalars: over the whole current point set that is the plan on window tables where they
+ * exist or would be built (opts->no_tables: the plain plan, which msm_window_sums and every shard of the points always run).
+ * Host scalars of 2^24 points and more cross PCIe behind the computation: msm_run then runs whole MSMs over growing ranges of
+ * the points, each under the plan of ITS size, and msm_result reports the plan of the last, biggest range. */
 int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_out, int32_t* K_out);
 
 /* Synthetic inputs generated on the GPU (randomPointsFast / randomScalars, src/curve-random.ts):

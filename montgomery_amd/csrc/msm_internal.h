@@ -410,13 +410,20 @@ class PieceUpload {
       : ctx_(ctx), dst_((char*)dst), src_((const char*)src), bytes_(bytes), ends_(piece_end_bytes), enq_(piece_end_bytes.size(), 0) {
     ensure_staging(ctx);
     MSM_KNOB(n_streams_, "MSM_UPLOAD_STREAMS", 1);
-    n_streams_ = std::min<long long>(n_streams_, T);
+    n_streams_ = std::max<long long>(1, std::min<long long>(n_streams_, T));
     HIPCHK(hipStreamSynchronize(ctx->stream));   // dst may still be in use by what the stream holds
     for (int t = 0; t < T; t++) HIPCHK(hipStreamSynchronize(ctx->stage_stream[t]));
     for (int t = 0; t < T; t++) rc_[t] = hipSuccess;
     t0_ = std::chrono::steady_clock::now();
-    for (int t = 0; t < T; t++) {
-      try { th_.emplace_back([this, t] { run(t); }); } catch (const std::system_error&) { run(t); }
+    th_.reserve(T);
+    try {
+      for (int t = 0; t < T; t++) {
+        // a thread that cannot be started (resource limits) must not leave the others unjoined: its share runs here
+        try { th_.emplace_back([this, t] { run(t); }); } catch (const std::system_error&) { run(t); }
+      }
+    } catch (...) {   // anything else: the destructor of a half-built object does not run, so the started threads are joined here
+      join();
+      throw;
     }
   }
   ~PieceUpload() { join(); }
@@ -426,8 +433,13 @@ class PieceUpload {
       std::unique_lock<std::mutex> l(mu_);
       cv_.wait(l, [&] { return enq_[q] == T; });
     }
+    hipError_t rc[T];
+    {
+      std::lock_guard<std::mutex> l(mu_);   // the staging threads write rc_ under the mutex
+      for (int t = 0; t < T; t++) rc[t] = rc_[t];
+    }
     for (int t = 0; t < T; t++) {
-      if (rc_[t] != hipSuccess) throw HipFail{rc_[t], "staged upload of the scalars", __LINE__};
+      if (rc[t] != hipSuccess) throw HipFail{rc[t], "staged upload of the scalars", __LINE__, __FILE__};
       HIPCHK(hipStreamWaitEvent(stream, ctx_->piece_ev[q][t], 0));
     }
   }

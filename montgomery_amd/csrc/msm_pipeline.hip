@@ -95,6 +95,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     const int big = n >= (1ull << 25);
     for (int sh : {big ? 4 : 3, big ? 2 : 1}) piece_end.push_back(((n >> sh) / gran) * gran);
     piece_end.push_back(n);
+    ctx->ensure(ctx->scal, n * 32);   // before the workspace budget is taken from what the device has free
   }
   std::unique_ptr<PieceUpload> pipe;
   if (piece_end.empty()) stage_scalars(ctx, scalars, n, on_device, &d_scal);
