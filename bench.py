@@ -54,17 +54,22 @@ PAIR_MADS_SURVEY = 1800
 # (tools/pmc_headline.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled: gfx950 halves wide coalesced
 # reads); the round-3 constant (2^24, regular rounds only) if that file is missing
 PAIR_TRAFFIC_BYTES_PMC = 488
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_2p26.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_2p26.json")
 
 
-def pmc_bytes_per_pair():
-    """(bytes per algorithmic pair addition over all rounds, source) from the committed PMC summary."""
+def pmc_summary(curve, log2n, window_bits):
+    """The committed PMC summary of THIS configuration (tools/pmc_headline.sh: separate rocprofv3 --pmc passes over this
+    command), or None: counters taken at another size, curve or window say nothing about this run."""
     try:
         with open(PMC_FILE) as f:
             d = json.load(f)
-        return float(d["per_pair_addition"]["all_rounds"]["hbm_bytes_per_pair_add"]), os.path.relpath(PMC_FILE, ROOT)
+        if curve != "bls12-377" or log2n != 26 or d.get("window_bits") != window_bits:
+            return None
+        return d
     except (OSError, KeyError, ValueError):
-        return float(PAIR_TRAFFIC_BYTES_PMC), "profiles/r03_pmc_2p24.json (regular rounds at 2^24)"
+        return None
+
+
 MAX_SCALAR_SETS = 8            # distinct 2^n x 32-byte scalar sets kept in HBM; steps cycle through them
 
 
@@ -176,6 +181,18 @@ def timed_config(curve_name, log2n, torch, steps=10, warmup=5, c=0):
         infos.append(info)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the same MSMs on the plain path (no window tables: K sets of buckets and a Horner step, the path of rounds 1-4), for the record
+    plain = None
+    if infos[-1]["tables"]:
+        p_ms, p_info = [], None
+        for i in range(warmup + steps):
+            ts = time.perf_counter()
+            p_last, p_info = ctx.run_device(scal[i % n_sets].data_ptr(), n, no_tables=True)
+            if i >= warmup:
+                p_ms.append((time.perf_counter() - ts) * 1e3)
+        same = (p_last.x, p_last.y) == (last.x, last.y)   # the last timed step of either loop ran on the same scalar set
+        plain = {"ms": statistics.median(p_ms), "std_ms": statistics.stdev(p_ms), "window_bits": p_info["c"], "windows": p_info["K"],
+                 "equals_tables_result": bool(same)}
     _, s_host = ctx.generate_scalars(n, seed=3000 + last_set, to_host=True, raw=True)
     exp = expected_from_logs(curve_name, a_host, s_host, n)
     verified = ((last.x, last.y) == exp) if te else (last.as_tuple() == exp)
@@ -189,6 +206,10 @@ def timed_config(curve_name, log2n, torch, steps=10, warmup=5, c=0):
     return {
         "workload": f"{'ed-on-bls12-377' if te else 'bls12-377-g1'}-msm-2^{log2n}",
         "window_bits": cc, "windows": K, "steps": steps, "warmup": warmup,
+        "window_tables": ({"tables": K, "gib": ctx.tables_info()[2] / 2 ** 30,
+                           "note": "K resident tables 2^(c k) P of the point set (built once per set, like the point conversion): all "
+                                   "windows share one set of buckets; `plain_path` = the same MSMs without them"} if infos[-1]["tables"] else None),
+        "plain_path": plain,
         "ms": statistics.median(step_ms), "std_ms": statistics.stdev(step_ms), "ms_per_step": dt / steps * 1e3,
         "points_per_s": n * steps / dt, "verified": bool(verified),
         "roofline": {"kernel": "k_te_add" if te else "k_batch_add", "bound": "int-alu", "achieved": mad_rate, "peak": INT_MAD_PEAK,
@@ -286,6 +307,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the known-discrete-log check of the last timed result")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-scalar (PCIe-inclusive) leg")
+    ap.add_argument("--no-tables-leg", action="store_true", help="skip the leg that builds window tables for the headline size and times the MSM on them")
     ap.add_argument("--no-c16", action="store_true", help="skip the serialised step at c = 16 (same_kernel_at_c16): counter runs "
                                                           "then hold MSMs of one plan only")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -563,6 +585,35 @@ def main():
                     "equals_device_resident": failed is None,
                     "note": "MSMs with host-resident (pageable) scalars: the upload runs in the background, range by range of the "
                             "points, under the window groups of the ranges that have arrived; upload_ms = wall time of the transfer"}
+        tables_leg = None
+        if not sharded and not args.no_tables_leg and not is381 and not infos[-1].get("tables"):
+            # The same MSM on WINDOW TABLES (msm_precompute): K resident tables 2^(c k) P of the point set, all windows of a window
+            # group in one set of buckets.  Off by default at this size (six tables of 2^26 points are 96 GiB for ~1.5 %); the leg
+            # builds them once, times 10 calls after 3 discarded ones and checks the result against the plain path.
+            ctx.set_tables_limit(1 << 42)
+            tb = time.perf_counter()
+            tc, tK, tbytes = ctx.precompute(n, c=c)
+            build_s = time.perf_counter() - tb
+            if tK:
+                t_ms = []
+                for i in range(13):
+                    tp = time.perf_counter()
+                    t_last, t_info = ctx.run_device(scal[i % n_sets].data_ptr(), n, c=c)
+                    if i >= 3:
+                        t_ms.append((time.perf_counter() - tp) * 1e3)
+                p_last, _ = ctx.run_device(scal[12 % n_sets].data_ptr(), n, c=c, no_tables=True)
+                tables_leg = {"median_ms": statistics.median(t_ms), "std_ms": statistics.stdev(t_ms), "points_per_s": n / (statistics.median(t_ms) * 1e-3),
+                              "tables": tK, "window_bits": tc, "gib": tbytes / 2 ** 30, "build_s": build_s, "ran_on_tables": bool(t_info["tables"]),
+                              "equals_plain_path": t_last.as_tuple() == p_last.as_tuple(),
+                              "note": "one-time per point set, like the point conversion the reference's protocol also leaves out of the "
+                                      "timed region (scripts/msm-weierstrass.ts:19,32); never `value` at this size"}
+                if not tables_leg["equals_plain_path"]:
+                    failed = "bench: the MSM on window tables differs from the plain path"
+            ctx.set_tables_limit(0)
+        pmc = pmc_summary(args.curve, args.log2n, c)
+        if excl and pmc and pmc.get("scatter_phase"):
+            excl["scatter"]["hbm_bytes_per_entry_pmc"] = pmc["scatter_phase"]["hbm_bytes_per_entry"]
+            excl["scatter"]["digits_ms"] = excl["phase_ms"]["digits"]
         mad_rate = (excl["int_mad_frac"] * INT_MAD_PEAK) if excl else (pairs * PAIR_MADS / (acc_ms * 1e-3) if acc_ms else 0.0)
         out = {
             "metric": f"{'BLS12-381' if is381 else 'BLS12-377'} G1 MSM throughput",
@@ -590,6 +641,7 @@ def main():
                 "points": "P_i = a_i*G generated on GPU (resident)",
                 "scalars": f"uniform < q, fresh per step ({n_sets} distinct sets cycled), resident in HBM before the timed region",
             },
+            "window_tables": bool(infos and infos[-1].get("tables")),
             "verified": verified,
             "verified_how": "last timed result == (sum s_i a_i mod q) G from the known discrete logs of the generated points "
                             "(dot product: oracle/msm_oracle.c, scalar multiplication: oracle/msm_oracle.py), outside the timed region",
@@ -604,15 +656,19 @@ def main():
                 "unit": "v_mad_u64_u32 lane-ops/s",
                 "frac": mad_rate / INT_MAD_PEAK,
                 "frac_1800_basis": mad_rate / PAIR_MADS * PAIR_MADS_SURVEY / INT_MAD_PEAK,
-                "frac_basis": ("exclusive (window groups serialised, one untimed step)" if excl else "overlapped streams")
+                "frac_basis": ("exclusive (window groups serialised, one untimed step; a launch that has the chip to itself walks its "
+                               "pairs in batches of 128 per lane, the overlapped run `value` is timed on in batches of 512: "
+                               "`int_mad_overlapped` is the figure of that geometry)" if excl else "overlapped streams")
                               + "; algorithmic pair additions (sum over non-empty buckets of size - 1) x 1 872 multiply-adds "
                                 "(13-limb count); frac_1800_basis prices them at SURVEY section 8(d)'s 300 per multiplication",
                 "mads_per_pair_add": PAIR_MADS,
-                "traffic": pairs / launches * pmc_bytes_per_pair()[0],
-                "traffic_note": "HBM bytes per launch = algorithmic pair additions per launch x the measured bytes per pair addition of "
-                                + pmc_bytes_per_pair()[1] + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
-                                "command at this size; not collected inside this run)",
-                "traffic_bytes_per_pair_add": pmc_bytes_per_pair()[0],
+                "traffic": (pairs / launches * pmc["per_pair_addition"]["all_rounds"]["hbm_bytes_per_pair_add"]) if pmc else None,
+                "traffic_note": ("HBM bytes per launch = algorithmic pair additions per launch x the measured bytes per pair addition of "
+                                 + os.path.relpath(PMC_FILE, ROOT) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                                 "command at this size, curve and window; not collected inside this run)") if pmc else
+                                "null: the committed PMC summary was taken at another size, curve or window (profiles/r05_pmc_2p26.json: "
+                                "BLS12-377, 2^26, 21-bit windows)",
+                "traffic_bytes_per_pair_add": pmc["per_pair_addition"]["all_rounds"]["hbm_bytes_per_pair_add"] if pmc else None,
                 "pair_adds_per_step": pairs / max(len(infos), 1),
                 "pair_adds_issued_per_step": pairs_issued / max(len(infos), 1),
                 "avg_launch_ms": acc_ms / launches,
@@ -640,6 +696,7 @@ def main():
             "ranks": ranks_info,
             "other_splits": other_splits,
             "pcie_inclusive": pcie,
+            "window_tables_leg": tables_leg,
             "result_is_infinity": bool(last.isZero) if last is not None else None,
         }
         if not sharded and not args.no_cpu_baseline and not is381:

@@ -337,6 +337,7 @@ struct RoundGeom {
 };
 
 RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather = false, bool lone = false);
+void release_workspaces(msm_ctx* ctx);   // drops every per-call buffer of both window-group workspaces (they only grow otherwise)
 long double window_bytes(const msm_ctx* ctx, uint64_t n, const Plan& pl);
 int windows_per_group(const msm_ctx* ctx, uint64_t n, const Plan& pl);
 uint64_t point_pieces(const msm_ctx* ctx, uint64_t n, const Plan& pl);

@@ -366,10 +366,7 @@ int window_sums_impl(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       throw;
     }
     (void)hipGetLastError();
-    for (auto& w : ctx->ws) {
-      (void)hipStreamSynchronize(w.stream);
-      for (DevBuf* b : w.all) ctx->release(*b);
-    }
+    release_workspaces(ctx);
     if (attempt >= 1) ctx->ws_limit = std::max<uint64_t>(ctx->ws_budget / 2, (uint64_t)64 << 20);
   }
 }

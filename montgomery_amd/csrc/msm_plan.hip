@@ -152,6 +152,13 @@ RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather, bool lone)
 }
 
 // how many windows fit one group under the workspace budget
+void release_workspaces(msm_ctx* ctx) {
+  for (auto& w : ctx->ws) {
+    (void)hipStreamSynchronize(w.stream);
+    for (DevBuf* b : w.all) ctx->release(*b);
+  }
+}
+
 long double window_bytes(const msm_ctx* ctx, uint64_t n, const Plan& pl) {
   // bytes per window and point (Weierstrass: 2 entries per point): digits 8, records of the sort's passes 16, slots (or the pair
   // list of a big window) ~9, tree buffers 96 + 48, prefix scratch 56; the tile-ordered round 1 of a big window (c >= 18) adds

@@ -22,7 +22,16 @@ static void build_tables(msm_ctx* ctx, const Plan& pl) {
   if (ctx->rows.cap < bytes) {
     // a bigger buffer: table 0 (the plain rows) moves over, the old buffer goes back
     DevBuf big;
-    ctx->ensure(big, bytes);
+    try {
+      ctx->ensure(big, bytes);
+    } catch (const HipFail& f) {
+      // the workspaces of earlier calls only grow: give them back and try once more (the next MSM allocates what it needs)
+      if (f.e != hipErrorOutOfMemory) throw;
+      (void)hipGetLastError();
+      release_workspaces(ctx);
+      ctx->release(ctx->scal);
+      ctx->ensure(big, bytes);
+    }
     HIPCHK(hipMemcpyAsync(big.p, ctx->rows.p, n * row_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->release(ctx->rows);
@@ -77,10 +86,16 @@ int make_run_plan(msm_ctx* ctx, uint64_t n, const msm_opts* opts, bool placed, P
         }
       }
     }
-    // none yet (or others): a default-plan call on an endomorphism curve may build them if they fit the limit
-    if (!(opts && opts->c) && !(opts && opts->no_glv) && !ctx->is_te()) {
+    // none yet (or others): a call with the default plan on an endomorphism curve may build them if they fit the limit --
+    // opts->c == 0, or the very window the library would pick (a facade that asks msm_plan first and hands its answer back)
+    if (!(opts && opts->no_glv) && !ctx->is_te()) {
       Plan pt;
-      if (make_plan(ctx, n, opts, pt, true) == MSM_OK && plan_suits_tables(pt) && table_bytes(ctx, n, pt.K) <= ctx->tables_limit) {
+      msm_opts o;
+      if (opts) o = *opts; else memset(&o, 0, sizeof o);
+      const int asked = o.c;
+      o.c = 0;
+      if (make_plan(ctx, n, &o, pt, true) == MSM_OK && (asked == 0 || asked == pt.c) && plan_suits_tables(pt) &&
+          table_bytes(ctx, n, pt.K) <= ctx->tables_limit) {
         pl = pt;
         tables_wanted = true;
         return MSM_OK;

@@ -11,7 +11,7 @@ REPO=$PWD
 export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/pmc_${TAG}${SFX}_2p$LG
 rm -rf $OUT; mkdir -p $OUT
-PM="python3 $REPO/bench.py --steps 1 --warmup 0 --log2n $LG --no-cpu-baseline --no-verify --no-other-configs --no-pcie --no-c16 $EXTRA"
+PM="python3 $REPO/bench.py --steps 1 --warmup 0 --log2n $LG --no-cpu-baseline --no-verify --no-other-configs --no-pcie --no-c16 --no-tables-leg $EXTRA"
 cd /tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PM > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PM > $OUT/pmc_write.log 2>&1

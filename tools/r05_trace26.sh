@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 REPO=$PWD; export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/trace_26; rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $REPO/bench.py --steps 3 --warmup 1 --log2n 26 --no-cpu-baseline --no-other-configs --no-pcie --no-c16 ${BENCH_ARGS} > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $REPO/bench.py --steps 3 --warmup 1 --log2n 26 --no-cpu-baseline --no-other-configs --no-pcie --no-c16 --no-tables-leg ${BENCH_ARGS} > $OUT/log.txt 2>&1
 cd $REPO
 cp $(ls $OUT/*/*_kernel_stats.csv | head -1) gpurun_out/r05_kstats26.csv
 find $OUT -name "*_kernel_trace.csv" -size +30M -delete
