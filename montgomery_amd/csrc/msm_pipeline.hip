@@ -128,7 +128,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   {
     const uint64_t entries = ctx->is_te() ? n : 2 * n;
     const bool fits_lds = ((size_t)pl.L * 4 <= 128 * 1024);
-    if (pl.c - 1 > (int)RX_FINE_BITS && (!fits_lds || entries >= (1ull << 22))) wpg = std::min(wpg, 16);
+    if (pl.c - 1 > (int)RX_FINE_BITS && (!fits_lds || entries >= (ctx->is_te() ? 1ull << 22 : 1ull << 21))) wpg = std::min(wpg, 16);
   }
   const int nwin = k_hi - k_lo;
   // measured on MI355X: two groups win 14 % at 2^23 / 2^24, 3 % at 2^22, nothing at 2^21 -- below that the fixed

@@ -67,7 +67,9 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   //                of round 1 in an order that keeps its row gathers local
   const int cbits = pl.L_log;   // bits of a bucket index
   const bool fits_lds = (size_t)L * 4 <= 128 * 1024;
-  long long want_radix = (fits_lds && cbits > (int)RX_FINE_BITS && two_n >= (1ull << 22)) ? 1 : 0;   // measured: wins from N = 2^21 up
+  // measured (round 5, with one ds_add per key as the ranking: tools/sortpath_sweep.sh): the split wins from 2^21 entries per
+  // window -- 2^20 points: sort 0.31 against 0.36 ms, 2^21: 0.51 / 0.85; 2^19: level, below: the one-level sort (2^16 0.11 / 0.14)
+  long long want_radix = (fits_lds && cbits > (int)RX_FINE_BITS && two_n >= (te ? 1ull << 22 : 1ull << 21)) ? 1 : 0;
   MSM_KNOB(want_radix, "MSM_RADIX", 0);
   // (the merged window of a run on window tables has kc = 1: the radix split would give its last pass one block per coarse bin,
   // 2^(c-8) of them for the whole chip -- the bin split cuts it into 2^10 bins whatever the window is)
