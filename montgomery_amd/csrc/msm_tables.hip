@@ -58,6 +58,11 @@ static bool tables_eligible(const msm_ctx* ctx, uint64_t n, const msm_opts* opts
   return n == ctx->n_points && n >= 4096;
 }
 
+// entry indices of a merged window (one per table row and GLV half) travel in 31 bits of the sort's payloads
+static bool tables_addressable(const msm_ctx* ctx, uint64_t n, int K) {
+  return (uint64_t)K * (ctx->is_te() ? n : 2 * n) < (1ull << 31);
+}
+
 // A short top window would pile its entries on the lowest buckets of the merged window (a 2-bit top window: an eighth of all
 // entries in four buckets): tables are built by default only for plans whose top window is about as wide as the others.
 static bool plan_suits_tables(const Plan& pl) {
@@ -95,7 +100,7 @@ int make_run_plan(msm_ctx* ctx, uint64_t n, const msm_opts* opts, bool placed, P
       const int asked = o.c;
       o.c = 0;
       if (make_plan(ctx, n, &o, pt, true) == MSM_OK && (asked == 0 || asked == pt.c) && plan_suits_tables(pt) &&
-          table_bytes(ctx, n, pt.K) <= ctx->tables_limit) {
+          table_bytes(ctx, n, pt.K) <= ctx->tables_limit && tables_addressable(ctx, n, pt.K)) {
         pl = pt;
         tables_wanted = true;
         return MSM_OK;
@@ -108,7 +113,7 @@ int make_run_plan(msm_ctx* ctx, uint64_t n, const msm_opts* opts, bool placed, P
 bool use_window_tables(msm_ctx* ctx, uint64_t n, const msm_opts* opts, const Plan& pl, bool may_build) {
   if (!tables_eligible(ctx, n, opts, false) || pl.K < 2) return false;
   if (ctx->tab_c == pl.c && ctx->tab_K == pl.K) return true;
-  if (!may_build || table_bytes(ctx, n, pl.K) > ctx->tables_limit) return false;
+  if (!may_build || table_bytes(ctx, n, pl.K) > ctx->tables_limit || !tables_addressable(ctx, n, pl.K)) return false;
   build_tables(ctx, pl);
   return true;
 }
