@@ -111,10 +111,9 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     // the digit kernel histograms ALL windows of the group over its slice of the points: four slices per CU
     long long mult = 4;
     MSM_KNOB(mult, "MSM_SORTB_MULT", 1);
-    // (on tables every digit window contributes its own slices to the one merged window: the same number of slices in all,
-    // k_colscan walks them one after the other)
-    const uint64_t per_window = pl.tables ? std::max<uint64_t>(1, (uint64_t)mult * ctx->n_cu / kc_d) : (uint64_t)mult * ctx->n_cu;
-    sortB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per_window, n / 4096));
+    // one slice per 4 096 points at least; the digit kernel wants a few blocks per CU whatever kc_d is, k_slice_scan walks
+    // the kc_d * sortB rows of the merged window with 32 lanes per column
+    sortB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)mult * ctx->n_cu, n / 4096));
     pps = (n + sortB - 1) / sortB;
     chunk = (te ? 1 : 2) * pps;
     ctx->ensure(w.block_hist, (size_t)kc_d * sortB * hb * 4 + 64);
@@ -162,7 +161,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     d_bin_start = d_bin_tot + V;
     ctx->ensure(w.rec, n_entries * 8);
     // (on tables the slices of all kc_d digit windows are the slices of the one merged window, in the same row order)
-    hipLaunchKernelGGL(k_colscan, dim3((V + 255) / 256), dim3(256), 0, s, (uint32_t*)w.block_hist.p, d_bin_tot,
+    hipLaunchKernelGGL(k_slice_scan, dim3((hb + 31) / 32, kc), dim3(1024), 0, s, (uint32_t*)w.block_hist.p, d_bin_tot,
                        pl.tables ? sortB * (uint32_t)kc_d : sortB, hb, (uint32_t)kc);
     hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_bin_start, (const uint32_t*)d_bin_tot, V);
     hipLaunchKernelGGL(k_bin_split, dim3(sortB, kc_d), dim3(BS_THREADS), bin_split_lds(hb), s, (uint2*)w.rec.p,

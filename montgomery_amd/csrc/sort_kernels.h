@@ -584,6 +584,56 @@ __device__ __forceinline__ uint32_t bucket_scan(uint32_t NB, uint32_t* lds_wave,
 #define MSM_BS_PREFETCH 0
 #endif
 constexpr int BS_THREADS = MSM_BS_THREADS, BS_ITEMS = MSM_BS_ITEMS, BS_TILE = BS_THREADS * BS_ITEMS;
+// k_colscan for the bin split's slice histograms: few columns (the coarse bins of the group), many rows (one per slice -- on
+// window tables kc times as many).  k_colscan walks a column with one thread: B latencies in sequence (0.5 ms for 8 192 rows).
+// Here 32 row lanes share a column: each sums a contiguous range of the rows, the 32 sums are scanned in the LDS, and each lane
+// walks its range a second time writing the exclusive prefixes.  grid (ceil(L / 32), k_cnt), 1024 threads.
+__global__ void __launch_bounds__(1024) k_slice_scan(uint32_t* block_hist, uint32_t* totals, uint32_t B, uint32_t L, uint32_t k_cnt)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
+  __shared__ uint32_t part[32][33];
+  const uint32_t c = threadIdx.x & 31u, r = threadIdx.x >> 5, kk = blockIdx.y;
+  const uint32_t l = blockIdx.x * 32 + c;
+  const bool live = l < L;
+  const uint32_t b0 = (uint32_t)((uint64_t)B * r / 32), b1 = (uint32_t)((uint64_t)B * (r + 1) / 32);
+  uint32_t* p = block_hist + (uint64_t)kk * B * L + (live ? l : 0);
+  uint32_t sum = 0;
+  if (live) {
+    uint32_t b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = p[(uint64_t)(b + i) * L];
+#pragma unroll
+      for (int i = 0; i < 8; i++) sum += v[i];
+    }
+    for (; b < b1; b++) sum += p[(uint64_t)b * L];
+  }
+  part[r][c] = sum;
+  __syncthreads();
+  uint32_t run = 0;
+  for (uint32_t q = 0; q < r; q++) run += part[q][c];
+  if (live) {
+    uint32_t b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = p[(uint64_t)(b + i) * L];
+#pragma unroll
+      for (int i = 0; i < 8; i++) { p[(uint64_t)(b + i) * L] = run; run += v[i]; }
+    }
+    for (; b < b1; b++) {
+      const uint32_t v = p[(uint64_t)b * L];
+      p[(uint64_t)b * L] = run;
+      run += v;
+    }
+    if (r == 31) totals[(uint64_t)kk * L + l] = run;
+  }
+}
+#endif
+
 constexpr uint32_t BS_MAX_AB = 11, BS_MAX_FB = 12;
 inline size_t bin_split_lds(uint32_t hb) { return (size_t)BS_TILE * 8 + (size_t)3 * hb * 4 + 64 * 4; }
 
