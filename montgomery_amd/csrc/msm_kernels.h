@@ -627,29 +627,61 @@ constexpr int BT_THREADS = 64;
 // amdgpu_waves_per_eu(1, 1): one wave per SIMD.  The work is a chain of dependent additions per wave; a second wave on
 // the same SIMD halves the speed of both, and the dispatcher fills a SIMD before it moves to the next one (measured:
 // 40 us per addition in sequence with two resident waves against 19 us alone).
-template <class CV>
-__global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_bit_tree(uint32_t* out, const uint32_t* rows, const uint32_t* tris,
-                                                         uint32_t n_in, uint32_t nbits, int masked, int pack_out,
-                                                         uint32_t nblk_out) {
-  using F = typename CV::F;
-  constexpr int NL = F::NL, NW = F::NW, NP = F::NW / 4;
-  __shared__ uint32_t lds[3 * NL * BT_THREADS];
+// What a kind of point must offer the bit tree: raw words (limb w of the point as it sits in registers), the group addition,
+// and the packed window sum the host reads.
+template <class F>
+struct ProjPT {
+  using P = Proj<F>;
+  static constexpr int W = 3 * F::NL;     // raw words per point between the reduction kernels
+  static constexpr int PW = PART_WORDS;   // words of a packed window sum
+  static MSM_DEV void zero(P& p) { proj_set_zero<F>(p); }
+  static MSM_DEV void add(P& r, const P& a, const P& b) { proj_add<F>(r, a, b); }
+  static MSM_DEV uint32_t& word(P& p, int w) { return w < F::NL ? p.X.l[w] : w < 2 * F::NL ? p.Y.l[w - F::NL] : p.Z.l[w - 2 * F::NL]; }
+  static MSM_DEV void pack(uint32_t* dst, P& acc) {
+    constexpr int NW = F::NW;
+    fe_reduce_2p<F>(acc.X);
+    fe_reduce_2p<F>(acc.Y);
+    fe_reduce_2p<F>(acc.Z);
+    uint32_t w[NW];
+#pragma unroll
+    for (int j = 0; j < PART_WORDS; j++) dst[j] = 0;
+    fe_pack<F>(w, acc.X);
+#pragma unroll
+    for (int j = 0; j < NW; j++) dst[j] = w[j];
+    fe_pack<F>(w, acc.Y);
+#pragma unroll
+    for (int j = 0; j < NW; j++) dst[12 + j] = w[j];
+    fe_pack<F>(w, acc.Z);
+#pragma unroll
+    for (int j = 0; j < NW; j++) dst[24 + j] = w[j];
+  }
+};
+
+// the body of k_bit_tree / k_te_bit_tree (see above); one wave per block
+template <class PT>
+MSM_DEV void bit_tree_body(uint32_t* out, const uint32_t* rows, const uint32_t* tris, uint32_t n_in, uint32_t nbits, int masked,
+                           int pack_out, uint32_t nblk_out, uint32_t* lds) {
+  using P = typename PT::P;
+  constexpr int W = PT::W;
   // First stage (masked): grid.x enumerates, per window, nbits masked sums of nblk_out / 2 blocks each and then the
   // triangle sum of nblk_out blocks -- the masked sums have half as many elements, so every wave of the launch has
-  // the same number of additions in sequence.  The unused upper half of a masked sum's block slots in `out` is
-  // zero-filled (= the identity) by the host.  Second stage: grid (1, nbits + 1, kc).
+  // the same number of additions in sequence.  Second stage (masked == 2): grid (1, nbits + 1, kc).
   uint32_t blk = blockIdx.x, y = blockIdx.y, nblk = gridDim.x;
   const uint32_t kk = blockIdx.z, tid = threadIdx.x;
-  if (masked) {
+  if (masked == 1) {
     const uint32_t half = nblk_out >> 1;
     if (blk < nbits * half) { y = blk / half; blk -= y * half; nblk = half; }
     else { blk -= nbits * half; y = nbits; nblk = nblk_out; }
   }
-  const bool sel = masked && y < nbits;              // n_in = 2^nbits on the masked stage
-  const uint32_t count = sel ? n_in >> 1 : n_in;
+  // masked == 1: first stage.  masked == 2: second stage over the first stage's block sums -- a masked sum filled only the
+  // first half of its nblk_out slots (the rest is never written, never read: all-zero words are the identity of a projective
+  // point but not of an extended Edwards one).  masked == 0: plain sums of n_in points.
+  const bool sel = masked == 1 && y < nbits;         // n_in = 2^nbits on the masked stage
+  const uint32_t count = (sel || (masked == 2 && y < nbits)) ? n_in >> 1 : n_in;
+  if (masked == 2) masked = 0;
   const uint32_t span = (count + nblk - 1) / nblk;
   const uint32_t beg = min(blk * span, count), end = min(beg + span, count);
-  // first stage: planar arrays [kk][39][n_in] written by k_bucket_reduce; second stage: [kk][y][n_in] points of 39 words
+  // first stage: planar arrays [kk][W][n_in] written by the bucket-reduce kernel; second stage: [kk][y][n_in] points of W words
   const uint64_t base = ((uint64_t)kk * (nbits + 1) + y) * n_in;
   const uint32_t* src = (masked && y == nbits) ? tris : rows;
   // Every lane takes part in every addition: a wave whose EXEC mask is down to a few lanes runs this arithmetic
@@ -661,60 +693,53 @@ __global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu
   uint32_t m = 1;
   while (m < n_el && m < BT_THREADS) m <<= 1;
   const uint32_t gl = tid & (m - 1);
-  Proj<F> acc;
-  proj_set_zero<F>(acc);
+  P acc;
+  PT::zero(acc);
 #pragma unroll 1
   for (uint32_t i = beg + gl; i < end; i += m) {
     // i-th index with bit y set: insert a one at bit position y
     const uint32_t j = sel ? ((((i >> y) << 1) | 1u) << y) | (i & ((1u << y) - 1u)) : i;
-    Proj<F> Q;
-    if (masked) proj_load_planar(Q, src + (uint64_t)kk * (3 * NL) * n_in, n_in, j);
-    else proj_load(Q, src + (base + j) * (3 * NL));
-    proj_add<F>(acc, acc, Q);
+    P Q;
+    if (masked) {
+      const uint32_t* pl = src + (uint64_t)kk * W * n_in;
+#pragma unroll
+      for (int w = 0; w < W; w++) PT::word(Q, w) = pl[(uint64_t)w * n_in + j];
+    } else {
+      const uint32_t* pp = src + (base + j) * W;
+#pragma unroll
+      for (int w = 0; w < W; w++) PT::word(Q, w) = pp[w];
+    }
+    PT::add(acc, acc, Q);
   }
 #pragma unroll 1
   for (uint32_t s = m >> 1; s >= 1; s >>= 1) {
 #pragma unroll
-    for (int l = 0; l < NL; l++) {
-      lds[(l)*BT_THREADS + tid] = acc.X.l[l];
-      lds[(NL + l) * BT_THREADS + tid] = acc.Y.l[l];
-      lds[(2 * NL + l) * BT_THREADS + tid] = acc.Z.l[l];
-    }
+    for (int w = 0; w < W; w++) lds[w * BT_THREADS + tid] = PT::word(acc, w);
     __syncthreads();
     const uint32_t partner = (tid & ~(m - 1)) | ((gl + s) & (m - 1));
-    Proj<F> Q;
+    P Q;
 #pragma unroll
-    for (int l = 0; l < NL; l++) {
-      Q.X.l[l] = lds[(l)*BT_THREADS + partner];
-      Q.Y.l[l] = lds[(NL + l) * BT_THREADS + partner];
-      Q.Z.l[l] = lds[(2 * NL + l) * BT_THREADS + partner];
-    }
+    for (int w = 0; w < W; w++) PT::word(Q, w) = lds[w * BT_THREADS + partner];
     __syncthreads();
-    proj_add<F>(acc, acc, Q);
+    PT::add(acc, acc, Q);
   }
   if (tid == 0) {
     const uint64_t o = ((uint64_t)kk * (nbits + 1) + y) * nblk_out + blk;
     if (!pack_out) {
-      proj_store(out + o * (3 * NL), acc);
+#pragma unroll
+      for (int w = 0; w < W; w++) out[o * W + w] = PT::word(acc, w);
     } else {
-      fe_reduce_2p<F>(acc.X);
-      fe_reduce_2p<F>(acc.Y);
-      fe_reduce_2p<F>(acc.Z);
-      uint32_t* dst = out + o * PART_WORDS;
-      uint32_t w[NW];
-#pragma unroll
-      for (int j = 0; j < PART_WORDS; j++) dst[j] = 0;
-      fe_pack<F>(w, acc.X);
-#pragma unroll
-      for (int j = 0; j < NW; j++) dst[j] = w[j];
-      fe_pack<F>(w, acc.Y);
-#pragma unroll
-      for (int j = 0; j < NW; j++) dst[12 + j] = w[j];
-      fe_pack<F>(w, acc.Z);
-#pragma unroll
-      for (int j = 0; j < NW; j++) dst[24 + j] = w[j];
+      PT::pack(out + o * PT::PW, acc);
     }
   }
+}
+
+template <class CV>
+__global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_bit_tree(uint32_t* out, const uint32_t* rows, const uint32_t* tris,
+                                                         uint32_t n_in, uint32_t nbits, int masked, int pack_out,
+                                                         uint32_t nblk_out) {
+  __shared__ uint32_t lds[ProjPT<typename CV::F>::W * BT_THREADS];
+  bit_tree_body<ProjPT<typename CV::F>>(out, rows, tris, n_in, nbits, masked, pack_out, nblk_out, lds);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -65,32 +65,46 @@ void reduce_buckets(msm_ctx* ctx, msm_ctx::Workspace& w, const uint4* fin, uint6
   // bit-sliced weighting (Weierstrass path, enough chunks to matter, TC a power of two)
   uint32_t nbits = 0;
   while ((1u << nbits) < nchunks) nbits++;
-  const bool bit_sliced = !te && nchunks >= 64 && (TC & (TC - 1)) == 0;
+  // bit-sliced weighting (enough chunks to matter, TC a power of two)
+  // (the host finishes every window with ~2 c additions and doublings: on the Edwards path, whose plain plans have 13 - 28
+  // windows, that tail costs more than the weighting chains it replaces -- 0.28 against 0.05 ms at 2^20 -- so it takes the
+  // bit-sliced form only for the one or two merged windows of a run on window tables)
+  const bool bit_sliced = nchunks >= 64 && (TC & (TC - 1)) == 0 && (!te || kc <= 2);
+  const size_t raw_words = te ? (size_t)4 * te::TL : (size_t)3 * NL;   // raw limb words of one point between the reduction kernels
   ctx->ensure(w.columns, (size_t)kc * nchunks * 4 * NL * 4);
   ctx->ensure(w.partials, (size_t)kc * 36 * 4);
   {
     uint32_t threads = nchunks * (uint32_t)kc;
-    if (te) {
-      hipLaunchKernelGGL(te::k_te_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, fin, fin_cap,
-                         off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
-      hipLaunchKernelGGL(te::k_te_window_sum, dim3(kc), dim3(te::TE_WS_THREADS), 0, s, (uint32_t*)w.partials.p,
-                         (const uint32_t*)w.columns.p, nchunks);
-    } else if (bit_sliced) {
-      ctx->ensure(w.rows_sum, (size_t)kc * nchunks * 3 * NL * 4);
-      W_LAUNCH(ctx, k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p,
-                         (uint32_t*)w.rows_sum.p, fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
+    if (bit_sliced) {
+      ctx->ensure(w.rows_sum, (size_t)kc * nchunks * raw_words * 4);
+      if (te)
+        hipLaunchKernelGGL(te::k_te_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, (uint32_t*)w.rows_sum.p,
+                           fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
+      else
+        W_LAUNCH(ctx, k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p,
+                           (uint32_t*)w.rows_sum.p, fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
       // first stage: one wave per 512 elements (8 per lane; at 2^20 that is about one wave per SIMD) -- the masked sums
       // have half as many elements as the triangle sum and get half as many blocks; second stage: one wave per
-      // (window, bit) over the block sums (unused block slots stay zero = the identity)
+      // (window, bit) over the block sums it finds (the slots a masked sum did not fill are never read)
       const uint32_t nblk = std::max<uint32_t>(2, nchunks / (8 * BT_THREADS));
-      const size_t c2_bytes = (size_t)kc * (nbits + 1) * nblk * 3 * NL * 4;
-      ctx->ensure(w.columns2, c2_bytes);
+      ctx->ensure(w.columns2, (size_t)kc * (nbits + 1) * nblk * raw_words * 4);
       ctx->ensure(w.partials, (size_t)kc * (nbits + 1) * 36 * 4);
-      HIPCHK(hipMemsetAsync(w.columns2.p, 0, c2_bytes, s));
-      W_LAUNCH(ctx, k_bit_tree, dim3(nbits * (nblk / 2) + nblk, 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.columns2.p,
-                         (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, nbits, 1, 0, nblk);
-      W_LAUNCH(ctx, k_bit_tree, dim3(1, nbits + 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.partials.p,
-                         (const uint32_t*)w.columns2.p, (const uint32_t*)nullptr, nblk, nbits, 0, 1, 1u);
+      if (te) {
+        hipLaunchKernelGGL(te::k_te_bit_tree, dim3(nbits * (nblk / 2) + nblk, 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.columns2.p,
+                           (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, nbits, 1, 0, nblk);
+        hipLaunchKernelGGL(te::k_te_bit_tree, dim3(1, nbits + 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.partials.p,
+                           (const uint32_t*)w.columns2.p, (const uint32_t*)nullptr, nblk, nbits, 2, 1, 1u);
+      } else {
+        W_LAUNCH(ctx, k_bit_tree, dim3(nbits * (nblk / 2) + nblk, 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.columns2.p,
+                           (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, nbits, 1, 0, nblk);
+        W_LAUNCH(ctx, k_bit_tree, dim3(1, nbits + 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.partials.p,
+                           (const uint32_t*)w.columns2.p, (const uint32_t*)nullptr, nblk, nbits, 2, 1, 1u);
+      }
+    } else if (te) {
+      hipLaunchKernelGGL(te::k_te_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, (uint32_t*)nullptr,
+                         fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
+      hipLaunchKernelGGL(te::k_te_window_sum, dim3(kc), dim3(te::TE_WS_THREADS), 0, s, (uint32_t*)w.partials.p,
+                         (const uint32_t*)w.columns.p, nchunks);
     } else {
       W_LAUNCH(ctx, k_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, (uint32_t*)nullptr,
                          fin, fin_cap, off_fin, bucket_proj, L, TC, nchunks, (uint32_t)kc);
@@ -111,50 +125,67 @@ void reduce_buckets(msm_ctx* ctx, msm_ctx::Workspace& w, const uint4* fin, uint6
   }
   if (bit_sliced) {
     // read the (nbits + 1) sums per window back and finish P_k = tri + TC * sum_b 2^b S_b on the host
-    HIPCHK(hipMemcpyAsync(w.h_part, w.partials.p, (size_t)kc * (nbits + 1) * 36 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(w.h_part, w.partials.p, (size_t)kc * (nbits + 1) * part_words * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(w.ev[4], s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
-    const auto& C = ctx->hc;
-    if (merged) {
-      // The caller only wants S_g = sum_kk 2^(c kk) P_kk of the whole group (a full MSM on this device: the Horner step over
-      // the windows follows anyway).  One double-and-add pass over the c kc bit positions then does both jobs -- inside window
-      // kk the sum S_b sits at bit log2(TC) + b, the triangle sum at bit 0 -- with c kc doublings instead of (c - 1) kc for
-      // the windows plus c (kc - 1) for their combination.  S_g goes into the slot of the group's first window, the identity
-      // into the others: sum_k 2^(c k) (slot k) is the same group element as with one P_k per slot.
-      // With a folded top window (Plan::fold) a window has one bit position more than it advances by: position `stride` of
-      // window kk coincides with position 0 of window kk + 1, so the pass walks GLOBAL bit positions and adds what every
-      // window has there.
-      uint32_t lt = 0, cbits = 1;
-      while ((1u << lt) < TC) lt++;
-      while ((1u << (cbits - 1)) < L) cbits++;
-      const int adv = stride ? stride : (int)cbits;
-      msm_host::Proj6 acc = C.zero();
-      for (int gpos = (kc - 1) * adv + (int)cbits - 1; gpos >= 0; gpos--) {
-        acc = C.dbl(acc);
-        for (int kk = kc - 1; kk >= 0; kk--) {
-          const int pos = gpos - kk * adv;
-          if (pos < 0 || pos >= (int)cbits) continue;
-          const uint32_t* base = w.h_part + (size_t)kk * (nbits + 1) * 36;
-          const int b = pos - (int)lt;
-          if (b >= 0 && b < (int)nbits) acc = C.add(acc, partial_to_host(ctx, base + (size_t)b * 36));
-          if (pos == 0) acc = C.add(acc, partial_to_host(ctx, base + (size_t)nbits * 36));
+    uint32_t lt = 0, cbits = 1;
+    while ((1u << lt) < TC) lt++;
+    while ((1u << (cbits - 1)) < L) cbits++;
+    const int adv = stride ? stride : (int)cbits;
+    // one implementation for both kinds of point: zero, doubling, addition, a packed sum in, a packed sum out
+    auto finish = [&](auto zero, auto dbl, auto add, auto from_part, auto to_part, auto ident_part) {
+      if (merged) {
+        // The caller only wants S_g = sum_kk 2^(c kk) P_kk of the whole group (a full MSM on this device: the Horner step over
+        // the windows follows anyway).  One double-and-add pass over the c kc bit positions then does both jobs -- inside window
+        // kk the sum S_b sits at bit log2(TC) + b, the triangle sum at bit 0 -- with c kc doublings instead of (c - 1) kc for
+        // the windows plus c (kc - 1) for their combination.  S_g goes into the slot of the group's first window, the identity
+        // into the others: sum_k 2^(c k) (slot k) is the same group element as with one P_k per slot.
+        // With a folded top window (Plan::fold) a window has one bit position more than it advances by: position `stride` of
+        // window kk coincides with position 0 of window kk + 1, so the pass walks GLOBAL bit positions and adds what every
+        // window has there.
+        auto acc = zero();
+        for (int gpos = (kc - 1) * adv + (int)cbits - 1; gpos >= 0; gpos--) {
+          acc = dbl(acc);
+          for (int kk = kc - 1; kk >= 0; kk--) {
+            const int pos = gpos - kk * adv;
+            if (pos < 0 || pos >= (int)cbits) continue;
+            const uint32_t* base = w.h_part + (size_t)kk * (nbits + 1) * part_words;
+            const int b = pos - (int)lt;
+            if (b >= 0 && b < (int)nbits) acc = add(acc, from_part(base + (size_t)b * part_words));
+            if (pos == 0) acc = add(acc, from_part(base + (size_t)nbits * part_words));
+          }
         }
+        for (int kk = 1; kk < kc; kk++) ident_part(h_partials_out + (size_t)kk * part_words);
+        to_part(acc, h_partials_out);
+        return;
       }
-      memset(h_partials_out, 0, (size_t)kc * 36 * 4);
-      host_to_partial(ctx, acc, h_partials_out);
-      return;
-    }
-    for (int kk = 0; kk < kc; kk++) {
-      const uint32_t* base = w.h_part + (size_t)kk * (nbits + 1) * 36;
-      msm_host::Proj6 acc = C.zero();
-      for (int b = (int)nbits - 1; b >= 0; b--) {
-        acc = C.dbl(acc);
-        acc = C.add(acc, partial_to_host(ctx, base + (size_t)b * 36));
+      for (int kk = 0; kk < kc; kk++) {
+        const uint32_t* base = w.h_part + (size_t)kk * (nbits + 1) * part_words;
+        auto acc = zero();
+        for (int b = (int)nbits - 1; b >= 0; b--) {
+          acc = dbl(acc);
+          acc = add(acc, from_part(base + (size_t)b * part_words));
+        }
+        for (uint32_t t = TC; t > 1; t >>= 1) acc = dbl(acc);   // TC is a power of two on this path
+        acc = add(acc, from_part(base + (size_t)nbits * part_words));
+        to_part(acc, h_partials_out + (size_t)kk * part_words);
       }
-      for (uint32_t t = TC; t > 1; t >>= 1) acc = C.dbl(acc);   // TC is a power of two on this path
-      acc = C.add(acc, partial_to_host(ctx, base + (size_t)nbits * 36));
-      host_to_partial(ctx, acc, h_partials_out + (size_t)kk * 36);
+    };
+    if (te) {
+      const auto& C = ctx->hte;
+      finish([&] { return C.zero(); }, [&](const msm_host::Ext6& a) { return C.add(a, a); },
+             [&](const msm_host::Ext6& a, const msm_host::Ext6& b) { return C.add(a, b); },
+             [&](const uint32_t* p) { return te_partial_to_host(ctx, p); },
+             [&](const msm_host::Ext6& a, uint32_t* out) { te_host_to_partial(ctx, a, out); },
+             [&](uint32_t* out) { te_host_to_partial(ctx, C.zero(), out); });
+    } else {
+      const auto& C = ctx->hc;
+      finish([&] { return C.zero(); }, [&](const msm_host::Proj6& a) { return C.dbl(a); },
+             [&](const msm_host::Proj6& a, const msm_host::Proj6& b) { return C.add(a, b); },
+             [&](const uint32_t* p) { return partial_to_host(ctx, p); },
+             [&](const msm_host::Proj6& a, uint32_t* out) { host_to_partial(ctx, a, out); },
+             [&](uint32_t* out) { memset(out, 0, 36 * 4); });
     }
     return;
   }

@@ -164,9 +164,11 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     hipLaunchKernelGGL(k_slice_scan, dim3((hb + 31) / 32, kc), dim3(1024), 0, s, (uint32_t*)w.block_hist.p, d_bin_tot,
                        pl.tables ? sortB * (uint32_t)kc_d : sortB, hb, (uint32_t)kc);
     hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_bin_start, (const uint32_t*)d_bin_tot, V);
-    hipLaunchKernelGGL(k_bin_split, dim3(sortB, kc_d), dim3(BS_THREADS), bin_split_lds(hb), s, (uint2*)w.rec.p,
+    // a block of pass A takes as many consecutive slices of the digit kernel as make two tiles
+    const uint32_t per_block = (uint32_t)std::min<uint64_t>(sortB, std::max<uint64_t>(1, (2 * (uint64_t)BS_TILE + chunk - 1) / chunk));
+    hipLaunchKernelGGL(k_bin_split, dim3((sortB + per_block - 1) / per_block, kc_d), dim3(BS_THREADS), bin_split_lds(hb), s, (uint2*)w.rec.p,
                        (const uint32_t*)d_bin_start, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n_d, chunk, hb, ws,
-                       pl.tables ? 1u : 0u);
+                       pl.tables ? 1u : 0u, sortB, per_block);
     HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));
     hipLaunchKernelGGL(k_bin_count, dim3(V), dim3(256), (size_t)nbmax * 4, s, (uint32_t*)w.counts.p, (const uint32_t*)d_bin_start,
                        (const uint2*)w.rec.p, hb, L, ws);

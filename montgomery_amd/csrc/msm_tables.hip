@@ -91,9 +91,9 @@ int make_run_plan(msm_ctx* ctx, uint64_t n, const msm_opts* opts, bool placed, P
         }
       }
     }
-    // none yet (or others): a call with the default plan on an endomorphism curve may build them if they fit the limit --
+    // none yet (or others): a call with the default plan may build them if they fit the limit --
     // opts->c == 0, or the very window the library would pick (a facade that asks msm_plan first and hands its answer back)
-    if (!(opts && opts->no_glv) && !ctx->is_te()) {
+    if (!(opts && opts->no_glv)) {
       Plan pt;
       msm_opts o;
       if (opts) o = *opts; else memset(&o, 0, sizeof o);

@@ -641,9 +641,11 @@ inline size_t bin_split_lds(uint32_t hb) { return (size_t)BS_TILE * 8 + (size_t)
 // starts at bin_start[kk * hb + h]; this slice's share of it slice_off[(kk * SB + b) * hb + h] further.
 // merged (window tables: the kc digit windows of the group are ONE window of kc * two_n entries for the sort): every block
 // works for window 0, its slice is number kk * SB + b of that window, and entry indices count from the group's first digit.
+// The histograms come per slice of the DIGIT kernel (SBd of them per window, `chunk` entries each); a block of this pass takes
+// g consecutive ones, so that small inputs -- whose digit kernel still wants a block per 4 096 points -- sort whole tiles.
 __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint32_t* bin_start, const uint32_t* slice_off,
                                                           const uint32_t* dig, uint64_t two_n, uint64_t chunk, uint32_t hb, WinSplit ws,
-                                                          uint32_t merged)
+                                                          uint32_t merged, uint32_t SBd, uint32_t g)
 #ifndef MSM_SORT_TU
     ;
 #else
@@ -654,12 +656,12 @@ __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint
   uint32_t* t_start = t_cnt + hb;
   uint32_t* g_base = t_start + hb;
   uint32_t* lds_wave = g_base + hb;                       // 64 words
-  const uint32_t b = blockIdx.x, seg = blockIdx.y, SB = gridDim.x, tid = threadIdx.x;
+  const uint32_t b = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x;
   const uint32_t kk = merged ? 0u : seg;
   const uint32_t ab = ws.ab[kk], fb = ws.fb[kk], HN = 1u << ab;
   for (uint32_t h = tid; h < HN; h += BS_THREADS)
-    g_base[h] = bin_start[(uint64_t)kk * hb + h] + slice_off[((uint64_t)seg * SB + b) * hb + h];
-  const uint64_t beg = (uint64_t)b * chunk, end = min(beg + chunk, two_n);
+    g_base[h] = bin_start[(uint64_t)kk * hb + h] + slice_off[((uint64_t)seg * SBd + (uint64_t)b * g) * hb + h];
+  const uint64_t beg = (uint64_t)b * g * chunk, end = min(beg + (uint64_t)g * chunk, two_n);
   const uint32_t* d = dig + (uint64_t)seg * two_n;
   const uint32_t e_base = merged ? (uint32_t)((uint64_t)seg * two_n) : 0u;
   const uint32_t fmask = (1u << fb) - 1;

@@ -445,9 +445,11 @@ __global__ void __launch_bounds__(256) k_te_bucket_finish(uint32_t* bucket_ext, 
 }
 #endif
 
-__global__ void __launch_bounds__(64) k_te_bucket_reduce(uint32_t* columns, const uint4* fin, uint64_t fin_cap, const uint32_t* off_fin,
-                                                          const uint32_t* bucket_ext, uint32_t L, uint32_t TC, uint32_t nchunks,
-                                                          uint32_t k_cnt)
+// rows != nullptr: bit-sliced mode, as k_bucket_reduce (msm_kernels.h) -- the chunk's plain sum goes to rows, its local
+// triangle to columns, both planar ([window][word][chunk]); the weight ch * TC is applied through per-bit sums (k_te_bit_tree)
+__global__ void __launch_bounds__(64) k_te_bucket_reduce(uint32_t* columns, uint32_t* rows, const uint4* fin, uint64_t fin_cap,
+                                                          const uint32_t* off_fin, const uint32_t* bucket_ext, uint32_t L, uint32_t TC,
+                                                          uint32_t nchunks, uint32_t k_cnt)
 #ifndef MSM_TE_TU
     ;
 #else
@@ -477,6 +479,18 @@ __global__ void __launch_bounds__(64) k_te_bucket_reduce(uint32_t* columns, cons
     }
     te_add(tri, tri, row);
   }
+  if (rows) {
+    uint32_t* rp = rows + (uint64_t)kk * (4 * TL) * nchunks;
+    uint32_t* cp = columns + (uint64_t)kk * (4 * TL) * nchunks;
+#pragma unroll
+    for (int l = 0; l < TL; l++) {
+      rp[(uint64_t)l * nchunks + ch] = row.X.l[l]; rp[(uint64_t)(TL + l) * nchunks + ch] = row.Y.l[l];
+      rp[(uint64_t)(2 * TL + l) * nchunks + ch] = row.Z.l[l]; rp[(uint64_t)(3 * TL + l) * nchunks + ch] = row.T.l[l];
+      cp[(uint64_t)l * nchunks + ch] = tri.X.l[l]; cp[(uint64_t)(TL + l) * nchunks + ch] = tri.Y.l[l];
+      cp[(uint64_t)(2 * TL + l) * nchunks + ch] = tri.Z.l[l]; cp[(uint64_t)(3 * TL + l) * nchunks + ch] = tri.T.l[l];
+    }
+    return;
+  }
   uint32_t ls = lstart - 1;
   if (ls) {
 #pragma unroll 1
@@ -488,6 +502,43 @@ __global__ void __launch_bounds__(64) k_te_bucket_reduce(uint32_t* columns, cons
     }
   }
   ext_store_raw(columns + (uint64_t)id * (4 * TL), tri);
+}
+#endif
+
+// the bit tree of msm_kernels.h over extended Edwards points (X, Y, Z, T: 4 x 9 limbs; packed sums: 4 x 8 words)
+struct TePT {
+  using P = Ext;
+  static constexpr int W = 4 * TL;
+  static constexpr int PW = 32;
+  static MSM_DEV void zero(P& p) { te_set_identity(p); }
+  static MSM_DEV void add(P& r, const P& a, const P& b) { te_add(r, a, b); }
+  static MSM_DEV uint32_t& word(P& p, int w) { return w < TL ? p.X.l[w] : w < 2 * TL ? p.Y.l[w - TL] : w < 3 * TL ? p.Z.l[w - 2 * TL] : p.T.l[w - 3 * TL]; }
+  static MSM_DEV void pack(uint32_t* dst, P& acc) {
+    uint32_t w[TW];
+    fe_pack<FT>(w, acc.X);
+#pragma unroll
+    for (int j = 0; j < TW; j++) dst[j] = w[j];
+    fe_pack<FT>(w, acc.Y);
+#pragma unroll
+    for (int j = 0; j < TW; j++) dst[8 + j] = w[j];
+    fe_pack<FT>(w, acc.Z);
+#pragma unroll
+    for (int j = 0; j < TW; j++) dst[16 + j] = w[j];
+    fe_pack<FT>(w, acc.T);
+#pragma unroll
+    for (int j = 0; j < TW; j++) dst[24 + j] = w[j];
+  }
+};
+
+__global__ void __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_te_bit_tree(uint32_t* out, const uint32_t* rows,
+                                                         const uint32_t* tris, uint32_t n_in, uint32_t nbits, int masked,
+                                                         int pack_out, uint32_t nblk_out)
+#ifndef MSM_TE_TU
+    ;
+#else
+{
+  __shared__ uint32_t lds[TePT::W * BT_THREADS];
+  bit_tree_body<TePT>(out, rows, tris, n_in, nbits, masked, pack_out, nblk_out, lds);
 }
 #endif
 

@@ -239,9 +239,10 @@ def test_two_rank_bench_launches_itself():
     assert d["config"]["workload"] == "bls12-377-g1-msm-2^20" and "window-shard x2" in d["config"]["parallelism"]
     assert d["split"] == "windows" and [r["shard"] for r in d["ranks"]] == [[0, 4], [4, 8]]
     assert all("phase_ms" in r and r["all_gather_ms"] is not None for r in d["ranks"])
-    (o,) = d["other_splits"]
-    assert o["split"] == "points" and o["verified"] is True and o["value"] > 0
-    assert [r["shard"] for r in o["ranks"]] == [[0, 1 << 19], [1 << 19, 1 << 19]]
+    others = {o["split"]: o for o in d["other_splits"]}
+    assert set(others) == {"points", "buckets"} and all(o["verified"] is True and o["value"] > 0 for o in others.values())
+    assert [r["shard"] for r in others["points"]["ranks"]] == [[0, 1 << 19], [1 << 19, 1 << 19]]
+    assert [r["shard"] for r in others["buckets"]["ranks"]] == [[0, 2], [1, 2]]   # rank g of G: its part of every window's buckets
 
 
 def test_bench_refuses_a_world_size_other_than_gpus():

@@ -105,20 +105,17 @@ def test_limit_reserve_and_point_sets(gpu_ctx):
 
 
 def test_edwards_and_other_curves_on_tables():
-    """The Edwards path builds tables only when asked to (msm_precompute); BLS12-381 and Pallas by default."""
+    """All four curves build tables by default; the Edwards path finishes the merged window's sums bit-sliced."""
     from montgomery_amd import _lib
     from montgomery_amd.api import MsmContext
 
     for curve, te in ((_lib.CURVE_ED_ON_BLS12_377, True), (_lib.CURVE_BLS12_381_G1, False), (_lib.CURVE_PALLAS, False)):
         ctx = MsmContext(curve)
-        n = 1 << 14
-        ctx.generate_points(n, seed=11)
-        dev, _ = ctx.generate_scalars(n, seed=12)
-        plain, ip = ctx.run_device(dev, n, no_tables=True)
-        if te:
-            assert not ctx.run_device(dev, n)[1]["tables"]
-            ctx.precompute()
-        got, it = ctx.run_device(dev, n)
         key = (lambda r: (r.x, r.y)) if te else (lambda r: r.as_tuple())
-        assert it["tables"] and not ip["tables"] and key(got) == key(plain), curve
+        for n in ((1 << 14), (1 << 18) + 77):
+            ctx.generate_points(n, seed=11)
+            dev, _ = ctx.generate_scalars(n, seed=12)
+            plain, ip = ctx.run_device(dev, n, no_tables=True)
+            got, it = ctx.run_device(dev, n)
+            assert it["tables"] and not ip["tables"] and key(got) == key(plain), (curve, n)
         ctx.close()
