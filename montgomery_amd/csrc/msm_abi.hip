@@ -1,6 +1,8 @@
 // The C ABI of include/msm_hip.h: contexts, resident point sets, msm_run / msm_window_sums / msm_combine, device buffers.
 // (reference interface replaced: Curve.Parallel.* of src/parallel.ts:135-145,251-259)
 #include "msm_internal.h"
+#include <chrono>
+#include <thread>
 
 using namespace msm;
 using namespace msmi;
@@ -67,6 +69,11 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
 void msm_ctx_destroy(msm_ctx* ctx) {
   if (!ctx) return;
   ctx->fan.clear();
+  if (ctx->twin) {
+    ctx->twin->rows = DevBuf{};   // borrowed
+    msm_ctx_destroy(ctx->twin);
+    ctx->twin = nullptr;
+  }
   for (msm_ctx* c : ctx->children) msm_ctx_destroy(c);
   ctx->children.clear();
   (void)hipSetDevice(ctx->device);
@@ -269,38 +276,97 @@ static int run_piped(msm_ctx* ctx, const void* scalars, uint64_t n, const msm_op
     for (int sh : shifts) piece_end.push_back(((n >> sh) / gran) * gran);
     piece_end.push_back(n);
     ctx->ensure(ctx->scal, n * 32);   // before any workspace is sized from what the device has free
+    // Consecutive ranges run on two pipelines of the device, even ones on this context, odd ones on its twin: a range starts when
+    // its scalars are there and the range two before it is done, so the head of one sub-MSM (digits and sort, which no tree of its
+    // own hides) and the tail of its predecessor (last tree rounds on a few CUs, bucket reduction, read-backs) share the chip.
+    // Measured at 2^26: 160.3 -> see profiles/r05_experiments.txt item 10.
+    long long want_twin = 1;
+    MSM_KNOB(want_twin, "MSM_PIPE_TWIN", 0);
+    if (want_twin && !ctx->twin) {
+      msm_ctx* t = nullptr;
+      if (msm_ctx_create(&t, ctx->curve, ctx->device) != MSM_OK) return fail(ctx, MSM_ERR_HIP, "%s: no second pipeline on the device", who);
+      ctx->twin = t;
+    }
+    struct Borrow {   // the twin reads this context's point rows for the length of the call
+      msm_ctx *c, *t;
+      Borrow(msm_ctx* c_, msm_ctx* t_) : c(c_), t(t_) {
+        if (t) { t->rows = c->rows; t->n_points = c->n_points; t->tab_c = t->tab_K = 0; t->ws_limit = c->ws_limit; }
+      }
+      ~Borrow() { if (t) { t->rows = DevBuf{}; t->n_points = 0; } }
+    } borrow(ctx, want_twin ? ctx->twin : nullptr);
     std::vector<size_t> ends;
     for (uint64_t e : piece_end) ends.push_back((size_t)e * 32);
     PieceUpload pipe(ctx, ctx->scal.p, scalars, n * 32, ends);
     const uint32_t base_lo = opts ? opts->point_lo : 0;
-    msm_host::Proj6 acc = ctx->hc.zero();
-    uint64_t lo = 0;
-    for (size_t q = 0; q < piece_end.size(); q++) {
-      const uint64_t cnt = piece_end[q] - lo;
-      if (cnt == 0) continue;
-      pipe.wait_piece((int)q, ctx->stream);
-      HIPCHK(hipStreamSynchronize(ctx->stream));       // the range's scalars are in HBM
-      msm_opts o;
-      if (opts) o = *opts; else memset(&o, 0, sizeof o);
-      o.point_lo = base_lo + (uint32_t)lo;
+    const size_t Q = piece_end.size();
+    struct Range {
+      uint64_t lo = 0, cnt = 0;
       Plan pq;
-      if (make_plan(ctx, cnt, &o, pq)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);
-      pq.merged = true;
-      std::vector<uint32_t> words;
+      msm_opts o;
       msm_result st;
-      memset(&st, 0, sizeof st);
-      window_sums_impl(ctx, (const uint32_t*)ctx->scal.p + lo * 8, cnt, 1, &o, 0, pq.K, pq, words, &st, o.point_lo);
-      std::vector<msm_host::Proj6> P(pq.K);
-      for (int k = 0; k < pq.K; k++) P[k] = partial_to_host(ctx, &words[(size_t)k * 36]);
-      acc = ctx->hc.add(acc, horner_points(ctx->hc, P, pq.c));
-      for (int j = 0; j < MSM_N_PHASES; j++) out->phase_ms[j] += st.phase_ms[j];
-      out->n_pairs += st.n_pairs;
-      out->n_pairs_algo += st.n_pairs_algo;
-      out->rounds += st.rounds;
-      out->max_bucket = std::max(out->max_bucket, st.max_bucket);
-      out->c = pq.c;   // the plan of the last, biggest range
-      out->K = pq.K;
-      lo = piece_end[q];
+      std::vector<uint32_t> words;
+    };
+    std::vector<Range> R(Q);
+    for (size_t q = 0; q < Q; q++) {
+      R[q].lo = q ? piece_end[q - 1] : 0;
+      R[q].cnt = piece_end[q] - R[q].lo;
+      if (opts) R[q].o = *opts; else memset(&R[q].o, 0, sizeof(msm_opts));
+      R[q].o.point_lo = base_lo + (uint32_t)R[q].lo;
+      memset(&R[q].st, 0, sizeof(msm_result));
+      if (R[q].cnt && make_plan(ctx, R[q].cnt, &R[q].o, R[q].pq)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);
+      R[q].pq.merged = true;
+    }
+#ifdef MSM_TUNING
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    const bool pipe_log = getenv("MSM_PIPE_LOG") != nullptr;
+#endif
+    // the ranges of one pipeline, in order
+    auto lane = [&](msm_ctx* c, size_t first, size_t step) {
+      HIPCHK(hipSetDevice(c->device));
+      for (size_t q = first; q < Q; q += step) {
+        Range& r = R[q];
+        if (r.cnt == 0) continue;
+#ifdef MSM_TUNING
+        const double t_w0 = since();
+#endif
+        pipe.wait_piece((int)q, c->stream);
+        HIPCHK(hipStreamSynchronize(c->stream));       // the range's scalars are in HBM
+#ifdef MSM_TUNING
+        const double t_w1 = since();
+#endif
+        window_sums_impl(c, (const uint32_t*)ctx->scal.p + r.lo * 8, r.cnt, 1, &r.o, 0, r.pq.K, r.pq, r.words, &r.st, r.o.point_lo);
+#ifdef MSM_TUNING
+        if (pipe_log) fprintf(stderr, "range %zu: %llu scalars, c = %d: waited %.2f .. %.2f, ran until %.2f ms (device total %.2f)\n", q,
+                              (unsigned long long)r.cnt, r.pq.c, t_w0, t_w1, since(), r.st.phase_ms[MSM_T_TOTAL]);
+#endif
+      }
+    };
+    {
+      std::exception_ptr err, err_t;
+      std::thread side;
+      if (borrow.t && Q >= 2) side = std::thread([&] { try { lane(borrow.t, 1, 2); } catch (...) { err_t = std::current_exception(); } });
+      try { lane(ctx, 0, borrow.t ? 2 : 1); } catch (...) { err = std::current_exception(); }
+      if (side.joinable()) side.join();
+      if (err || err_t) {
+        // (a failure of the twin is reported through this context: MsmFail and HipFail carry their own text)
+        std::rethrow_exception(err ? err : err_t);
+      }
+    }
+    msm_host::Proj6 acc = ctx->hc.zero();
+    for (size_t q = 0; q < Q; q++) {
+      const Range& r = R[q];
+      if (r.cnt == 0) continue;
+      std::vector<msm_host::Proj6> P(r.pq.K);
+      for (int k = 0; k < r.pq.K; k++) P[k] = partial_to_host(ctx, &r.words[(size_t)k * 36]);
+      acc = ctx->hc.add(acc, horner_points(ctx->hc, P, r.pq.c));
+      for (int j = 0; j < MSM_N_PHASES; j++) out->phase_ms[j] += r.st.phase_ms[j];
+      out->n_pairs += r.st.n_pairs;
+      out->n_pairs_algo += r.st.n_pairs_algo;
+      out->rounds += r.st.rounds;
+      out->max_bucket = std::max(out->max_bucket, r.st.max_bucket);
+      out->c = r.pq.c;   // the plan of the last, biggest range
+      out->K = r.pq.K;
     }
     out->phase_ms[MSM_T_UPLOAD] = pipe.finish();   // wall time of the background transfer
     proj_to_result(ctx->hc, acc, out);

@@ -114,6 +114,9 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     // one slice per 4 096 points at least; the digit kernel wants a few blocks per CU whatever kc_d is, k_slice_scan walks
     // the kc_d * sortB rows of the merged window with 32 lanes per column
     sortB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)mult * ctx->n_cu, n / 4096));
+    // (pass A names an entry by its offset inside the slice in BS_SPAN_LOG bits: from 2^27 points the slices multiply instead of growing)
+    const uint64_t max_pps = (1ull << BS_SPAN_LOG) / (te ? 1 : 2);
+    sortB = (uint32_t)std::max<uint64_t>(sortB, (n + max_pps - 1) / max_pps);
     pps = (n + sortB - 1) / sortB;
     chunk = (te ? 1 : 2) * pps;
     ctx->ensure(w.block_hist, (size_t)kc_d * sortB * hb * 4 + 64);
@@ -165,12 +168,13 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
                        pl.tables ? sortB * (uint32_t)kc_d : sortB, hb, (uint32_t)kc);
     hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_bin_start, (const uint32_t*)d_bin_tot, V);
     // a block of pass A takes as many consecutive slices of the digit kernel as make two tiles
-    const uint32_t per_block = (uint32_t)std::min<uint64_t>(sortB, std::max<uint64_t>(1, (2 * (uint64_t)BS_TILE + chunk - 1) / chunk));
+    const uint32_t per_block = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(sortB, std::max<uint64_t>(1, (1ull << BS_SPAN_LOG) / chunk)),
+                                                            std::max<uint64_t>(1, (2 * (uint64_t)BS_TILE + chunk - 1) / chunk));
     hipLaunchKernelGGL(k_bin_split, dim3((sortB + per_block - 1) / per_block, kc_d), dim3(BS_THREADS), bin_split_lds(hb), s, (uint2*)w.rec.p,
                        (const uint32_t*)d_bin_start, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n_d, chunk, hb, ws,
                        pl.tables ? 1u : 0u, sortB, per_block);
     HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));
-    hipLaunchKernelGGL(k_bin_count, dim3(V), dim3(256), (size_t)nbmax * 4, s, (uint32_t*)w.counts.p, (const uint32_t*)d_bin_start,
+    hipLaunchKernelGGL(k_bin_count, dim3(V), dim3(BC_THREADS), (size_t)nbmax * 4, s, (uint32_t*)w.counts.p, (const uint32_t*)d_bin_start,
                        (const uint2*)w.rec.p, hb, L, ws);
   }
   int RT = 0;

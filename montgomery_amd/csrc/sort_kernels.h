@@ -19,6 +19,18 @@ namespace msm {
 constexpr int SCAN_THREADS = 1024;
 constexpr int SCAN_ITEMS = 4;
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence too: it waits for every global load and store
+// of the wave (s_waitcnt vmcnt(0)) before the barrier, so a tile loop with one workgroup per CU stalls at each barrier until its
+// copy-out has drained to the L2 and the next tile's loads are back.  The passes of the bin split exchange data between
+// threads through the LDS alone (what they load from or store to global memory is private to the thread), so their barriers
+// need not wait for it.
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+template <bool LDS_ONLY = false>
 MSM_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wave, uint32_t& total) {
   // inclusive scan inside the wave
   uint32_t x = v;
@@ -28,9 +40,9 @@ MSM_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wave, uint32_t& total
     uint32_t y = __shfl_up(x, d, 64);
     if (lane >= d) x += y;
   }
-  __syncthreads();
+  if (LDS_ONLY) lds_barrier(); else __syncthreads();
   if (lane == 63) lds_wave[wave] = x;
-  __syncthreads();
+  if (LDS_ONLY) lds_barrier(); else __syncthreads();
   uint32_t wave_base = 0, tot = 0;
   const int nw = blockDim.x >> 6;
   for (int w = 0; w < nw; w++) {
@@ -52,8 +64,9 @@ MSM_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wave, uint32_t& total
 // together with the totals, in one read-back behind k_pscan_final, and sizes the scan for the largest RT there can be.
 // ---------------------------------------------------------------------------------------------
 
-constexpr int PS_BLOCK = 256;
-constexpr int PS_ITEMS = 16;
+// (four consecutive buckets per lane: a wave instruction of the scans touches 16 sectors, not 64)
+constexpr int PS_BLOCK = 1024;
+constexpr int PS_ITEMS = 4;
 constexpr int PS_SPAN = PS_BLOCK * PS_ITEMS;
 
 MSM_DEV uint32_t scan_quantity(uint32_t n, uint32_t logG, int q) {
@@ -552,14 +565,14 @@ __global__ void __launch_bounds__(RXB_THREADS) k_radix_fine(uint32_t* slots, con
 
 // exclusive scan over NB per-bin values val(b) by a block of THREADS: thread t owns the bins [t * per, (t + 1) * per); calls
 // put(b, prefix) in order; returns the total
-template <int THREADS, class Val, class Put>
+template <int THREADS, bool LDS_ONLY = false, class Val, class Put>
 __device__ __forceinline__ uint32_t bucket_scan(uint32_t NB, uint32_t* lds_wave, Val val, Put put) {
   const uint32_t per = (NB + THREADS - 1) / THREADS, b0 = threadIdx.x * per;
   uint32_t sum = 0;
   for (uint32_t j = 0; j < per; j++)
     if (b0 + j < NB) sum += val(b0 + j);
   uint32_t tot;
-  uint32_t ex = block_excl_scan(sum, lds_wave, tot);
+  uint32_t ex = block_excl_scan<LDS_ONLY>(sum, lds_wave, tot);
   for (uint32_t j = 0; j < per; j++)
     if (b0 + j < NB) {
       const uint32_t x = val(b0 + j);
@@ -569,19 +582,19 @@ __device__ __forceinline__ uint32_t bucket_scan(uint32_t NB, uint32_t* lds_wave,
   return tot;
 }
 
-// pass A geometry, measured at 2^26 (tools/ab_kernels.sh, profiles/r05_experiments.txt item 2): 1024 threads x 16 records = tiles of
-// 16 384 records (128 KB staged, one workgroup per CU) 2.08 ms per window group; x 12 with the next tile's digits requested before
-// the staging 2.14; 512 threads x 16 or x 24 with two workgroups per CU 2.4 / 2.13.  The pass is bound by its writes: runs of ~16
-// records of 8 bytes start anywhere in a 128-byte line, so every run boundary writes one 64-byte unit twice (WRITE_SIZE 4.4 GB for
-// 3.2 GB of records).  Fewer, longer runs (2^9 bins: 1.7 ms) cost the second pass more than they save here (2.2 against 1.3 ms).
+// pass A geometry (tools/ab_kernels.sh, profiles/r05_experiments.txt items 2 and 10).  The pass is bound by the NUMBER of runs it
+// writes, not by their bytes: a tile leaves tile / 2^ab records per bin, one run each, at 3 k places of the record array per
+// block and 0.8 M over the chip -- every run opens another DRAM page.  Measured per window group at 2^26 (403 M entries):
+//   16 k tiles, 2^10 bins (128-byte runs)   2.1 - 2.4 ms      the same with 2^9 bins (256-byte runs) 1.7
+//   ... with every run cut at 64-byte units (partial units held back in the LDS)   2.4: partial writes are not it
+//   ... with barriers that do not wait for the stores to drain                      2.35: nor the fences
+//   32 k tiles (256-byte runs), records staged in 4 bytes                           see item 10
+// 512 threads x 16 or x 24 with two workgroups per CU: 2.4 / 2.13; the next tile's digits requested early: no change.
 #ifndef MSM_BS_THREADS
 #define MSM_BS_THREADS 1024
 #endif
 #ifndef MSM_BS_ITEMS
-#define MSM_BS_ITEMS 16
-#endif
-#ifndef MSM_BS_PREFETCH
-#define MSM_BS_PREFETCH 0
+#define MSM_BS_ITEMS 32
 #endif
 constexpr int BS_THREADS = MSM_BS_THREADS, BS_ITEMS = MSM_BS_ITEMS, BS_TILE = BS_THREADS * BS_ITEMS;
 // k_colscan for the bin split's slice histograms: few columns (the coarse bins of the group), many rows (one per slice -- on
@@ -635,7 +648,9 @@ __global__ void __launch_bounds__(1024) k_slice_scan(uint32_t* block_hist, uint3
 #endif
 
 constexpr uint32_t BS_MAX_AB = 11, BS_MAX_FB = 12;
-inline size_t bin_split_lds(uint32_t hb) { return (size_t)BS_TILE * 8 + (size_t)3 * hb * 4 + 64 * 4; }
+// a block's entries are named by their offset from its first one inside the LDS: BS_SPAN_LOG bits (the host cuts the slices so)
+constexpr uint32_t BS_SPAN_LOG = 17;
+inline size_t bin_split_lds(uint32_t hb) { return (size_t)BS_TILE * 4 + (size_t)3 * hb * 4 + 64 * 4; }
 
 // pass A.  grid (SB, kc); block (b, kk) owns entries [b * chunk, (b + 1) * chunk) of window kk.  Coarse bin h of window kk
 // starts at bin_start[kk * hb + h]; this slice's share of it slice_off[(kk * SB + b) * hb + h] further.
@@ -643,6 +658,9 @@ inline size_t bin_split_lds(uint32_t hb) { return (size_t)BS_TILE * 8 + (size_t)
 // works for window 0, its slice is number kk * SB + b of that window, and entry indices count from the group's first digit.
 // The histograms come per slice of the DIGIT kernel (SBd of them per window, `chunk` entries each); a block of this pass takes
 // g consecutive ones, so that small inputs -- whose digit kernel still wants a block per 4 096 points -- sort whole tiles.
+// The LDS holds a record in 4 bytes -- fine bits + 1 (13 bits) | offset of the entry from the block's first one << 13 (17 bits)
+// | sign << 31 -- so that a tile is 32 k records; the copy-out walks the bins, 32 lanes each (a staged position no longer
+// says which bin it belongs to), and widens the records to the (fine bits + 1 | sign, entry index) pairs the next pass reads.
 __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint32_t* bin_start, const uint32_t* slice_off,
                                                           const uint32_t* dig, uint64_t two_n, uint64_t chunk, uint32_t hb, WinSplit ws,
                                                           uint32_t merged, uint32_t SBd, uint32_t g)
@@ -651,10 +669,10 @@ __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint
 #else
 {
   extern __shared__ uint32_t lds_bs[];
-  uint2* stage = reinterpret_cast<uint2*>(lds_bs);       // BS_TILE records
-  uint32_t* t_cnt = lds_bs + 2 * BS_TILE;
+  uint32_t* stage = lds_bs;                               // BS_TILE packed records, bin by bin
+  uint32_t* t_cnt = stage + BS_TILE;
   uint32_t* t_start = t_cnt + hb;
-  uint32_t* g_base = t_start + hb;
+  uint32_t* g_base = t_start + hb;                        // where the bin's next record goes
   uint32_t* lds_wave = g_base + hb;                       // 64 words
   const uint32_t b = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x;
   const uint32_t kk = merged ? 0u : seg;
@@ -663,66 +681,74 @@ __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint
     g_base[h] = bin_start[(uint64_t)kk * hb + h] + slice_off[((uint64_t)seg * SBd + (uint64_t)b * g) * hb + h];
   const uint64_t beg = (uint64_t)b * g * chunk, end = min(beg + (uint64_t)g * chunk, two_n);
   const uint32_t* d = dig + (uint64_t)seg * two_n;
-  const uint32_t e_base = merged ? (uint32_t)((uint64_t)seg * two_n) : 0u;
+  const uint32_t e_first = (merged ? (uint32_t)((uint64_t)seg * two_n) : 0u) + (uint32_t)beg;   // entry index of offset 0
   const uint32_t fmask = (1u << fb) - 1;
-  uint32_t v[BS_ITEMS], nv[BS_ITEMS];
-  auto load_tile = [&](uint32_t (&dst)[BS_ITEMS], uint64_t t0) {
+  uint32_t v[BS_ITEMS];
+  // the tile's digits through a buffer descriptor over [t0, t0 + left): one 32-bit lane offset for all 32 loads (64-bit
+  // addresses for them would spill), and what lies behind the slice reads as 0 = "no entry" without a compare per load
+  auto load_tile = [&](uint64_t t0) {
+#if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t left = t0 < end ? (uint32_t)min<uint64_t>(end - t0, BS_TILE) : 0u;
-    const uint32_t* dt = d + t0;
+    const uint64_t a = (uint64_t)(d + t0);
+    const uint32_t a_lo = __builtin_amdgcn_readfirstlane((uint32_t)a), a_hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)a_hi << 32) | a_lo), 0, __builtin_amdgcn_readfirstlane(left * 4u), 0x00020000);
 #pragma unroll
-    for (int i = 0; i < BS_ITEMS; i++) {
-      const uint32_t j = (uint32_t)i * BS_THREADS + tid;
-      dst[i] = j < left ? dt[j] : 0u;
-    }
+    for (int i = 0; i < BS_ITEMS; i++) v[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, tid * 4u, i * BS_THREADS * 4, 0);
+#endif
   };
-  load_tile(v, beg);
+  load_tile(beg);
   for (uint64_t t0 = beg; t0 < end; t0 += BS_TILE) {
     for (uint32_t h = tid; h < HN; h += BS_THREADS) t_cnt[h] = 0;
-    __syncthreads();
-    uint32_t rk[BS_ITEMS];
+    lds_barrier();
+    uint32_t rk[BS_ITEMS / 2];   // two ranks (< 2^15) per register: 32 digits and 32 ranks would not fit 128 registers
 #pragma unroll
     for (int i = 0; i < BS_ITEMS; i++) {
       const uint32_t l = v[i] & 0x7FFFFFFFu;
-      rk[i] = lds_rank_add(t_cnt, l ? (l - 1) >> fb : 0u, l != 0);
-    }
-#if MSM_BS_PREFETCH
-    load_tile(nv, t0 + BS_TILE);   // in flight during the scan, the staging and the copy-out
+      const uint32_t r = lds_rank_add(t_cnt, l ? (l - 1) >> fb : 0u, l != 0);
+      if (i & 1) rk[i / 2] |= r << 16; else rk[i / 2] = r;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // (eight in flight: all 32 with their temporaries would spill)
 #endif
-    __syncthreads();
-    const uint32_t n_tile = bucket_scan<BS_THREADS>(HN, lds_wave, [&](uint32_t h) { return t_cnt[h]; },
-                                                    [&](uint32_t h, uint32_t ex) { t_start[h] = ex; });
-    __syncthreads();
+    }
+    lds_barrier();
+    (void)bucket_scan<BS_THREADS, true>(HN, lds_wave, [&](uint32_t h) { return t_cnt[h]; }, [&](uint32_t h, uint32_t ex) { t_start[h] = ex; });
+    lds_barrier();
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (the staging below derives the bin of a digit once more: kept alive from the ranking, 64 such values were spilled)
+#pragma unroll
+    for (int i = 0; i < BS_ITEMS; i++) asm volatile("" : "+v"(v[i]));
+#endif
+    const uint32_t off0 = (uint32_t)(t0 - beg) + tid;
 #pragma unroll
     for (int i = 0; i < BS_ITEMS; i++) {
       const uint32_t l = v[i] & 0x7FFFFFFFu;
-      if (l) {
-        const uint32_t h = (l - 1) >> fb;
-        // record: fine bits + 1 (<= 2^12; 0 never occurs) | coarse bin << 16 (stripped on the way out) | sign << 31
-        stage[t_start[h] + rk[i]] = make_uint2((((l - 1) & fmask) + 1) | (h << 16) | (v[i] & 0x80000000u),
-                                               e_base + (uint32_t)(t0 + (uint64_t)i * BS_THREADS + tid));
+      if (l) stage[t_start[(l - 1) >> fb] + ((rk[i / 2] >> (16 * (i & 1))) & 0xFFFFu)] = (((l - 1) & fmask) + 1) | ((off0 + (uint32_t)i * BS_THREADS) << 13) | (v[i] & 0x80000000u);
+#if defined(__HIP_DEVICE_COMPILE__)
+      if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    lds_barrier();
+    load_tile(t0 + BS_TILE);   // in flight during the copy-out
+    const uint32_t lane = tid & 31u;
+    for (uint32_t h = tid >> 5; h < HN; h += BS_THREADS / 32) {
+      const uint32_t T = t_cnt[h], pos = g_base[h], ts = t_start[h];
+      for (uint32_t o = lane; o < T; o += 32) {
+        const uint32_t r = stage[ts + o];
+        rec[pos + o] = make_uint2(r & 0x80001FFFu, e_first + ((r >> 13) & ((1u << BS_SPAN_LOG) - 1)));
       }
+      if (lane == 0) g_base[h] = pos + T;
     }
-    __syncthreads();
-    for (uint32_t i = tid; i < n_tile; i += BS_THREADS) {
-      const uint2 r = stage[i];
-      const uint32_t h = (r.x >> 16) & 0x7FFu;
-      rec[g_base[h] + (i - t_start[h])] = make_uint2(r.x & 0x8000FFFFu, r.y);
-    }
-    __syncthreads();
-    for (uint32_t h = tid; h < HN; h += BS_THREADS) g_base[h] += t_cnt[h];
-#if MSM_BS_PREFETCH
-#pragma unroll
-    for (int i = 0; i < BS_ITEMS; i++) v[i] = nv[i];
-#else
-    load_tile(v, t0 + BS_TILE);
-#endif
+    lds_barrier();
   }
 }
 #endif
 
-// bucket sizes of bin v = kk * hb + h (the 2^fb buckets from h << fb of window kk) from its records; `counts` is zeroed before
-__global__ void __launch_bounds__(256) k_bin_count(uint32_t* counts, const uint32_t* bin_start, const uint2* rec, uint32_t hb, uint32_t L,
-                                                   WinSplit ws)
+// bucket sizes of bin v = kk * hb + h (the 2^fb buckets from h << fb of window kk) from its records; `counts` is zeroed before.
+// 1024 threads and two records per 16-byte load: with 256 threads the 3 072 bins of a 21-bit window group were 1.5 rounds of
+// the 2 048 blocks the chip holds and every lane load was half a request (0.92 -> see profiles/r05_experiments.txt item 10).
+constexpr int BC_THREADS = 1024;
+__global__ void __launch_bounds__(BC_THREADS) k_bin_count(uint32_t* counts, const uint32_t* bin_start, const uint2* rec, uint32_t hb, uint32_t L,
+                                                          WinSplit ws)
 #ifndef MSM_SORT_TU
     ;
 #else
@@ -738,15 +764,20 @@ __global__ void __launch_bounds__(256) k_bin_count(uint32_t* counts, const uint3
     if (tid == 0) out[0] = (uint32_t)(end - beg);
     return;
   }
-  for (uint32_t j = tid; j < NB; j += 256) lds_bc[j] = 0;
+  for (uint32_t j = tid; j < NB; j += BC_THREADS) lds_bc[j] = 0;
   __syncthreads();
-  for (uint64_t j0 = beg; j0 < end; j0 += 256) {   // whole waves stay in the loop (lds_rank_add looks at the whole wave)
+  const uint4* rec2 = reinterpret_cast<const uint4*>(rec);   // records 2 j and 2 j + 1
+  for (uint64_t j0 = beg >> 1; 2 * j0 < end; j0 += BC_THREADS) {   // whole waves stay in the loop (lds_rank_add looks at the whole wave)
     const uint64_t j = j0 + tid;
-    const uint32_t l = j < end ? rec[j].x & 0xFFFFu : 0u;
-    (void)lds_rank_add(lds_bc, l ? l - 1 : 0u, l != 0);
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (2 * j < end) r = rec2[j];   // (the record array is allocated with slack beyond its last record)
+    const uint32_t l0 = (2 * j >= beg && 2 * j < end) ? r.x & 0xFFFFu : 0u;
+    const uint32_t l1 = (2 * j + 1 >= beg && 2 * j + 1 < end) ? r.z & 0xFFFFu : 0u;
+    (void)lds_rank_add(lds_bc, l0 ? l0 - 1 : 0u, l0 != 0);
+    (void)lds_rank_add(lds_bc, l1 ? l1 - 1 : 0u, l1 != 0);
   }
   __syncthreads();
-  for (uint32_t j = tid; j < NB; j += 256) out[j] = lds_bc[j];
+  for (uint32_t j = tid; j < NB; j += BC_THREADS) out[j] = lds_bc[j];
 }
 #endif
 
@@ -824,7 +855,7 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_pairs(uint2* pairs, uint32_t
   load_tile(r, beg);
   for (uint64_t t0 = beg; t0 < end; t0 += BP_TILE) {
     for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) t_cnt[bk] = 0;
-    __syncthreads();
+    lds_barrier();
     uint32_t rk[BP_ITEMS];
 #pragma unroll
     for (int i = 0; i < BP_ITEMS; i++) {
@@ -931,7 +962,7 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_slots(uint32_t* slots, const
   for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) g_cur[bk] = cur[((uint64_t)h << fb) + bk];
   for (uint64_t t0 = beg; t0 < end; t0 += BP_TILE) {
     for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) t_cnt[bk] = 0;
-    __syncthreads();
+    lds_barrier();
     uint2 r[BP_ITEMS];
     uint32_t rk[BP_ITEMS];
 #pragma unroll
@@ -944,10 +975,10 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_slots(uint32_t* slots, const
       const uint32_t l = r[i].x & 0xFFFFu;
       rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0);
     }
-    __syncthreads();
-    const uint32_t n_tile = bucket_scan<BP_THREADS>(NB, lds_wave, [&](uint32_t bk) { return t_cnt[bk]; },
+    lds_barrier();
+    const uint32_t n_tile = bucket_scan<BP_THREADS, true>(NB, lds_wave, [&](uint32_t bk) { return t_cnt[bk]; },
                                            [&](uint32_t bk, uint32_t ex) { t_start[bk] = ex; });
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < BP_ITEMS; i++) {
       const uint32_t l = r[i].x & 0xFFFFu;
@@ -957,12 +988,12 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_slots(uint32_t* slots, const
         stage_b[p] = (uint16_t)(l - 1);
       }
     }
-    __syncthreads();
+    lds_barrier();
     for (uint32_t i = tid; i < n_tile; i += BP_THREADS) {
       const uint32_t bk = stage_b[i];
       slots[g_cur[bk] + (i - t_start[bk])] = stage[i];
     }
-    __syncthreads();
+    lds_barrier();
     for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) g_cur[bk] += t_cnt[bk];
   }
 }
