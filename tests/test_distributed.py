@@ -223,7 +223,7 @@ def test_choose_window_for_shards():
     from montgomery_amd.distributed import choose_window
 
     def plan(m, c):   # msm_plan of the BLS12-377 context: b + 1 = 127 bits, the carry bit folded for c = 18 and 21
-        c = c or (21 if m >= 1 << 24 else 16)
+        c = c or (21 if m >= 1 << 24 else 18 if m >= 1 << 22 else 16)
         return c, -(-127 // c) - (1 if c in (18, 21) else 0)
 
     n = 1 << 26
@@ -232,7 +232,7 @@ def test_choose_window_for_shards():
         assert choose_window(plan, n, world, "windows") == (16, 8)      # K = 8 divides: every rank the same number of windows
     assert choose_window(plan, n, 2, "points") == (21, 6)               # a share of 2^25 points: the library's pick for it
     assert choose_window(plan, n, 4, "points") == (21, 6)
-    assert choose_window(plan, n, 8, "points") == (16, 8)               # 2^23 points per rank
+    assert choose_window(plan, n, 8, "points") == (18, 7)               # 2^23 points per rank
     assert choose_window(plan, n, 3, "windows") == (21, 6)              # 8 does not divide by 3: the pick for a rank's share
     assert choose_window(plan, 1 << 20, 8, "windows") == (16, 8)
     for world in (2, 3, 8):

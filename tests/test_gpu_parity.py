@@ -365,10 +365,10 @@ def test_msm_2p26_known_discrete_logs(gpu_ctx, c_oracle):
 
 
 def test_default_plan_at_2p22_is_seven_folded_18_bit_windows(gpu_ctx, c_oracle):
-    """2^22 <= n < 2^23 picks seven 18-bit windows with the carry bit folded into the top one (pick_window): the plan must be
+    """2^22 <= n < 2^24 picks seven 18-bit windows with the carry bit folded into the top one (pick_window): the plan must be
     the one the library PICKS here, not only one a test forces; same element as the 16-bit plan and as the known discrete logs."""
     n = 1 << 22
-    assert gpu_ctx.plan(n) == (18, 7) and gpu_ctx.plan((1 << 23) - 1) == (18, 7) and gpu_ctx.plan(1 << 23) == (16, 8)
+    assert gpu_ctx.plan(n) == (18, 7) and gpu_ctx.plan((1 << 24) - 1) == (18, 7) and gpu_ctx.plan(1 << 24) == (21, 6) and gpu_ctx.plan((1 << 22) - 1) == (16, 8)
     a = gpu_ctx.generate_points(n, seed=2222, want_scalars=True, raw=True)
     dev, s = gpu_ctx.generate_scalars(n, seed=4444, to_host=True, raw=True)
     res, info = gpu_ctx.run_device(dev, n)
