@@ -201,12 +201,13 @@ def timed_config(curve_name, log2n, torch, steps=10, warmup=5, c=0):
     algo_bytes, mads = (384, 9 * 153) if te else (PAIR_ALGO_BYTES, PAIR_MADS)
     mad_rate = pairs * mads / (acc_ms * 1e-3)
     hbm = pairs * algo_bytes / (acc_ms * 1e-3) / 1e9
+    tables_gib = ctx.tables_info()[2] / 2 ** 30
     ctx.close()
     del scal
     return {
         "workload": f"{'ed-on-bls12-377' if te else 'bls12-377-g1'}-msm-2^{log2n}",
         "window_bits": cc, "windows": K, "steps": steps, "warmup": warmup,
-        "window_tables": ({"tables": K, "gib": ctx.tables_info()[2] / 2 ** 30,
+        "window_tables": ({"tables": K, "gib": tables_gib,
                            "note": "K resident tables 2^(c k) P of the point set (built once per set, like the point conversion): all "
                                    "windows share one set of buckets; `plain_path` = the same MSMs without them"} if infos[-1]["tables"] else None),
         "plain_path": plain,

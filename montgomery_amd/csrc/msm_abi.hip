@@ -35,6 +35,7 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     HIPCHK(hipHostMalloc((void**)&ctx->h_info, 64 * 4, hipHostMallocDefault));
     for (auto& w : ctx->ws) {
       HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+      HIPCHK(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
       for (auto& e : w.ev) HIPCHK(hipEventCreate(&e));
       HIPCHK(hipHostMalloc((void**)&w.h_info, 64 * 4, hipHostMallocDefault));
       HIPCHK(hipHostMalloc((void**)&w.h_part, 128 * 20 * 36 * 4, hipHostMallocDefault));
@@ -89,6 +90,7 @@ void msm_ctx_destroy(msm_ctx* ctx) {
     if (w.h_info) (void)hipHostFree(w.h_info);
     if (w.h_part) (void)hipHostFree(w.h_part);
     for (auto& e : w.ev) if (e) (void)hipEventDestroy(e);
+    if (w.side) { (void)hipStreamSynchronize(w.side); (void)hipStreamDestroy(w.side); }
     if (w.stream) (void)hipStreamDestroy(w.stream);
   }
   if (ctx->h_info) (void)hipHostFree(ctx->h_info);

@@ -224,7 +224,8 @@ struct msm_ctx {
     msmi::DevBuf dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, columns2, rows_sum, bucket_proj, bufA, bufB,
         scratch, columns, partials, part, dig2, idx2, rec, blk_tab2, slots2, dest, rows1;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipStream_t side = nullptr;   // read-backs that the host needs while `stream` goes on (the sort's totals under its last pass)
+    hipEvent_t ev[8] = {};        // (ev[7]: the scans of the bucket sizes are done)
     uint32_t* h_info = nullptr;   // pinned, 64 words
     uint32_t* h_part = nullptr;   // pinned, window sums read-back
     msmi::DevBuf* all[25] = {&dig, &counts, &cursor, &tail_off, &info, &slots, &block_hist, &scan_partial, &desc, &columns2, &rows_sum,

@@ -47,7 +47,8 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   // 128 .. 256: 16 (2^21 6.92 -> 6.88, 2^22 12.45 -> 12.17, Ed-377 2^20 2.64 -> 2.59, 2^26 145.7 -> 142.5, 2^27 304.9 -> 301.8);
   // from 512: 32 (2^23 22.65 -> 22.18, 2^26 at c = 16 152.7 -> 152.1); 32 entries: 8 (2^24: 16 costs 8 %).
   uint64_t mean = std::max<uint64_t>(1, two_n / (pl.fold ? L / 2 : L));   // (a folded plan's lower windows fill half their buckets)
-  uint64_t per_bucket_left = mean >= 512 ? 32 : (mean >= 128 || (mean >= 64 && pl.c >= 18)) ? 16 : 8;
+  // (on window tables at 2^20 points, mean 112 at c = 18: 8 -- a third regular round -- 3.37 against 3.41 ms)
+  uint64_t per_bucket_left = mean >= 512 ? 32 : (mean >= 128 || (mean >= 64 && pl.c >= 18 && !pl.tables)) ? 16 : 8;
   MSM_KNOB(per_bucket_left, "MSM_PBL", 1);
   uint32_t logG = 1;
   while (logG < 10 && (1ull << (logG + 1)) * per_bucket_left <= mean) logG++;
@@ -166,16 +167,20 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     // (on tables the slices of all kc_d digit windows are the slices of the one merged window, in the same row order)
     hipLaunchKernelGGL(k_slice_scan, dim3((hb + 31) / 32, kc), dim3(1024), 0, s, (uint32_t*)w.block_hist.p, d_bin_tot,
                        pl.tables ? sortB * (uint32_t)kc_d : sortB, hb, (uint32_t)kc);
-    hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_bin_start, (const uint32_t*)d_bin_tot, V);
+    hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_bin_start, (const uint32_t*)d_bin_tot, V, (uint32_t*)w.info.p);
     // a block of pass A takes as many consecutive slices of the digit kernel as make two tiles
     const uint32_t per_block = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(sortB, std::max<uint64_t>(1, (1ull << BS_SPAN_LOG) / chunk)),
                                                             std::max<uint64_t>(1, (2 * (uint64_t)BS_TILE + chunk - 1) / chunk));
     hipLaunchKernelGGL(k_bin_split, dim3((sortB + per_block - 1) / per_block, kc_d), dim3(BS_THREADS), bin_split_lds(hb), s, (uint2*)w.rec.p,
                        (const uint32_t*)d_bin_start, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n_d, chunk, hb, ws,
                        pl.tables ? 1u : 0u, sortB, per_block);
-    HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));
+    // k_bin_count leaves the largest bucket and the pair count in `info` as k_bucket_max does for the other paths, and writes
+    // every bucket of the bins it is launched for: `counts` needs a fill only where a window's digits do not span all L buckets
+    bool spans_all = true;
+    for (int kk = 0; kk < kc; kk++) spans_all &= (1u << ws.ab[kk]) == hb && (int)ws.ab[kk] + (int)ws.fb[kk] == cbits;
+    if (!spans_all) HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));   // (`info` was cleared by k_vscan)
     hipLaunchKernelGGL(k_bin_count, dim3(V), dim3(BC_THREADS), (size_t)nbmax * 4, s, (uint32_t*)w.counts.p, (const uint32_t*)d_bin_start,
-                       (const uint2*)w.rec.p, hb, L, ws);
+                       (const uint2*)w.rec.p, hb, L, ws, (uint32_t*)w.info.p);
   }
   int RT = 0;
   uint64_t total_slots = 0;
@@ -183,9 +188,11 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   {
     // largest bucket -> number of tail rounds RT, then the multi-block scan of RT + 2 quantities.  The scan kernels take RT
     // from the device (pscan_nq), so ONE read-back behind them brings the largest bucket and the totals together.
-    HIPCHK(hipMemsetAsync(w.info.p, 0, 64 * 4, s));
-    hipLaunchKernelGGL(k_bucket_max, dim3((uint32_t)std::min<uint64_t>(1024, (nb + 255) / 256)), dim3(256), 0, s,
-                       (const uint32_t*)w.counts.p, (uint32_t)nb, (uint32_t*)w.info.p);
+    if (!bin_split) {
+      HIPCHK(hipMemsetAsync(w.info.p, 0, 64 * 4, s));
+      hipLaunchKernelGGL(k_bucket_max, dim3((uint32_t)std::min<uint64_t>(1024, (nb + 255) / 256)), dim3(256), 0, s,
+                         (const uint32_t*)w.counts.p, (uint32_t)nb, (uint32_t*)w.info.p);
+    }
     const uint32_t nblocks = (uint32_t)((nb + PS_SPAN - 1) / PS_SPAN);
     ctx->ensure(w.scan_partial, (size_t)PS_MAX_NQ * nblocks * 4);
     hipLaunchKernelGGL(k_pscan_partial, dim3(nblocks), dim3(PS_BLOCK), 0, s, (const uint32_t*)w.counts.p, (uint32_t)nb, logG,
@@ -195,16 +202,8 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     hipLaunchKernelGGL(k_pscan_final, dim3(nblocks), dim3(PS_BLOCK), 0, s, (const uint32_t*)w.counts.p, (uint32_t)nb, logG,
                        (const uint32_t*)w.scan_partial.p, nblocks, (uint32_t*)w.cursor.p, (uint32_t*)w.tail_off.p,
                        (const uint32_t*)w.info.p);
-    HIPCHK(hipMemcpyAsync(w.h_info, w.info.p, 64 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    total_slots = w.h_info[0];
-    max_bucket = w.h_info[1];
-    st.n_pairs_algo += (uint64_t)w.h_info[INFO_ALGO_PAIRS] | ((uint64_t)w.h_info[INFO_ALGO_PAIRS + 1] << 32);
-    const uint32_t capmax = (max_bucket + (1u << logG) - 1) >> logG;
-    while (RT < 32 && (1u << RT) < capmax) RT++;
+    HIPCHK(hipEventRecord(w.ev[7], s));
   }
-  st.max_bucket = std::max<uint64_t>(st.max_bucket, max_bucket);
-
   // Big windows over a big table: round 1 walks the pairs in the order the last pass of the sort emits them -- tile by tile of
   // a bin's records, which are in point order -- and writes every sum to the element index that comes with the pair, as
   // 64-byte records that round 2 reads back (batch_add.h).  Needed once the 128 slots of a wave span more than ~1 GB of
@@ -220,20 +219,53 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     long long want_chunks = (bin_split && !te && pl.c >= 18 && table_rows > (1ull << chunk_rows_log)) ? 1 : 0;
     MSM_KNOB(want_chunks, "MSM_CHUNKED", 0);
     // (round 2 must be an index-free round to read the element records round 1 then writes: logG >= 2)
-    chunked = bin_split && want_chunks && !te && logG >= 2 && total_slots >= 2;
+    chunked = bin_split && want_chunks && !te && logG >= 2;
+  }
+  // The bin split's last pass needs nothing from the host but room for what it writes, and the padded slots have a bound --
+  // every non-empty bucket pads by less than G -- so it is launched BEHIND the scans at once and the read-back of the totals
+  // (which the tree's launches wait for) crosses on a side stream while it runs: no idle gap of a host round trip in front of
+  // it (25 us of the 3.4 ms of an MSM over 2^20 points).
+  const uint64_t slots_bound = n_entries + (((uint64_t)1 << logG) - 1) * std::min<uint64_t>(nb, n_entries);
+  auto launch_bin_pass = [&](uint64_t slots_cap) {
+    if (chunked) {
+      const uint64_t pairs_cap = slots_cap / 2 + 1;
+      ctx->ensure(w.slots2, pairs_cap * 8);
+      ctx->ensure(w.dest, pairs_cap * 4);
+      rec_y_off = (pairs_cap * 64 + 255) & ~(uint64_t)255;
+      ctx->ensure(w.rows1, 2 * rec_y_off + 256);
+      hipLaunchKernelGGL(k_bin_pairs, dim3(V), dim3(BP_THREADS), bin_pairs_lds(nbmax), s, (uint2*)w.slots2.p, (uint32_t*)w.dest.p,
+                         (const uint2*)w.rec.p, (const uint32_t*)d_bin_start, (const uint32_t*)w.cursor.p, hb, L, nbmax, ws);
+      round1_slots = (const uint32_t*)w.slots2.p;
+      round1_dest = (const uint32_t*)w.dest.p;
+    } else {
+      ctx->ensure(w.slots, std::max<uint64_t>(slots_cap, 2) * 4);
+      HIPCHK(hipMemsetAsync(w.slots.p, 0xFF, std::max<uint64_t>(slots_cap, 2) * 4, s));
+      round1_slots = (const uint32_t*)w.slots.p;
+      hipLaunchKernelGGL(k_bin_slots, dim3(V), dim3(BP_THREADS), bin_slots_lds(nbmax), s, (uint32_t*)w.slots.p,
+                         (const uint2*)w.rec.p, (const uint32_t*)d_bin_start, (const uint32_t*)w.cursor.p, hb, L, nbmax, ws);
+    }
+  };
+  if (bin_split) launch_bin_pass(slots_bound);
+  {
+    HIPCHK(hipStreamWaitEvent(w.side, w.ev[7], 0));
+    HIPCHK(hipMemcpyAsync(w.h_info, w.info.p, 64 * 4, hipMemcpyDeviceToHost, w.side));
+    HIPCHK(hipStreamSynchronize(w.side));
+    total_slots = w.h_info[0];
+    max_bucket = w.h_info[1];
+    st.n_pairs_algo += (uint64_t)w.h_info[INFO_ALGO_PAIRS] | ((uint64_t)w.h_info[INFO_ALGO_PAIRS + 1] << 32);
+    const uint32_t capmax = (max_bucket + (1u << logG) - 1) >> logG;
+    while (RT < 32 && (1u << RT) < capmax) RT++;
+  }
+  st.max_bucket = std::max<uint64_t>(st.max_bucket, max_bucket);
+  if (total_slots > slots_bound) throw MsmFail{MSM_ERR_INTERNAL, "the padded slots exceed their bound"};
+  if (bin_split && chunked && total_slots < 2) {   // (no entry at all: the plain slot form handles the empty tree)
+    chunked = false;
+    round1_dest = nullptr;
+    rec_y_off = 0;
+    launch_bin_pass(2);
   }
   // scatter
-  if (chunked) {
-    const uint64_t n_pairs = total_slots / 2;
-    ctx->ensure(w.slots2, total_slots * 4);
-    ctx->ensure(w.dest, n_pairs * 4);
-    rec_y_off = (n_pairs * 64 + 255) & ~(uint64_t)255;
-    ctx->ensure(w.rows1, 2 * rec_y_off + 256);
-    hipLaunchKernelGGL(k_bin_pairs, dim3(V), dim3(BP_THREADS), bin_pairs_lds(nbmax), s, (uint2*)w.slots2.p, (uint32_t*)w.dest.p,
-                       (const uint2*)w.rec.p, (const uint32_t*)d_bin_start, (const uint32_t*)w.cursor.p, hb, L, nbmax, ws);
-    round1_slots = (const uint32_t*)w.slots2.p;
-    round1_dest = (const uint32_t*)w.dest.p;
-  } else {
+  if (!bin_split) {
     ctx->ensure(w.slots, std::max<uint64_t>(total_slots, 2) * 4);
     HIPCHK(hipMemsetAsync(w.slots.p, 0xFF, std::max<uint64_t>(total_slots, 2) * 4, s));
     round1_slots = (const uint32_t*)w.slots.p;
@@ -248,7 +280,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
       const uint64_t co = (uint64_t)kc * (sortB + 1) * Hn;
       hipLaunchKernelGGL(k_coarse_offsets, dim3((uint32_t)((co + 255) / 256)), dim3(256), 0, s, d_blk_off, d_vtot,
                          (const uint32_t*)w.block_hist.p, (const uint32_t*)w.counts.p, sortB, L, Hn, (uint32_t)kc);
-      hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_vstart, (const uint32_t*)d_vtot, V);
+      hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_vstart, (const uint32_t*)d_vtot, V, (uint32_t*)nullptr);
       hipLaunchKernelGGL(k_radix_coarse, dim3(sortB, kc), dim3(RX_THREADS), 0, s, (uint32_t*)w.dig2.p, (uint32_t*)w.idx2.p,
                          (const uint32_t*)d_vstart, (const uint32_t*)d_blk_off, (const uint32_t*)w.dig.p, two_n, chunk, Hn, ws);
       hipLaunchKernelGGL(k_radix_fine, dim3(V), dim3(RXB_THREADS), 0, s, (uint32_t*)w.slots.p, (const uint32_t*)w.cursor.p,
@@ -257,9 +289,6 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
       hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.slots.p,
                          (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n,
                          chunk, L);
-    } else {
-      hipLaunchKernelGGL(k_bin_slots, dim3(V), dim3(BP_THREADS), bin_slots_lds(nbmax), s, (uint32_t*)w.slots.p,
-                         (const uint2*)w.rec.p, (const uint32_t*)d_bin_start, (const uint32_t*)w.cursor.p, hb, L, nbmax, ws);
     }
   }
   HIPCHK(hipEventRecord(w.ev[2], s));

@@ -403,12 +403,14 @@ __global__ void __launch_bounds__(256) k_coarse_offsets(uint32_t* blk_off, uint3
 }
 #endif
 
-__global__ void __launch_bounds__(SCAN_THREADS) k_vscan(uint32_t* v_start, const uint32_t* v_tot, uint32_t V)
+// (zero64: 64 words this launch clears on the way -- the `info` block of the bucket scans -- or null: one fill fewer in the stream)
+__global__ void __launch_bounds__(SCAN_THREADS) k_vscan(uint32_t* v_start, const uint32_t* v_tot, uint32_t V, uint32_t* zero64)
 #ifndef MSM_SORT_TU
     ;
 #else
 {
   __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
+  if (zero64 && threadIdx.x < 64) zero64[threadIdx.x] = 0;
   uint32_t carry = 0;
   for (uint32_t base = 0; base < V; base += SCAN_THREADS) {
     const uint32_t i = base + threadIdx.x;
@@ -747,23 +749,35 @@ __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint
 // 1024 threads and two records per 16-byte load: with 256 threads the 3 072 bins of a 21-bit window group were 1.5 rounds of
 // the 2 048 blocks the chip holds and every lane load was half a request (0.92 -> see profiles/r05_experiments.txt item 10).
 constexpr int BC_THREADS = 1024;
+// Also what k_bucket_max does on the other sort paths: the largest bucket -> info[1], sum of (size - 1) -> info[40..41] (`info`
+// is zeroed before; a bin without records writes its zeros itself, so `counts` needs no fill).
 __global__ void __launch_bounds__(BC_THREADS) k_bin_count(uint32_t* counts, const uint32_t* bin_start, const uint2* rec, uint32_t hb, uint32_t L,
-                                                          WinSplit ws)
+                                                          WinSplit ws, uint32_t* info)
 #ifndef MSM_SORT_TU
     ;
 #else
 {
   extern __shared__ uint32_t lds_bc[];
+  __shared__ uint32_t lds_max;
+  __shared__ unsigned long long lds_sum;
   const uint32_t v = blockIdx.x, tid = threadIdx.x;
   const uint32_t kk = v / hb, h = v - kk * hb, fb = ws.fb[kk], NB = 1u << fb;
   if (h >= (1u << ws.ab[kk])) return;
   const uint64_t beg = bin_start[v], end = bin_start[v + 1];
-  if (beg == end) return;
   uint32_t* out = counts + (uint64_t)kk * L + ((uint64_t)h << fb);
-  if (fb == 0) {   // one bucket
-    if (tid == 0) out[0] = (uint32_t)(end - beg);
+  if (beg == end) {
+    for (uint32_t j = tid; j < NB; j += BC_THREADS) out[j] = 0;
     return;
   }
+  if (fb == 0) {   // one bucket
+    if (tid == 0) {
+      out[0] = (uint32_t)(end - beg);
+      atomicMax(&info[1], (uint32_t)(end - beg));
+      atomicAdd(reinterpret_cast<unsigned long long*>(info + INFO_ALGO_PAIRS), (unsigned long long)(end - beg - 1));
+    }
+    return;
+  }
+  if (tid == 0) { lds_max = 0; lds_sum = 0; }
   for (uint32_t j = tid; j < NB; j += BC_THREADS) lds_bc[j] = 0;
   __syncthreads();
   const uint4* rec2 = reinterpret_cast<const uint4*>(rec);   // records 2 j and 2 j + 1
@@ -777,7 +791,21 @@ __global__ void __launch_bounds__(BC_THREADS) k_bin_count(uint32_t* counts, cons
     (void)lds_rank_add(lds_bc, l1 ? l1 - 1 : 0u, l1 != 0);
   }
   __syncthreads();
-  for (uint32_t j = tid; j < NB; j += BC_THREADS) out[j] = lds_bc[j];
+  uint32_t mx = 0;
+  unsigned long long sum = 0;
+  for (uint32_t j = tid; j < NB; j += BC_THREADS) {
+    const uint32_t cnt = lds_bc[j];
+    out[j] = cnt;
+    mx = max(mx, cnt);
+    sum += cnt ? cnt - 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o); mx = max(mx, (uint32_t)__shfl_down(mx, o)); }
+  if ((tid & 63u) == 0 && (mx | sum)) { atomicMax(&lds_max, mx); atomicAdd(&lds_sum, sum); }
+  __syncthreads();
+  if (tid == 0) {
+    atomicMax(&info[1], lds_max);
+    atomicAdd(reinterpret_cast<unsigned long long*>(info + INFO_ALGO_PAIRS), lds_sum);
+  }
 }
 #endif
 
