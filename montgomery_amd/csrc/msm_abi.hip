@@ -278,11 +278,11 @@ static int run_piped(msm_ctx* ctx, const void* scalars, uint64_t n, const msm_op
     for (int sh : shifts) piece_end.push_back(((n >> sh) / gran) * gran);
     piece_end.push_back(n);
     ctx->ensure(ctx->scal, n * 32);   // before any workspace is sized from what the device has free
-    // Consecutive ranges run on two pipelines of the device, even ones on this context, odd ones on its twin: a range starts when
-    // its scalars are there and the range two before it is done, so the head of one sub-MSM (digits and sort, which no tree of its
-    // own hides) and the tail of its predecessor (last tree rounds on a few CUs, bucket reduction, read-backs) share the chip.
-    // Measured at 2^26: 160.3 -> see profiles/r05_experiments.txt item 10.
-    long long want_twin = 1;
+    // Experiment of the tuning build (MSM_PIPE_TWIN=1): odd ranges on a second pipeline of the device (a twin context that borrows
+    // the point rows), so that a range starts as soon as its scalars are there and runs beside its neighbours.  Measured at 2^26:
+    // 156.5 ms either way -- the ranges share the chip and each takes longer, work is conserved (profiles/r05_experiments.txt
+    // item 11).  Off.
+    long long want_twin = 0;
     MSM_KNOB(want_twin, "MSM_PIPE_TWIN", 0);
     if (want_twin && !ctx->twin) {
       msm_ctx* t = nullptr;
