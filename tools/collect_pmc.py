@@ -67,7 +67,7 @@ if pairs_algo:
         p["hbm_bytes_per_pair_add"] = (p["fetch_bytes_x2"] + p["write_bytes"]) / denom
         p["valu_insts_per_pair_add"] = p["valu_wave_insts"] / (denom / 64)
 # the scatter phase (digits + sort kernels): HBM bytes per (entry, window) and its share of the wall time
-sort_keys = ("k_digits", "k_te_digits", "k_hist", "k_colscan", "k_coarse_offsets", "k_vscan", "k_radix_", "k_fine_hist", "k_scatter_lds",
+sort_keys = ("k_digits", "k_te_digits", "k_hist", "k_colscan", "k_slice_scan", "k_coarse_offsets", "k_vscan", "k_radix_", "k_fine_hist", "k_scatter_lds",
              "k_chunk_order", "k_pscan", "k_bucket_max", "k_pair_", "k_bin_")
 def is_sort(k):
     return any(s in k for s in sort_keys)
