@@ -143,4 +143,16 @@ MSM_DEV uint32_t bn_bits(const uint32_t* x, int start, int len) {
   return (uint32_t)(v >> bs) & ((1u << len) - 1u);
 }
 
+// The windows of a scalar one after the other: take the low `len` bits (len <= 31) and shift the words down by them -- one
+// funnel shift per word and window, where bn_bits at a running position selects its two words with a compare and a
+// conditional move per word (the digit loop was three quarters of k_digits' instructions)
+template <int NX>
+MSM_DEV uint32_t bn_take_bits(uint32_t (&x)[NX], int len) {
+  const uint32_t v = x[0] & ((1u << len) - 1u);
+#pragma unroll
+  for (int i = 0; i + 1 < NX; i++) x[i] = (x[i] >> len) | (x[i + 1] << (32 - len));   // (len >= 1: window sizes start at 2)
+  x[NX - 1] >>= len;
+  return v;
+}
+
 }  // namespace msm

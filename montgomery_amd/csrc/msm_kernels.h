@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(1024) k_digits(uint32_t* dig, const uint32_t* 
     uint32_t carry = 0;
     for (int k = 0; k < k_total; k++) {
       const bool top = fold && k == k_total - 1;
-      uint32_t l = bn_bits<8>(s, k * c, top ? c + 1 : c) + carry;
+      uint32_t l = bn_take_bits<8>(s, top ? c + 1 : c) + carry;
       if (!top && l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
       if (top && l > 2 * L) { atomicOr(err, 8u); l = 2 * L; }   // (see below: a folded top window must stay within its buckets)
       uint32_t sgn = carry;
@@ -326,8 +326,8 @@ __global__ void __launch_bounds__(1024) k_digits(uint32_t* dig, const uint32_t* 
   uint32_t carry0 = 0, carry1 = 0;
   for (int k = 0; k < k_total; k++) {
     const bool top = fold && k == k_total - 1;
-    uint32_t l0 = bn_bits<4>(h[0].mag, k * c, top ? c + 1 : c) + carry0;
-    uint32_t l1 = bn_bits<4>(h[1].mag, k * c, top ? c + 1 : c) + carry1;
+    uint32_t l0 = bn_take_bits<4>(h[0].mag, top ? c + 1 : c) + carry0;
+    uint32_t l1 = bn_take_bits<4>(h[1].mag, top ? c + 1 : c) + carry1;
     if (!top && l0 > L) { l0 = 2 * L - l0; carry0 = 1; } else { carry0 = 0; }
     if (!top && l1 > L) { l1 = 2 * L - l1; carry1 = 1; } else { carry1 = 0; }
     // the folded top window is not recoded: its value stays within its 2^c buckets only while the GLV halves stay below

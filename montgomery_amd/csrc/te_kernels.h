@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(1024) k_te_digits(uint32_t* dig, const uint32_
     const uint32_t L = 1u << (c - 1);
     uint32_t carry = 0;
     for (int k = 0; k < k_total; k++) {
-      uint32_t l = bn_bits<8>(s, k * c, c) + carry;
+      uint32_t l = bn_take_bits<8>(s, c) + carry;
       if (l > L) { l = 2 * L - l; carry = 1; } else { carry = 0; }
       int kk = k - k_lo;
       if (kk >= 0 && kk < k_cnt) {
