@@ -136,3 +136,24 @@ def test_degenerate_inputs_through_the_big_window_paths():
             assert info["c"] == 22 and res.as_tuple() == (O.aff_scale(k, P, C.p) if k else None), info
     finally:
         ctx.close()
+
+
+def test_2p27_points_sort_in_capped_slices():
+    """From 2^27 points the first pass of the bin split multiplies its slices instead of growing them (an entry is named by a
+    17-bit offset inside its slice, sort_kernels.h BS_SPAN_LOG): the six-window plan the library picks must give the element
+    the 16-bit plan (radix split, no such slices) gives, and a forced 18-bit plan as well."""
+    from montgomery_amd.api import MsmContext
+
+    n = 1 << 27
+    ctx = MsmContext()
+    try:
+        ctx.generate_points(n, seed=127)
+        dev, _ = ctx.generate_scalars(n, seed=227)
+        res, info = ctx.run_device(dev, n)
+        assert (info["c"], info["K"]) == (21, 6) and not info["tables"], info
+        ref, _ = ctx.run_device(dev, n, c=16)
+        assert res.as_tuple() == ref.as_tuple()
+        r18, i18 = ctx.run_device(dev, n, c=18)
+        assert i18["K"] == 7 and r18.as_tuple() == ref.as_tuple()
+    finally:
+        ctx.close()
