@@ -276,6 +276,12 @@ static int run_piped(msm_ctx* ctx, const void* scalars, uint64_t n, const msm_op
     }
 #endif
     for (int sh : shifts) piece_end.push_back(((n >> sh) / gran) * gran);
+#ifdef MSM_TUNING
+    if (const char* e = getenv("MSM_PIPE_64")) {   // experiment: "4,13" = ranges ending at 4/64 and 13/64 of the points, and n
+      piece_end.clear();
+      for (const char* q = e; *q;) { piece_end.push_back(((n * (uint64_t)atoi(q) / 64) / gran) * gran); while (*q && *q != ',') q++; if (*q) q++; }
+    }
+#endif
     piece_end.push_back(n);
     ctx->ensure(ctx->scal, n * 32);   // before any workspace is sized from what the device has free
     // Experiment of the tuning build (MSM_PIPE_TWIN=1): odd ranges on a second pipeline of the device (a twin context that borrows
