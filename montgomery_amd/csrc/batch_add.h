@@ -72,6 +72,10 @@ constexpr int BA_THREADS = 256;
 #define BA_INV(r, x) fe_inv<F>(r, x)
 #endif
 #endif
+#ifndef MSM_BA_SHARED_INV
+#define MSM_BA_SHARED_INV 1  // one inversion per workgroup and lane column (k_batch_add); 0: one per lane, the form of rounds 1-4
+#endif
+static_assert(!MSM_BA_SHARED_INV || BA_THREADS == 256, "the shared inversion is written for four waves per workgroup");
 #ifndef MSM_BA_WAVES
 #define MSM_BA_WAVES 2      // resident waves per SIMD the register allocation is held to (2: 256 VGPRs, 3: 168 + LDS parking)
 #endif
@@ -395,7 +399,53 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
   }
 
   Fe<F> inv;
+#if MSM_BA_SHARED_INV && !defined(BA_X_NOMUL) && !defined(BA_X_NOINV)
+  {
+    // One inversion per WORKGROUP and lane column instead of one per wave.  An inversion costs ~13 pair additions' worth of
+    // instructions and every lane paid one per launch: a quarter of the tree at 2^20, where a lane's chain is 28 - 56 pairs,
+    // 3.6 % of the multiply-adds at 2^26.  The four waves publish their running products in the LDS; every wave multiplies the
+    // other three of its lane column (2 products), wave 0 also its own and inverts the product of all four, and every wave
+    // gets its inverse with one more product: three multiplications of latency around the one inversion, during which the
+    // other three waves leave their issue slots to the other workgroup of the CU.  Measured (profiles/r05_experiments.txt
+    // item 13): 2^20 3.40 -> 3.33 ms, 2^22 10.86 -> 10.67, 2^23 19.88 -> 19.56, 2^26 133.9 -> 132.1; with wave 0 doing all nine
+    // products of the serial form alone: 3.36 / 10.73 / 19.54 / 132.0.
+    constexpr int NLI = F::NL;
+    __shared__ uint32_t xch[NLI * BA_THREADS];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int l = 0; l < NLI; l++) xch[l * BA_THREADS + threadIdx.x] = acc.l[l];
+    __syncthreads();
+    Fe<F> e;
+    {
+      Fe<F> b0, b1, b2;
+#pragma unroll
+      for (int l = 0; l < NLI; l++) {
+        b0.l[l] = xch[l * BA_THREADS + ((wave + 1) & 3u) * 64 + lane];
+        b1.l[l] = xch[l * BA_THREADS + ((wave + 2) & 3u) * 64 + lane];
+        b2.l[l] = xch[l * BA_THREADS + ((wave + 3) & 3u) * 64 + lane];
+      }
+      fe_mul<F>(e, b0, b1);
+      fe_mul<F>(e, e, b2);             // the product of the other three waves' running products
+    }
+    __syncthreads();                   // (everyone has read the running products: the buffer may take the inverse)
+    if (wave == 0) {
+      Fe<F> t, ti;
+      fe_mul<F>(t, e, acc);
+      fe_inv<F>(ti, t);                // 1 / (a0 a1 a2 a3)
+#pragma unroll
+      for (int l = 0; l < NLI; l++) xch[l * BA_THREADS + lane] = ti.l[l];
+    }
+    __syncthreads();
+    {
+      Fe<F> ti;
+#pragma unroll
+      for (int l = 0; l < NLI; l++) ti.l[l] = xch[l * BA_THREADS + lane];
+      fe_mul<F>(inv, ti, e);
+    }
+  }
+#else
   BA_INV(inv, acc);
+#endif
 
   // ---- backward sweep ------------------------------------------------------------------------
   // Order inside one step (what is live where decides the register allocation, hence the resident waves):
