@@ -2,7 +2,6 @@
 // (reference interface replaced: Curve.Parallel.* of src/parallel.ts:135-145,251-259)
 #include "msm_internal.h"
 #include <chrono>
-#include <thread>
 
 using namespace msm;
 using namespace msmi;
@@ -70,11 +69,6 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
 void msm_ctx_destroy(msm_ctx* ctx) {
   if (!ctx) return;
   ctx->fan.clear();
-  if (ctx->twin) {
-    ctx->twin->rows = DevBuf{};   // borrowed
-    msm_ctx_destroy(ctx->twin);
-    ctx->twin = nullptr;
-  }
   for (msm_ctx* c : ctx->children) msm_ctx_destroy(c);
   ctx->children.clear();
   (void)hipSetDevice(ctx->device);
@@ -284,24 +278,6 @@ static int run_piped(msm_ctx* ctx, const void* scalars, uint64_t n, const msm_op
 #endif
     piece_end.push_back(n);
     ctx->ensure(ctx->scal, n * 32);   // before any workspace is sized from what the device has free
-    // Experiment of the tuning build (MSM_PIPE_TWIN=1): odd ranges on a second pipeline of the device (a twin context that borrows
-    // the point rows), so that a range starts as soon as its scalars are there and runs beside its neighbours.  Measured at 2^26:
-    // 156.5 ms either way -- the ranges share the chip and each takes longer, work is conserved (profiles/r05_experiments.txt
-    // item 11).  Off.
-    long long want_twin = 0;
-    MSM_KNOB(want_twin, "MSM_PIPE_TWIN", 0);
-    if (want_twin && !ctx->twin) {
-      msm_ctx* t = nullptr;
-      if (msm_ctx_create(&t, ctx->curve, ctx->device) != MSM_OK) return fail(ctx, MSM_ERR_HIP, "%s: no second pipeline on the device", who);
-      ctx->twin = t;
-    }
-    struct Borrow {   // the twin reads this context's point rows for the length of the call
-      msm_ctx *c, *t;
-      Borrow(msm_ctx* c_, msm_ctx* t_) : c(c_), t(t_) {
-        if (t) { t->rows = c->rows; t->n_points = c->n_points; t->tab_c = t->tab_K = 0; t->ws_limit = c->ws_limit; }
-      }
-      ~Borrow() { if (t) { t->rows = DevBuf{}; t->n_points = 0; } }
-    } borrow(ctx, want_twin ? ctx->twin : nullptr);
     std::vector<size_t> ends;
     for (uint64_t e : piece_end) ends.push_back((size_t)e * 32);
     PieceUpload pipe(ctx, ctx->scal.p, scalars, n * 32, ends);
@@ -329,37 +305,24 @@ static int run_piped(msm_ctx* ctx, const void* scalars, uint64_t n, const msm_op
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     const bool pipe_log = getenv("MSM_PIPE_LOG") != nullptr;
 #endif
-    // the ranges of one pipeline, in order
-    auto lane = [&](msm_ctx* c, size_t first, size_t step) {
-      HIPCHK(hipSetDevice(c->device));
-      for (size_t q = first; q < Q; q += step) {
-        Range& r = R[q];
-        if (r.cnt == 0) continue;
+    // the ranges in order, each as soon as its scalars are in HBM (a second pipeline on the device running the middle range beside
+    // its neighbours was tried and bought nothing -- work is conserved: profiles/r05_experiments.txt item 11)
+    for (size_t q = 0; q < Q; q++) {
+      Range& r = R[q];
+      if (r.cnt == 0) continue;
 #ifdef MSM_TUNING
-        const double t_w0 = since();
+      const double t_w0 = since();
 #endif
-        pipe.wait_piece((int)q, c->stream);
-        HIPCHK(hipStreamSynchronize(c->stream));       // the range's scalars are in HBM
+      pipe.wait_piece((int)q, ctx->stream);
+      HIPCHK(hipStreamSynchronize(ctx->stream));       // the range's scalars are in HBM
 #ifdef MSM_TUNING
-        const double t_w1 = since();
+      const double t_w1 = since();
 #endif
-        window_sums_impl(c, (const uint32_t*)ctx->scal.p + r.lo * 8, r.cnt, 1, &r.o, 0, r.pq.K, r.pq, r.words, &r.st, r.o.point_lo);
+      window_sums_impl(ctx, (const uint32_t*)ctx->scal.p + r.lo * 8, r.cnt, 1, &r.o, 0, r.pq.K, r.pq, r.words, &r.st, r.o.point_lo);
 #ifdef MSM_TUNING
-        if (pipe_log) fprintf(stderr, "range %zu: %llu scalars, c = %d: waited %.2f .. %.2f, ran until %.2f ms (device total %.2f)\n", q,
-                              (unsigned long long)r.cnt, r.pq.c, t_w0, t_w1, since(), r.st.phase_ms[MSM_T_TOTAL]);
+      if (pipe_log) fprintf(stderr, "range %zu: %llu scalars, c = %d: waited %.2f .. %.2f, ran until %.2f ms (device total %.2f)\n", q,
+                            (unsigned long long)r.cnt, r.pq.c, t_w0, t_w1, since(), r.st.phase_ms[MSM_T_TOTAL]);
 #endif
-      }
-    };
-    {
-      std::exception_ptr err, err_t;
-      std::thread side;
-      if (borrow.t && Q >= 2) side = std::thread([&] { try { lane(borrow.t, 1, 2); } catch (...) { err_t = std::current_exception(); } });
-      try { lane(ctx, 0, borrow.t ? 2 : 1); } catch (...) { err = std::current_exception(); }
-      if (side.joinable()) side.join();
-      if (err || err_t) {
-        // (a failure of the twin is reported through this context: MsmFail and HipFail carry their own text)
-        std::rethrow_exception(err ? err : err_t);
-      }
     }
     msm_host::Proj6 acc = ctx->hc.zero();
     for (size_t q = 0; q < Q; q++) {

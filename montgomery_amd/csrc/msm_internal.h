@@ -198,9 +198,6 @@ struct msm_ctx {
   std::vector<void*> allocs;        // device buffers handed out by msm_device_alloc
   // multi-device context (msm_ctx_create_multi): this context drives devices[0], one child context per further device
   std::vector<msm_ctx*> children;
-  // second pipeline on the SAME device (streams, workspaces; `rows` borrowed for the length of a call): the middle range of a
-  // host-scalar MSM runs on it beside its neighbours (run_piped, msm_abi.hip); made by the first such call
-  msm_ctx* twin = nullptr;
   std::vector<std::unique_ptr<msmi::HelperThread>> fan;   // one host thread per child for the window-shard fan-out
 
   // staging / misc buffers shared by all window groups
