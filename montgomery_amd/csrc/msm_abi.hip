@@ -31,6 +31,7 @@ int msm_ctx_create(msm_ctx** out, int curve, int device) {
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
+    for (auto& e : ctx->ev_dig) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipHostMalloc((void**)&ctx->h_info, 64 * 4, hipHostMallocDefault));
     for (auto& w : ctx->ws) {
       HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
@@ -93,6 +94,7 @@ void msm_ctx_destroy(msm_ctx* ctx) {
   for (auto& row : ctx->stage_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
   for (auto& row : ctx->piece_ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->ev_dig) if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -177,6 +177,7 @@ struct msm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[12] = {};
+  hipEvent_t ev_dig[2] = {};   // around the digit kernel that serves both window groups of a call (GroupDigits)
   std::string err;
   int n_cu = 256;
 
@@ -374,8 +375,22 @@ struct SortOut {
   uint64_t rec_y_off = 0;       // 12-word fields: where the y records of round 1's results start inside w.rows1
   bool chunked = false;         // round 1 walks tile-ordered pairs and writes element records, round 2 reads them
 };
+// Digits and slice histograms of SEVERAL window groups from one launch of the digit kernel (the two groups of a call decompose
+// the same scalars: one GLV decomposition instead of two).  sort_window_group(..., share) with share->produce set runs the digit
+// kernel over [k_lo, k_hi) -- all groups' windows -- into w's buffers, fills the rest of `share`, records `ready` and returns;
+// a group's own call then takes its part of the arrays (bin split only) instead of slicing the scalars again.
+struct GroupDigits {
+  bool produce = false;
+  int k_lo = 0;                   // first window of the arrays
+  const uint32_t* dig = nullptr;  // [windows][entries per window]
+  uint32_t* hist = nullptr;       // [windows][sortB][hb]
+  uint32_t hb = 0, sortB = 0;
+  uint64_t pps = 0, chunk = 0;
+  hipEvent_t ready = nullptr;     // behind the digit kernel, on the producing workspace's stream
+  bool valid = false;             // the producer found the bin split applicable and has run
+};
 void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars, uint64_t n, const Plan& pl, int k_lo, int k_hi,
-                       GroupStats& st, SortOut& so);
+                       GroupStats& st, SortOut& so, GroupDigits* share = nullptr);
 // what the tree leaves behind for the bucket reduction
 struct TreeOut {
   const uint4* fin = nullptr;   // tree buffer holding what is left of every bucket

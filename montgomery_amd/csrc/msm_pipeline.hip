@@ -44,14 +44,14 @@ class PairSync {
 // before_tree: called once with the group's stream when everything up to the scatter has been queued (see PairSync).
 void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars_all, uint64_t p_lo, uint64_t n, const Plan& pl,
                       int k_lo, int k_hi, uint32_t* h_partials_out, GroupStats& st, uint64_t p_off = 0,
-                      const std::function<void(hipStream_t)>* before_tree = nullptr) {
+                      const std::function<void(hipStream_t)>* before_tree = nullptr, GroupDigits* share = nullptr) {
   hipStream_t s = w.stream;
   const uint32_t* d_scalars = d_scalars_all + p_lo * 8;   // scalar i of the call <-> resident point p_off + i
   p_lo += p_off;
   const int kc = k_hi - k_lo;
   SortOut so;
   HIPCHK(hipEventRecord(w.ev[0], s));
-  sort_window_group(ctx, w, d_scalars, n, pl, k_lo, k_hi, st, so);
+  sort_window_group(ctx, w, d_scalars, n, pl, k_lo, k_hi, st, so, share);
   st.max_bucket = std::max<uint64_t>(st.max_bucket, so.max_bucket);
   if (before_tree) (*before_tree)(s);
   HIPCHK(hipEventRecord(w.ev[5], s));   // the tree starts here (behind the partner group's sort, if there is one)
@@ -199,6 +199,21 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     for (uint64_t e : piece_end) ends.push_back((size_t)e * 32);
     pipe.reset(new PieceUpload(ctx, ctx->scal.p, scalars, n * 32, ends));
   }
+  // The two window groups of a call slice the same scalars: one launch of the digit kernel (on the first workspace's stream)
+  // writes the digits and slice histograms of both -- one GLV decomposition per scalar instead of two (2^26: the two
+  // concurrent launches took 2.3 ms, the one takes 1.5) -- and each group then takes its part (GroupDigits, msm_sort.hip).
+  GroupDigits share;
+  if (groups.size() == 2 && !pl.tables && !ctx->is_te() && groups[0].piece < 0 && groups[1].piece < 0 &&
+      groups[0].p_lo == groups[1].p_lo && groups[0].p_n == groups[1].p_n && groups[0].kb == groups[1].ka &&
+      groups[1].kb - groups[0].ka <= 16) {   // (the digit kernel describes up to 16 windows: WinSplit)
+    share.produce = true;
+    share.ready = ctx->ev_dig[1];
+    SortOut none;
+    GroupStats gs;
+    HIPCHK(hipEventRecord(ctx->ev_dig[0], ctx->ws[0].stream));
+    sort_window_group(ctx, ctx->ws[0], d_scal + groups[0].p_lo * 8, groups[0].p_n, pl, groups[0].ka, groups[1].kb, gs, none, &share);
+    share.produce = false;
+  }
   std::atomic<int> next{0};
   GroupStats sts[msm_ctx::N_WS];
   const int nthreads = (opts && opts->serial) ? 1 : std::min<int>(msm_ctx::N_WS, (int)groups.size());
@@ -233,7 +248,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       };
       try {
         run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, part.data(), sts[slot], p_off,
-                         pair >= 0 ? &meet : nullptr);
+                         pair >= 0 ? &meet : nullptr, share.valid ? &share : nullptr);
       } catch (...) {
         psync.abort();   // the partner must not wait for a group that will not arrive
         throw;
@@ -306,6 +321,11 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
         host_to_partial(ctx, acc, out);
       }
     }
+  }
+  if (share.valid) {
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev_dig[0], ctx->ev_dig[1]));
+    st.ms_digits += ms;
   }
   for (int i = 0; i < msm_ctx::N_WS; i++) {
     st.n_pairs += sts[i].n_pairs;

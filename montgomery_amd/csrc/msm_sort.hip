@@ -26,8 +26,10 @@ void sort_kernel_attributes() {
 // w.ev[0] (start), w.ev[1] (digits done), w.ev[2] (sort done) and returns after ONE read-back (largest bucket, scan totals ->
 // w.h_info: the launch geometry of the tree)
 void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars, uint64_t n, const Plan& pl, int k_lo, int k_hi,
-                       GroupStats& st, SortOut& so) {
+                       GroupStats& st, SortOut& so, GroupDigits* share) {
   hipStream_t s = w.stream;
+  const bool produce = share && share->produce;              // digits of all groups' windows, nothing else
+  const bool consume = share && !share->produce && share->valid;
   const int kc_d = k_hi - k_lo;             // windows the digit kernel slices
   const uint32_t L = pl.L;
   const bool te = ctx->is_te();
@@ -53,11 +55,15 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   uint32_t logG = 1;
   while (logG < 10 && (1ull << (logG + 1)) * per_bucket_left <= mean) logG++;
 
-  ctx->ensure(w.dig, n_entries * 4);
+  if (!consume) ctx->ensure(w.dig, n_entries * 4);
+  if (produce) {
+    share->valid = false;
+  } else {
   ctx->ensure(w.counts, nb * 4);
   ctx->ensure(w.cursor, (nb + 1) * 4);   // [nb] = the total (k_pscan_final)
   ctx->ensure(w.tail_off, (size_t)34 * (nb + 1) * 4);
   ctx->ensure(w.info, 64 * 4);
+  }
 
   // Sort path: LDS-privatised histogram / ranking, every pass staged through the LDS so that a wave store is a full segment
   // (sort_kernels.h; a direct scatter sends each 4-byte payload to a line of its own: round 1 wrote 7.7x the algorithmic bytes).
@@ -120,7 +126,14 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     sortB = (uint32_t)std::max<uint64_t>(sortB, (n + max_pps - 1) / max_pps);
     pps = (n + sortB - 1) / sortB;
     chunk = (te ? 1 : 2) * pps;
-    ctx->ensure(w.block_hist, (size_t)kc_d * sortB * hb * 4 + 64);
+    if (consume) {
+      // (the producer sliced all groups' windows at once: same slices, and the stride of the widest window's bins)
+      if (share->sortB != sortB || share->pps != pps || share->chunk != chunk || share->hb < hb)
+        throw MsmFail{MSM_ERR_INTERNAL, "shared digits do not match the group's sort geometry"};
+      hb = share->hb;
+    } else {
+      ctx->ensure(w.block_hist, (size_t)kc_d * sortB * hb * 4 + 64);
+    }
   } else {
     // big inputs: finer slices also keep the round-1 gathers of neighbouring lanes inside one Infinity-Cache-sized
     // range of point rows (measured: 193 -> 183 ms at 2^26); small inputs: fewer, larger blocks (less fixed cost)
@@ -133,9 +146,15 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     ctx->ensure(w.block_hist, (size_t)kc * sortB * L * 4 + 64);
   }
   uint32_t* d_bin_start = nullptr;   // bin split: V + 1 starts of the bins in the record array
+  if (produce && (!bin_split || pl.tables)) return;   // (only the bin split takes its histograms from the digit kernel)
+  if (share && !share->produce && !bin_split) throw MsmFail{MSM_ERR_INTERNAL, "shared digits for a group that does not take the bin split"};
+  // where this group's digits and slice histograms are: its own buffers, or its part of the producer's
+  const uint32_t* dig_p = consume ? share->dig + (uint64_t)(k_lo - share->k_lo) * two_n_d : (const uint32_t*)w.dig.p;
+  uint32_t* hist_p = consume ? share->hist + (uint64_t)(k_lo - share->k_lo) * sortB * hb : (uint32_t*)w.block_hist.p;
 
+  if (consume) HIPCHK(hipStreamWaitEvent(s, share->ready, 0));   // (the producer's launch is timed by the caller, not as this group's wait)
   HIPCHK(hipEventRecord(w.ev[0], s));
-  {
+  if (!consume) {
     // digits; the bin split also takes the histogram of its first pass from here (one slice of the points per block)
     const uint32_t grid = bin_split ? sortB : (uint32_t)((n + 255) / 256);
     const uint32_t per = bin_split ? (uint32_t)pps : 256u;
@@ -152,6 +171,18 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
       W_LAUNCH(ctx, k_digits, dim3(grid), dim3(threads), lds, s, (uint32_t*)w.dig.p, d_scalars, (uint32_t)n, pl.c, pl.K, k_lo, kc_d,
                          (pl.no_glv ? 0 : 1) | (pl.fold ? 2 : 0), pl.strict ? 1 : 0, (uint32_t*)ctx->errflag.p, per, hist, hb, pack_fine_bits(ws_d), pl.b_lo, pl.b_n, pl.bt_lo, pl.bt_n);
   }
+  if (produce) {
+    share->k_lo = k_lo;
+    share->dig = (const uint32_t*)w.dig.p;
+    share->hist = (uint32_t*)w.block_hist.p;
+    share->hb = hb;
+    share->sortB = sortB;
+    share->pps = pps;
+    share->chunk = chunk;
+    HIPCHK(hipEventRecord(share->ready, s));
+    share->valid = true;
+    return;
+  }
   HIPCHK(hipEventRecord(w.ev[1], s));
   if (!bin_split) {
     hipLaunchKernelGGL(k_hist, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.block_hist.p,
@@ -165,14 +196,14 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     d_bin_start = d_bin_tot + V;
     ctx->ensure(w.rec, n_entries * 8);
     // (on tables the slices of all kc_d digit windows are the slices of the one merged window, in the same row order)
-    hipLaunchKernelGGL(k_slice_scan, dim3((hb + 31) / 32, kc), dim3(1024), 0, s, (uint32_t*)w.block_hist.p, d_bin_tot,
+    hipLaunchKernelGGL(k_slice_scan, dim3((hb + 31) / 32, kc), dim3(1024), 0, s, hist_p, d_bin_tot,
                        pl.tables ? sortB * (uint32_t)kc_d : sortB, hb, (uint32_t)kc);
     hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_bin_start, (const uint32_t*)d_bin_tot, V, (uint32_t*)w.info.p);
     // a block of pass A takes as many consecutive slices of the digit kernel as make two tiles
     const uint32_t per_block = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(sortB, std::max<uint64_t>(1, (1ull << BS_SPAN_LOG) / chunk)),
                                                             std::max<uint64_t>(1, (2 * (uint64_t)BS_TILE + chunk - 1) / chunk));
     hipLaunchKernelGGL(k_bin_split, dim3((sortB + per_block - 1) / per_block, kc_d), dim3(BS_THREADS), bin_split_lds(hb), s, (uint2*)w.rec.p,
-                       (const uint32_t*)d_bin_start, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n_d, chunk, hb, ws,
+                       (const uint32_t*)d_bin_start, (const uint32_t*)hist_p, dig_p, two_n_d, chunk, hb, ws,
                        pl.tables ? 1u : 0u, sortB, per_block);
     // k_bin_count leaves the largest bucket and the pair count in `info` as k_bucket_max does for the other paths, and writes
     // every bucket of the bins it is launched for: `counts` needs a fill only where a window's digits do not span all L buckets
