@@ -55,7 +55,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   uint32_t logG = 1;
   while (logG < 10 && (1ull << (logG + 1)) * per_bucket_left <= mean) logG++;
 
-  if (!consume) ctx->ensure(w.dig, n_entries * 4);
+  if (!consume && !produce) ctx->ensure(w.dig, n_entries * 4);
   if (produce) {
     share->valid = false;
   } else {
@@ -143,10 +143,11 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     uint64_t maxb = std::max<uint64_t>(1, two_n / 8192);
     sortB = (uint32_t)std::min<uint64_t>(want, maxb);
     chunk = (two_n + sortB - 1) / sortB;
-    ctx->ensure(w.block_hist, (size_t)kc * sortB * L * 4 + 64);
+    if (!produce) ctx->ensure(w.block_hist, (size_t)kc * sortB * L * 4 + 64);
   }
   uint32_t* d_bin_start = nullptr;   // bin split: V + 1 starts of the bins in the record array
   if (produce && (!bin_split || pl.tables)) return;   // (only the bin split takes its histograms from the digit kernel)
+  if (produce) ctx->ensure(w.dig, n_entries * 4);
   if (share && !share->produce && !bin_split) throw MsmFail{MSM_ERR_INTERNAL, "shared digits for a group that does not take the bin split"};
   // where this group's digits and slice histograms are: its own buffers, or its part of the producer's
   const uint32_t* dig_p = consume ? share->dig + (uint64_t)(k_lo - share->k_lo) * two_n_d : (const uint32_t*)w.dig.p;
