@@ -203,7 +203,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   // writes the digits and slice histograms of both -- one GLV decomposition per scalar instead of two (2^26: the two
   // concurrent launches took 2.3 ms, the one takes 1.5) -- and each group then takes its part (GroupDigits, msm_sort.hip).
   GroupDigits share;
-  if (groups.size() == 2 && !pl.tables && !ctx->is_te() && groups[0].piece < 0 && groups[1].piece < 0 &&
+  if (groups.size() == 2 && !ctx->is_te() && groups[0].piece < 0 && groups[1].piece < 0 &&
       groups[0].p_lo == groups[1].p_lo && groups[0].p_n == groups[1].p_n && groups[0].kb == groups[1].ka &&
       groups[1].kb - groups[0].ka <= 16) {   // (the digit kernel describes up to 16 windows: WinSplit)
     share.produce = true;

@@ -146,7 +146,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     if (!produce) ctx->ensure(w.block_hist, (size_t)kc * sortB * L * 4 + 64);
   }
   uint32_t* d_bin_start = nullptr;   // bin split: V + 1 starts of the bins in the record array
-  if (produce && (!bin_split || pl.tables)) return;   // (only the bin split takes its histograms from the digit kernel)
+  if (produce && !bin_split) return;   // (only the bin split takes its histograms from the digit kernel)
   if (produce) ctx->ensure(w.dig, n_entries * 4);
   if (share && !share->produce && !bin_split) throw MsmFail{MSM_ERR_INTERNAL, "shared digits for a group that does not take the bin split"};
   // where this group's digits and slice histograms are: its own buffers, or its part of the producer's
