@@ -239,13 +239,16 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   // Big windows over a big table: round 1 walks the pairs in the order the last pass of the sort emits them -- tile by tile of
   // a bin's records, which are in point order -- and writes every sum to the element index that comes with the pair, as
   // 64-byte records that round 2 reads back (batch_add.h).  Needed once the 128 slots of a wave span more than ~1 GB of
-  // rows: 64 L rows of 256 bytes, i.e. from c = 18 with more than 2^22 points.
+  // rows (measured: from 2 GB of rows, see below).  Smaller tables take the bucket-ordered slots of k_bin_slots.
   const uint32_t* round1_slots = nullptr;
   const uint32_t* round1_dest = nullptr;
   uint64_t rec_y_off = 0;   // 12-word fields: where the y records of round 1's results start inside w.rows1
   bool chunked = false;
   {
-    long long chunk_rows_log = 22;   // 2^22 rows of 256 bytes = 1 GB
+    // from more than 2^23 rows of 256 bytes = 2 GB (measured, tools/chunk_plain.py and MSM_CHUNK_LOG of the tuning build: at
+    // 2^23 rows -- 2^23 points, or 2^20 on seven window tables -- the plain slot form is 2.5 % ahead: 20.15 against 20.64 ms,
+    // 3.23 / 3.32; at 2^23.8 rows level; at 2^24 rows the tile order wins by 10 %: 38.6 against 43.0)
+    long long chunk_rows_log = 23;
     MSM_KNOB(chunk_rows_log, "MSM_CHUNK_LOG", 10);
     const uint64_t table_rows = pl.tables ? (uint64_t)kc_d * n : n;
     long long want_chunks = (bin_split && !te && pl.c >= 18 && table_rows > (1ull << chunk_rows_log)) ? 1 : 0;
