@@ -133,7 +133,9 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   const int nwin = k_hi - k_lo;
   // measured on MI355X: two groups win 14 % at 2^23 / 2^24, 3 % at 2^22, nothing at 2^21 -- below that the fixed
   // per-group latencies (read-backs, bucket reduction depth) cost more than the overlap returns
-  int want_groups = (nwin >= 2 && n >= (1ull << 22)) ? 2 : 1;
+  // (on window tables from 2^21: 5.87 -> 5.73 ms, Edwards 3.96 -> 3.72; the plain path at 2^21 prefers one group, 6.71 / 6.88; at
+  // 2^20 one group wins on tables too, 3.24 / 3.33 -- round 5, tools/knob_sweep.sh MSM_GROUPS)
+  int want_groups = (nwin >= 2 && (n >= (1ull << 22) || (pl.tables && n >= (1ull << 21)))) ? 2 : 1;
   MSM_KNOB(want_groups, "MSM_GROUPS", 1);
   wpg = std::max(1, std::min(wpg, (nwin + want_groups - 1) / want_groups));
   struct Group {
