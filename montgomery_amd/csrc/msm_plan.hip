@@ -65,14 +65,14 @@ int pick_window(bool te, uint64_t n, int glv_max_bits) {
 // On window tables all windows of a group share one set of buckets, so a wider window costs its 2^(c-1) buckets once instead
 // of K times and the optimum moves up.  BLS12-377 after GLV (127 bits: 18- and 21-bit windows fold the carry bit, no short top
 // window to skew the merged buckets), measured with tools/tables_csweep.py (profiles/r05_experiments.txt item 5): 16 bits below
-// 2^15 points, 18 from there (2^18 1.58 against 1.76 ms plain, 2^20 3.65 / 3.90, 2^22 11.0 / 11.9, 2^23 20.3 / 21.7), 21 from
+// 2^16 points, 18 from there (2^18 1.58 against 1.76 ms plain, 2^20 3.65 / 3.90, 2^22 11.0 / 11.9, 2^23 20.3 / 21.7), 21 from
 // 2^24 (36.7 / 40.1).  BLS12-381 and Pallas keep the plain choice (their 18-bit plan would end in a two-bit top window).
 // Ed-on-BLS12-377 (252 bits, no endomorphism: K = 13 .. 28 windows on the plain path, whose reduction and host tail grow with K):
 // 14 bits below 2^17 points, 17 from there (K = 15; 2^18 0.98 against 1.09 ms plain, 2^20 2.11 / 2.63, 2^22 7.3 / 8.6; 16 bits
 // 2.28, 18 bits 2.17 at 2^20) -- with the merged window's sums finished bit-sliced (reduce_buckets).
 static int pick_window_tables(bool te, uint64_t n, int glv_max_bits) {
   if (te) return n >= (1ull << 17) ? 17 : 14;
-  if (glv_max_bits == 126) return n >= (1ull << 24) ? 21 : n >= (1ull << 15) ? 18 : 16;
+  if (glv_max_bits == 126) return n >= (1ull << 24) ? 21 : n >= (1ull << 16) ? 18 : 16;   // (2^15: 0.86 ms at 16 bits, 0.90 at 18; 2^16: 1.03 / 1.00)
   return pick_window(te, n, glv_max_bits);
 }
 
