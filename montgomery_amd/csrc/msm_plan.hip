@@ -43,12 +43,15 @@ int pick_window(bool te, uint64_t n, int glv_max_bits) {
   // b = 126 (BLS12-377 after GLV): 127 = 6 * 21 + 1, so 21-bit windows fold the carry bit into the sixth window (make_plan) --
   // K = 6 with half the buckets of the 22-bit plan: 2^24 43.6 against 44.3 (c = 16), 2^25 79.7 against 80.7, 2^26 148.9 against
   // 151.5 (c = 22) and 158.3 (c = 16), 2^27 302.8 against 311.5 (c = 22) on one box (profiles/r04_experiments.txt item 13).
-  // b = 127 (BLS12-381, Pallas): 128 = 5 * 22 + 18, the 22-bit plan has six whole windows from 2^26 points up.
+  // b = 127 (BLS12-381, Pallas): 128 = 5 * 22 + 18, the 22-bit plan has six whole windows (from 2^25 points, see below).
   // (127 = 7 * 18 + 1 folds too: seven 18-bit windows win from 2^22 points to 2^24 -- with the round-5 sort of the big windows
   // 2^22 11.4 against 12.1 ms, 2^23 20.6 / 21.8, level at 2^21 (6.8), behind the 21-bit plan at 2^24 (41.3 / 39.5): tools/plan_sweep.py)
   if (!te && glv_max_bits == 126)
     return n >= (1ull << 24) ? 21 : n >= (1ull << 22) ? 18 : n >= 4096 ? 16 : 8;
-  if (!te) return n >= (1ull << 26) ? 22 : n >= 4096 ? 16 : 8;
+  // b = 127 (BLS12-381, Pallas), with the round-5 sort of the big windows (tools/plan_sweep_curve.py, c = 16 / 19 / 22):
+  // BLS12-381 2^23 22.6 / 22.1 / 24.7 ms, 2^24 44.0 / 43.3 / 44.0, 2^25 81.6 / 80.5 / 75.0; Pallas 2^23 15.6 / 14.5 / 16.3,
+  // 2^24 32.0 / 30.6 / 29.7, 2^25 58.6 / 59.0 / 55.8; level at 2^22
+  if (!te) return n >= (1ull << 25) ? 22 : n >= (1ull << 23) ? 19 : n >= 4096 ? 16 : 8;
   static const int cand_te[] = {4, 6, 7, 9, 12, 14, 16};
   const int b1 = 252;
   int best = 4;

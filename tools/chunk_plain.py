@@ -1,5 +1,6 @@
+"""One size on the plain path (no window tables), best of five warmed-up calls: python tools/chunk_plain.py LOG2N"""
 import sys, time, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from montgomery_amd.api import MsmContext
 lg = int(sys.argv[1]); n = 1 << lg
 ctx = MsmContext(); ctx.generate_points(n, seed=7); dev, _ = ctx.generate_scalars(n, seed=9)
