@@ -52,6 +52,9 @@ int pick_window(bool te, uint64_t n, int glv_max_bits) {
   // BLS12-381 2^23 22.6 / 22.1 / 24.7 ms, 2^24 44.0 / 43.3 / 44.0, 2^25 81.6 / 80.5 / 75.0; Pallas 2^23 15.6 / 14.5 / 16.3,
   // 2^24 32.0 / 30.6 / 29.7, 2^25 58.6 / 59.0 / 55.8; level at 2^22
   if (!te) return n >= (1ull << 25) ? 22 : n >= (1ull << 23) ? 19 : n >= 4096 ? 16 : 8;
+  // Edwards plain path with the bin split of round 5 (tools/plan_sweep_curve.py 1, ms at c = 16 / 18): 2^22 8.6 / 7.9, 2^23 15.0 / 14.2,
+  // 2^24 28.0 / 26.3, 2^25 53.4 / 54.4, 2^26 101.8 / 105.7 (its gather round is not tile-ordered: beyond 2^25 the big windows lose)
+  if (te && n >= (1ull << 22) && n < (1ull << 25)) return 18;
   static const int cand_te[] = {4, 6, 7, 9, 12, 14, 16};
   const int b1 = 252;
   int best = 4;
