@@ -377,9 +377,10 @@ static int run_impl(msm_ctx* ctx, const void* scalars, const void* const* placed
     // window tables (msm_tables.hip): built here on the first default-plan call over the whole point set
     pl.tables = tables_wanted && use_window_tables(ctx, n, opts, pl, /*may_build=*/true);
     any_window_sums(ctx, scalars, n, on_device, opts, 0, pl.K, pl, words, out, placed);
-    out->tables = pl.tables ? 1 : 0;
     HIPCHK(hipEventRecord(ctx->ev[10], ctx->stream));
-    const int slots = pl.tables ? 1 : pl.K;   // on tables slot 0 holds the whole sum, weights included: no Horner step
+    // (a run on tables leaves the whole sum, weights included, in slot 0 and identities in the others: the Horner step over all
+    // K slots returns it unchanged, and is what a call that had to leave the tables -- ranges of the points -- needs)
+    const int slots = pl.K;
     if (ctx->is_te()) {
       te_horner_to_affine(ctx, words, slots, pl.c, out);
     } else {

@@ -193,7 +193,7 @@ struct msm_ctx {
   // Window tables of the CURRENT point set (msm_tables.hip): `rows` then holds tab_K tables of n_points rows each, table k =
   // 2^(tab_c k) P (0: none, `rows` is the plain table).  Travel with the set through msm_pointset_select.
   int tab_c = 0, tab_K = 0;
-  uint64_t tables_limit = 0;   // bytes the tables of one point set may take (msm_set_tables_limit; default: 40 % of the device)
+  uint64_t tables_limit = 0;   // bytes the tables of one point set may take (msm_set_tables_limit; default: 10 % of the device)
   std::vector<PointSet> sets = std::vector<PointSet>(1);   // slot 0 = the default set
   int cur_set = 0;
   std::vector<void*> allocs;        // device buffers handed out by msm_device_alloc
@@ -220,14 +220,15 @@ struct msm_ctx {
   // window group runs under the ALU-bound accumulation of the other
   struct Workspace {
     msmi::DevBuf dig, counts, cursor, tail_off, info, slots, block_hist, scan_partial, desc, columns2, rows_sum, bucket_proj, bufA, bufB,
-        scratch, columns, partials, part, dig2, idx2, rec, blk_tab2, slots2, dest, rows1;
+        scratch, columns, partials, part, dig2, idx2, rec, blk_tab2, slots2, dest, rows1, parts, sub;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;   // read-backs that the host needs while `stream` goes on (the sort's totals under its last pass)
     hipEvent_t ev[8] = {};        // (ev[7]: the scans of the bucket sizes are done)
     uint32_t* h_info = nullptr;   // pinned, 64 words
     uint32_t* h_part = nullptr;   // pinned, window sums read-back
-    msmi::DevBuf* all[25] = {&dig, &counts, &cursor, &tail_off, &info, &slots, &block_hist, &scan_partial, &desc, &columns2, &rows_sum,
-                       &bucket_proj, &bufA, &bufB, &scratch, &columns, &partials, &part, &dig2, &idx2, &rec, &blk_tab2, &slots2, &dest, &rows1};
+    msmi::DevBuf* all[27] = {&dig, &counts, &cursor, &tail_off, &info, &slots, &block_hist, &scan_partial, &desc, &columns2, &rows_sum,
+                       &bucket_proj, &bufA, &bufB, &scratch, &columns, &partials, &part, &dig2, &idx2, &rec, &blk_tab2, &slots2, &dest, &rows1,
+                       &parts, &sub};
   };
   static constexpr int N_WS = 2;
   Workspace ws[N_WS];

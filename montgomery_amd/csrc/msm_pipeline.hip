@@ -80,7 +80,8 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
 
 // windows [k_lo, k_hi) over the resident points [p_off, p_off + n); scalars[i] belongs to point p_off + i
 int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts, int k_lo, int k_hi,
-                     const Plan& pl, std::vector<uint32_t>& words, msm_result* stats, uint64_t p_off) {
+                     const Plan& pl_in, std::vector<uint32_t>& words, msm_result* stats, uint64_t p_off) {
+  Plan pl = pl_in;   // (a call that turns out to run over ranges of the points leaves the window tables: see below)
   const uint32_t* d_scal = nullptr;
   HIPCHK(hipEventRecord(ctx->ev[8], ctx->stream));
   // Host scalars of a big call cross PCIe BEHIND the computation, range by range of the points (PieceUpload); everything
@@ -129,6 +130,9 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     const uint64_t entries = ctx->is_te() ? n : 2 * n;
     const bool fits_lds = ((size_t)pl.L * 4 <= 128 * 1024);
     if (pl.c - 1 > (int)RX_FINE_BITS && (!fits_lds || entries >= (ctx->is_te() ? 1ull << 22 : 1ull << 21))) wpg = std::min(wpg, 16);
+    // (on window tables the merged window of a group may take the bin split whatever a single digit window would have taken,
+    // and the digit kernel describes the fine bits of at most 16 windows: pack_fine_bits)
+    if (pl.tables) wpg = std::min(wpg, 16);
   }
   const int nwin = k_hi - k_lo;
   // measured on MI355X: two groups win 14 % at 2^23 / 2^24, 3 % at 2^22, nothing at 2^21 -- below that the fixed
@@ -193,6 +197,12 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   // does more than one group contribute to a window?  Then the sums of its ranges are added on the host below.
   bool split_points = false;
   for (const Group& g : groups) split_points |= g.p_n != n;
+  // Window tables address row k * n_points + i of the resident set from the entry index alone, which counts from the GROUP's
+  // first point and in units of the group's own n: a group over a range of the points (a tight workspace limit, the retry
+  // after an out-of-memory error, host scalars arriving range by range) would read other points' rows.  Such a call runs the
+  // plain path under the same window -- table 0 is the plain row table -- and hands back one sum per window slot, which the
+  // caller's Horner step takes like the one weighted sum of a run on tables.
+  if (pl.tables && (split_points || n != ctx->n_points || p_off != 0)) pl.tables = false;
   std::vector<std::vector<uint32_t>> split_part((split_points || pl.tables) ? groups.size() : 0);
   HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));   // staged scalars are in place before the group streams start
@@ -356,6 +366,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     stats->rounds = st.rounds;
     stats->c = pl.c;
     stats->K = pl.K;
+    stats->tables = pl.tables ? 1 : 0;
   }
   return MSM_OK;
 }

@@ -88,7 +88,6 @@ int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl, bo
   const int glv_arg = (opts && opts->no_glv) ? 0 : glv_bits;
   int c = (opts && opts->c > 0) ? opts->c : for_tables ? pick_window_tables(te, n, glv_arg) : pick_window(te, n, glv_arg);
   if (c < 2 || c > 24) return MSM_ERR_ARG;
-  // b = Scalar.maxBits (126 after GLV, src/wasm/glv.ts:216-226) or Scalar.sizeInBits (251, src/msm-basic.ts:56)
   // b = Scalar.maxBits after GLV (src/wasm/glv.ts:216-226), or the bit length of q without it (src/msm-basic.ts:56)
   pl.no_glv = !te && opts && opts->no_glv;
   pl.strict = opts && opts->strict;

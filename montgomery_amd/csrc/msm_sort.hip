@@ -146,6 +146,23 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     if (!produce) ctx->ensure(w.block_hist, (size_t)kc * sortB * L * 4 + 64);
   }
   uint32_t* d_bin_start = nullptr;   // bin split: V + 1 starts of the bins in the record array
+  uint32_t *d_extra_first = nullptr, *d_mp_first = nullptr, *d_part_pair_off = nullptr;   // bin split: the parts of heavy bins
+  uint32_t part_len = 0, part_grid = 0;
+  // Big windows over a big table: round 1 walks the pairs in the order the last pass of the sort emits them (see below); decided
+  // here because the count pass of the bin split prepares the parts of heavy bins for that pass.
+  bool will_chunk = false;
+  {
+    // from more than 2^23 rows of 256 bytes = 2 GB (measured, tools/chunk_plain.py and MSM_CHUNK_LOG of the tuning build: at
+    // 2^23 rows -- 2^23 points, or 2^20 on seven window tables -- the plain slot form is 2.5 % ahead: 20.15 against 20.64 ms,
+    // 3.23 / 3.32; at 2^23.8 rows level; at 2^24 rows the tile order wins by 10 %: 38.6 against 43.0)
+    long long chunk_rows_log = 23;
+    MSM_KNOB(chunk_rows_log, "MSM_CHUNK_LOG", 10);
+    const uint64_t table_rows = pl.tables ? (uint64_t)kc_d * n : n;
+    long long want_chunks = (bin_split && !te && pl.c >= 18 && table_rows > (1ull << chunk_rows_log)) ? 1 : 0;
+    MSM_KNOB(want_chunks, "MSM_CHUNKED", 0);
+    // (round 2 must be an index-free round to read the element records round 1 then writes: logG >= 2)
+    will_chunk = bin_split && want_chunks && !te && logG >= 2;
+  }
   if (produce && !bin_split) return;   // (only the bin split takes its histograms from the digit kernel)
   if (produce) ctx->ensure(w.dig, n_entries * 4);
   if (share && !share->produce && !bin_split) throw MsmFail{MSM_ERR_INTERNAL, "shared digits for a group that does not take the bin split"};
@@ -211,8 +228,23 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     bool spans_all = true;
     for (int kk = 0; kk < kc; kk++) spans_all &= (1u << ws.ab[kk]) == hb && (int)ws.ab[kk] + (int)ws.fb[kk] == cbits;
     if (!spans_all) HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));   // (`info` was cleared by k_vscan)
-    hipLaunchKernelGGL(k_bin_count, dim3(V), dim3(BC_THREADS), (size_t)nbmax * 4, s, (uint32_t*)w.counts.p, (const uint32_t*)d_bin_start,
-                       (const uint2*)w.rec.p, hb, L, ws, (uint32_t*)w.info.p);
+    // heavy bins are cut into parts of part_len records, one block each (sort_kernels.h, "Parts of heavy bins"): twice the mean
+    // bin, so that uniform digits never see one; a multiple of the tile of pass B
+    part_len = (uint32_t)std::max<uint64_t>(1u << 16, ((2 * n_entries / V + BP_TILE - 1) / BP_TILE) * BP_TILE);
+    part_grid = V + V / 2 + 1;
+    ctx->ensure(w.parts, ((size_t)2 * (V + 1) + (V + 2)) * 4);
+    d_extra_first = (uint32_t*)w.parts.p;
+    d_mp_first = d_extra_first + (V + 1);
+    d_part_pair_off = d_mp_first + (V + 1);
+    ctx->ensure(w.sub, (size_t)(V + 2) * nbmax * 4);   // rows: the parts of multi-part bins, at most V of them
+    hipLaunchKernelGGL(k_bin_parts, dim3(1), dim3(SCAN_THREADS), 0, s, d_extra_first, d_mp_first, (const uint32_t*)d_bin_start, V, hb, part_len, ws);
+    HIPCHK(hipMemsetAsync(d_part_pair_off, 0, (size_t)(V + 2) * 4, s));
+    hipLaunchKernelGGL(k_bin_count, dim3(part_grid), dim3(BC_THREADS), (size_t)nbmax * 4, s, (uint32_t*)w.counts.p, (const uint32_t*)d_bin_start,
+                       (const uint2*)w.rec.p, hb, L, ws, (uint32_t*)w.info.p, V, (const uint32_t*)d_extra_first, (const uint32_t*)d_mp_first,
+                       part_len, (uint32_t*)w.sub.p, nbmax);
+    hipLaunchKernelGGL(k_part_scan, dim3(V), dim3(PSC_THREADS), 0, s, (uint32_t*)w.counts.p, (uint32_t*)w.sub.p, d_part_pair_off,
+                       (const uint32_t*)d_extra_first, (const uint32_t*)d_mp_first, hb, L, nbmax, ws, (uint32_t*)w.info.p,
+                       will_chunk ? 1u : 0u);
   }
   int RT = 0;
   uint64_t total_slots = 0;
@@ -243,24 +275,15 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   const uint32_t* round1_slots = nullptr;
   const uint32_t* round1_dest = nullptr;
   uint64_t rec_y_off = 0;   // 12-word fields: where the y records of round 1's results start inside w.rows1
-  bool chunked = false;
-  {
-    // from more than 2^23 rows of 256 bytes = 2 GB (measured, tools/chunk_plain.py and MSM_CHUNK_LOG of the tuning build: at
-    // 2^23 rows -- 2^23 points, or 2^20 on seven window tables -- the plain slot form is 2.5 % ahead: 20.15 against 20.64 ms,
-    // 3.23 / 3.32; at 2^23.8 rows level; at 2^24 rows the tile order wins by 10 %: 38.6 against 43.0)
-    long long chunk_rows_log = 23;
-    MSM_KNOB(chunk_rows_log, "MSM_CHUNK_LOG", 10);
-    const uint64_t table_rows = pl.tables ? (uint64_t)kc_d * n : n;
-    long long want_chunks = (bin_split && !te && pl.c >= 18 && table_rows > (1ull << chunk_rows_log)) ? 1 : 0;
-    MSM_KNOB(want_chunks, "MSM_CHUNKED", 0);
-    // (round 2 must be an index-free round to read the element records round 1 then writes: logG >= 2)
-    chunked = bin_split && want_chunks && !te && logG >= 2;
-  }
+  bool chunked = will_chunk;
   // The bin split's last pass needs nothing from the host but room for what it writes, and the padded slots have a bound --
   // every non-empty bucket pads by less than G -- so it is launched BEHIND the scans at once and the read-back of the totals
   // (which the tree's launches wait for) crosses on a side stream while it runs: no idle gap of a host round trip in front of
   // it (25 us of the 3.4 ms of an MSM over 2^20 points).
-  const uint64_t slots_bound = n_entries + (((uint64_t)1 << logG) - 1) * std::min<uint64_t>(nb, n_entries);
+  // (the parts of a heavy bin pair their entries up on their own: a bucket gains at most one slot per part that holds an odd
+  // number of its entries -- sort_kernels.h, "Parts of heavy bins")
+  const uint64_t parts_extra = will_chunk ? std::min<uint64_t>(n_entries, (uint64_t)V * nbmax) : 0;
+  const uint64_t slots_bound = n_entries + parts_extra + (((uint64_t)1 << logG) - 1) * std::min<uint64_t>(nb, n_entries);
   auto launch_bin_pass = [&](uint64_t slots_cap) {
     if (chunked) {
       const uint64_t pairs_cap = slots_cap / 2 + 1;
@@ -268,16 +291,19 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
       ctx->ensure(w.dest, pairs_cap * 4);
       rec_y_off = (pairs_cap * 64 + 255) & ~(uint64_t)255;
       ctx->ensure(w.rows1, 2 * rec_y_off + 256);
-      hipLaunchKernelGGL(k_bin_pairs, dim3(V), dim3(BP_THREADS), bin_pairs_lds(nbmax), s, (uint2*)w.slots2.p, (uint32_t*)w.dest.p,
-                         (const uint2*)w.rec.p, (const uint32_t*)d_bin_start, (const uint32_t*)w.cursor.p, hb, L, nbmax, ws);
+      hipLaunchKernelGGL(k_bin_pairs, dim3(part_grid), dim3(BP_THREADS), bin_pairs_lds(nbmax), s, (uint2*)w.slots2.p, (uint32_t*)w.dest.p,
+                         (const uint2*)w.rec.p, (const uint32_t*)d_bin_start, (const uint32_t*)w.cursor.p, hb, L, nbmax, ws, V,
+                         (const uint32_t*)d_extra_first, (const uint32_t*)d_mp_first, part_len, (const uint32_t*)w.sub.p,
+                         (const uint32_t*)d_part_pair_off);
       round1_slots = (const uint32_t*)w.slots2.p;
       round1_dest = (const uint32_t*)w.dest.p;
     } else {
       ctx->ensure(w.slots, std::max<uint64_t>(slots_cap, 2) * 4);
       HIPCHK(hipMemsetAsync(w.slots.p, 0xFF, std::max<uint64_t>(slots_cap, 2) * 4, s));
       round1_slots = (const uint32_t*)w.slots.p;
-      hipLaunchKernelGGL(k_bin_slots, dim3(V), dim3(BP_THREADS), bin_slots_lds(nbmax), s, (uint32_t*)w.slots.p,
-                         (const uint2*)w.rec.p, (const uint32_t*)d_bin_start, (const uint32_t*)w.cursor.p, hb, L, nbmax, ws);
+      hipLaunchKernelGGL(k_bin_slots, dim3(part_grid), dim3(BP_THREADS), bin_slots_lds(nbmax), s, (uint32_t*)w.slots.p,
+                         (const uint2*)w.rec.p, (const uint32_t*)d_bin_start, (const uint32_t*)w.cursor.p, hb, L, nbmax, ws, V,
+                         (const uint32_t*)d_extra_first, (const uint32_t*)d_mp_first, part_len, (const uint32_t*)w.sub.p);
     }
   };
   if (bin_split) launch_bin_pass(slots_bound);

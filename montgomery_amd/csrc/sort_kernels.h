@@ -745,14 +745,174 @@ __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// Parts of heavy bins (round 6).  The count pass and pass B give one block to a bin, which is right while the digits are
+// spread -- a bin is 1 / 2^10 of a window -- and a bound on nothing when they are not: one scalar repeated puts every entry of
+// a window into ONE bin (2^27 records for one block at 2^26 points: the reference walks any bucket-size distribution through the
+// same loop, src/msm-batched-affine.ts:204,243-263).  A bin of more than `part_len` records (twice the mean bin, at least 2^16)
+// is therefore cut into parts of part_len records, one block each:
+//   * block p < V works for bin p's first part as before; blocks V .. V + extra_first[V] take the further parts of the bins
+//     that have any (binary search in extra_first); the host launches V + V / 2 blocks, an upper bound without a read-back
+//     (sum of ceil(size / part_len) <= V + entries / part_len <= V + V / 2);
+//   * the count pass leaves the bucket sizes of a part of a multi-part bin in a row of `sub` (mp_first[v] + j) instead of
+//     `counts`; k_part_scan turns the rows of a bin into exclusive prefixes over its parts and writes the bin's `counts`;
+//   * pairs (k_bin_pairs): entries pair up inside their part only -- an odd one out is paired with nothing when its part ends --
+//     so a bucket's round-1 elements are the concatenation of ceil(n_part / 2) per part: `counts` gets 2 * that sum (the slots a
+//     bucket is padded from), the prefix is in elements, and part_pair_off[row] says where in the bin's run of the pair list the
+//     part starts;  slots (k_bin_slots): the prefix is in entries and `counts` is the true size.
+// Uniform digits never have a multi-part bin: one extra launch (k_part_scan, every block returns at once) and V / 2 blocks of
+// the two passes that return at once.
+// ---------------------------------------------------------------------------------------------
+struct PartLoc {
+  uint32_t v, j, np, row;   // bin, part of the bin, parts of the bin, row of `sub` (np > 1)
+  uint64_t beg, end;        // the part's records
+  bool valid;
+};
+// block p of a parts grid (see above); reverse: the first V blocks take the bins from the last (the heaviest: a short top window's)
+__device__ __forceinline__ PartLoc locate_part(uint32_t p, uint32_t V, const uint32_t* bin_start, const uint32_t* extra_first,
+                                               const uint32_t* mp_first, uint32_t part_len, bool reverse) {
+  PartLoc L;
+  L.valid = true;
+  if (p < V) {
+    L.v = reverse ? V - 1 - p : p;
+    L.j = 0;
+  } else {
+    const uint32_t q = p - V;
+    if (q >= extra_first[V]) { L.valid = false; L.v = L.j = L.np = L.row = 0; L.beg = L.end = 0; return L; }
+    uint32_t lo = 0, hi = V;   // last bin whose extra parts start at or before q
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (extra_first[mid] <= q) lo = mid; else hi = mid;
+    }
+    L.v = lo;
+    L.j = 1 + q - extra_first[lo];
+  }
+  L.np = extra_first[L.v + 1] - extra_first[L.v] + 1;
+  L.row = mp_first[L.v] + L.j;
+  const uint64_t b0 = bin_start[L.v], b1 = bin_start[L.v + 1];
+  L.beg = b0 + (uint64_t)L.j * part_len;
+  L.end = L.np == 1 ? b1 : min(b1, L.beg + (uint64_t)part_len);
+  return L;
+}
+
+// extra_first[v] = parts beyond the first of the bins before v, mp_first[v] = rows of `sub` of the bins before v (V + 1 entries each)
+__global__ void __launch_bounds__(SCAN_THREADS) k_bin_parts(uint32_t* extra_first, uint32_t* mp_first, const uint32_t* bin_start, uint32_t V,
+                                                            uint32_t hb, uint32_t part_len, WinSplit ws)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
+  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
+  uint32_t carry_e = 0, carry_m = 0;
+  for (uint32_t base = 0; base < V; base += SCAN_THREADS) {
+    const uint32_t v = base + threadIdx.x;
+    uint32_t np = 1;
+    if (v < V) {
+      const uint32_t kk = v / hb, size = bin_start[v + 1] - bin_start[v];
+      if (ws.fb[kk] != 0 && size > part_len) np = (size + part_len - 1) / part_len;   // (a window pass A sorted outright has no parts)
+    }
+    uint32_t tot_e, tot_m;
+    const uint32_t ex_e = block_excl_scan(np - 1, lds_wave, tot_e) + carry_e;
+    __syncthreads();
+    const uint32_t ex_m = block_excl_scan(np > 1 ? np : 0u, lds_wave, tot_m) + carry_m;
+    __syncthreads();
+    if (v < V) { extra_first[v] = ex_e; mp_first[v] = ex_m; }
+    carry_e += tot_e;
+    carry_m += tot_m;
+  }
+  if (threadIdx.x == 0) { extra_first[V] = carry_e; mp_first[V] = carry_m; }
+}
+#endif
+
+// Bins of several parts: sub[row of part j][bucket] = the part's entries of the bucket (k_bin_count) -> the exclusive prefix over
+// the parts, in round-1 elements (pairs_mode: ceil(n / 2) per part) or in entries; counts[bucket] = 2 * the sum of the parts'
+// elements, or the true size; part_pair_off[row] = pairs the parts before it emit (zeroed before the launch); the largest bucket
+// and the algorithmic pair additions of these bins go to `info` as k_bin_count leaves them for the others.  One block per bin.
+constexpr int PSC_THREADS = 1024;
+__global__ void __launch_bounds__(PSC_THREADS) k_part_scan(uint32_t* counts, uint32_t* sub, uint32_t* part_pair_off, const uint32_t* extra_first,
+                                                           const uint32_t* mp_first, uint32_t hb, uint32_t L, uint32_t nbmax, WinSplit ws,
+                                                           uint32_t* info, uint32_t pairs_mode)
+#ifndef MSM_SORT_TU
+    ;
+#else
+{
+  __shared__ uint32_t lds_wave[PSC_THREADS / 64];
+  __shared__ uint32_t lds_max;
+  __shared__ unsigned long long lds_sum;
+  const uint32_t v = blockIdx.x, tid = threadIdx.x;
+  const uint32_t np = extra_first[v + 1] - extra_first[v] + 1;
+  if (np == 1) return;
+  const uint32_t kk = v / hb, h = v - kk * hb, fb = ws.fb[kk], NB = 1u << fb, row0 = mp_first[v];
+  uint32_t* out = counts + (uint64_t)kk * L + ((uint64_t)h << fb);
+  if (tid == 0) { lds_max = 0; lds_sum = 0; }
+  __syncthreads();
+  constexpr int IT = ((1 << BS_MAX_FB) + PSC_THREADS - 1) / PSC_THREADS;   // buckets per thread
+  uint32_t run[IT], tot[IT];
+#pragma unroll
+  for (int i = 0; i < IT; i++) run[i] = tot[i] = 0;
+  for (uint32_t j = 0; j < np; j++) {
+    uint32_t* r = sub + (uint64_t)(row0 + j) * nbmax;
+    uint32_t n[IT], pp = 0;
+#pragma unroll
+    for (int i = 0; i < IT; i++) { const uint32_t bk = tid + i * PSC_THREADS; n[i] = bk < NB ? r[bk] : 0u; }
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+      const uint32_t bk = tid + i * PSC_THREADS, el = pairs_mode ? (n[i] + 1) >> 1 : n[i];
+      if (bk < NB) r[bk] = run[i];
+      run[i] += el;
+      tot[i] += n[i];
+      pp += (n[i] + 1) >> 1;
+    }
+    if (pairs_mode) {
+      for (int o = 32; o > 0; o >>= 1) pp += __shfl_down(pp, o);
+      if ((tid & 63u) == 0 && pp) atomicAdd(&part_pair_off[row0 + j], pp);
+    }
+  }
+  uint32_t mx = 0;
+  unsigned long long sum = 0;
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    const uint32_t bk = tid + i * PSC_THREADS;
+    if (bk < NB) {
+      const uint32_t cnt = pairs_mode ? 2 * run[i] : tot[i];
+      out[bk] = cnt;
+      mx = max(mx, cnt);
+      sum += tot[i] ? tot[i] - 1 : 0;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o); mx = max(mx, (uint32_t)__shfl_down(mx, o)); }
+  if ((tid & 63u) == 0 && (mx | sum)) { atomicMax(&lds_max, mx); atomicAdd(&lds_sum, sum); }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    atomicMax(&info[1], lds_max);
+    atomicAdd(reinterpret_cast<unsigned long long*>(info + INFO_ALGO_PAIRS), lds_sum);
+  }
+  if (!pairs_mode) return;
+  // pairs per part -> where the part starts in the bin's run of the pair list
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < np; base += PSC_THREADS) {
+    const uint32_t j = base + tid;
+    const uint32_t x = j < np ? __hip_atomic_load(&part_pair_off[row0 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    uint32_t t;
+    const uint32_t ex = block_excl_scan(x, lds_wave, t) + carry;
+    __syncthreads();
+    if (j < np) part_pair_off[row0 + j] = ex;
+    carry += t;
+  }
+}
+#endif
+
 // bucket sizes of bin v = kk * hb + h (the 2^fb buckets from h << fb of window kk) from its records; `counts` is zeroed before.
 // 1024 threads and two records per 16-byte load: with 256 threads the 3 072 bins of a 21-bit window group were 1.5 rounds of
 // the 2 048 blocks the chip holds and every lane load was half a request (0.92 -> see profiles/r05_experiments.txt item 10).
 constexpr int BC_THREADS = 1024;
 // Also what k_bucket_max does on the other sort paths: the largest bucket -> info[1], sum of (size - 1) -> info[40..41] (`info`
 // is zeroed before; a bin without records writes its zeros itself, so `counts` needs no fill).
+// Grid: V + V / 2 blocks, one per part (see "Parts of heavy bins"); a part of a multi-part bin leaves its sizes in its row of `sub`.
 __global__ void __launch_bounds__(BC_THREADS) k_bin_count(uint32_t* counts, const uint32_t* bin_start, const uint2* rec, uint32_t hb, uint32_t L,
-                                                          WinSplit ws, uint32_t* info)
+                                                          WinSplit ws, uint32_t* info, uint32_t V, const uint32_t* extra_first,
+                                                          const uint32_t* mp_first, uint32_t part_len, uint32_t* sub, uint32_t nbmax)
 #ifndef MSM_SORT_TU
     ;
 #else
@@ -760,10 +920,13 @@ __global__ void __launch_bounds__(BC_THREADS) k_bin_count(uint32_t* counts, cons
   extern __shared__ uint32_t lds_bc[];
   __shared__ uint32_t lds_max;
   __shared__ unsigned long long lds_sum;
-  const uint32_t v = blockIdx.x, tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const PartLoc pl = locate_part(blockIdx.x, V, bin_start, extra_first, mp_first, part_len, false);
+  if (!pl.valid) return;
+  const uint32_t v = pl.v;
   const uint32_t kk = v / hb, h = v - kk * hb, fb = ws.fb[kk], NB = 1u << fb;
   if (h >= (1u << ws.ab[kk])) return;
-  const uint64_t beg = bin_start[v], end = bin_start[v + 1];
+  const uint64_t beg = pl.beg, end = pl.end;
   uint32_t* out = counts + (uint64_t)kk * L + ((uint64_t)h << fb);
   if (beg == end) {
     for (uint32_t j = tid; j < NB; j += BC_THREADS) out[j] = 0;
@@ -791,6 +954,11 @@ __global__ void __launch_bounds__(BC_THREADS) k_bin_count(uint32_t* counts, cons
     (void)lds_rank_add(lds_bc, l1 ? l1 - 1 : 0u, l1 != 0);
   }
   __syncthreads();
+  if (pl.np > 1) {   // uniform: the bin's counts, largest bucket and pair additions come from k_part_scan
+    uint32_t* row = sub + (uint64_t)pl.row * nbmax;
+    for (uint32_t j = tid; j < NB; j += BC_THREADS) row[j] = lds_bc[j];
+    return;
+  }
   uint32_t mx = 0;
   unsigned long long sum = 0;
   for (uint32_t j = tid; j < NB; j += BC_THREADS) {
@@ -823,7 +991,9 @@ inline size_t bin_pairs_lds(uint32_t nbmax) { return (size_t)5 * nbmax * 4 + 64 
 inline size_t bin_slots_lds(uint32_t nbmax) { return (size_t)3 * nbmax * 4 + 64 * 4 + (size_t)BP_TILE * 6; }
 
 __global__ void __launch_bounds__(BP_THREADS) k_bin_pairs(uint2* pairs, uint32_t* dest, const uint2* rec, const uint32_t* bin_start,
-                                                          const uint32_t* cursor, uint32_t hb, uint32_t L, uint32_t nbmax, WinSplit ws)
+                                                          const uint32_t* cursor, uint32_t hb, uint32_t L, uint32_t nbmax, WinSplit ws,
+                                                          uint32_t V, const uint32_t* extra_first, const uint32_t* mp_first,
+                                                          uint32_t part_len, const uint32_t* sub, const uint32_t* part_pair_off)
 #ifndef MSM_SORT_TU
     ;
 #else
@@ -838,7 +1008,10 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_pairs(uint2* pairs, uint32_t
   uint32_t* pend = t_delta + nbmax;    // the odd entry a bucket carries into the next tile (SLOT_EMPTY: none)
   uint32_t* g_next = pend + nbmax;     // next element of the bucket
   uint32_t* lds_wave = g_next + nbmax; // 64 words
-  const uint32_t v = gridDim.x - 1 - blockIdx.x, tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const PartLoc pl = locate_part(blockIdx.x, V, bin_start, extra_first, mp_first, part_len, true);
+  if (!pl.valid) return;
+  const uint32_t v = pl.v;
   const uint32_t kk = v / hb, h = v - kk * hb;
   const uint32_t ab = ws.ab[kk], fb = ws.fb[kk], NB = 1u << fb, HN = 1u << ab;
   const uint32_t* cur = cursor + (uint64_t)kk * L;
@@ -865,13 +1038,15 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_pairs(uint2* pairs, uint32_t
   }
   if (h >= HN) return;
   const uint32_t* curb = cur + ((uint64_t)h << fb);               // this bin's buckets
-  const uint64_t beg = bin_start[v], end = bin_start[v + 1];
+  const uint64_t beg = pl.beg, end = pl.end;
   if (beg == end) return;                                          // no entries, hence no slots and no pairs
+  // (a part of a multi-part bin: its buckets' elements start behind those of the parts before it, and so do its pairs)
+  const uint32_t* sub_row = pl.np > 1 ? sub + (uint64_t)pl.row * nbmax : nullptr;
   for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) {
     pend[bk] = SLOT_EMPTY;
-    g_next[bk] = curb[bk] >> 1;
+    g_next[bk] = (curb[bk] >> 1) + (sub_row ? sub_row[bk] : 0u);
   }
-  uint64_t out_pos = curb[0] >> 1;                                 // the bin's pairs are consecutive in the list
+  uint64_t out_pos = (curb[0] >> 1) + (sub_row ? part_pair_off[pl.row] : 0u);   // the bin's pairs are consecutive in the list
   uint2 r[BP_ITEMS], nr[BP_ITEMS];
   auto load_tile = [&](uint2 (&dst)[BP_ITEMS], uint64_t t0) {
 #pragma unroll
@@ -937,6 +1112,18 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_pairs(uint2* pairs, uint32_t
     load_tile(r, t0 + BP_TILE);
 #endif
   }
+  if (pl.j + 1 < pl.np) {
+    // not the bin's last part: an odd one out is paired with nothing here (the bucket's entries pair up inside a part)
+    (void)bucket_scan<BP_THREADS>(
+        NB, lds_wave, [&](uint32_t bk) { return pend[bk] != SLOT_EMPTY ? 1u : 0u; },
+        [&](uint32_t bk, uint32_t ex) {
+          if (pend[bk] != SLOT_EMPTY) {
+            pairs[out_pos + ex] = make_uint2(pend[bk], SLOT_EMPTY);
+            dest[out_pos + ex] = g_next[bk];
+          }
+        });
+    return;
+  }
   // what every bucket still owes: its pending entry paired with nothing, then pairs of pads (their sums are identities
   // that the index-free rounds behind round 1 read)
   (void)bucket_scan<BP_THREADS>(
@@ -953,7 +1140,9 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_pairs(uint2* pairs, uint32_t
 
 // pass B': payloads (entry << 1 | sign) to their padded slots, bucket order (slots are pre-filled with SLOT_EMPTY)
 __global__ void __launch_bounds__(BP_THREADS) k_bin_slots(uint32_t* slots, const uint2* rec, const uint32_t* bin_start,
-                                                          const uint32_t* cursor, uint32_t hb, uint32_t L, uint32_t nbmax, WinSplit ws)
+                                                          const uint32_t* cursor, uint32_t hb, uint32_t L, uint32_t nbmax, WinSplit ws,
+                                                          uint32_t V, const uint32_t* extra_first, const uint32_t* mp_first,
+                                                          uint32_t part_len, const uint32_t* sub)
 #ifndef MSM_SORT_TU
     ;
 #else
@@ -965,7 +1154,10 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_slots(uint32_t* slots, const
   uint32_t* lds_wave = g_cur + nbmax;
   uint32_t* stage = lds_wave + 64;
   uint16_t* stage_b = reinterpret_cast<uint16_t*>(stage + BP_TILE);
-  const uint32_t v = gridDim.x - 1 - blockIdx.x, tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const PartLoc pl = locate_part(blockIdx.x, V, bin_start, extra_first, mp_first, part_len, true);
+  if (!pl.valid) return;
+  const uint32_t v = pl.v;
   const uint32_t kk = v / hb, h = v - kk * hb;
   const uint32_t ab = ws.ab[kk], fb = ws.fb[kk], NB = 1u << fb, HN = 1u << ab;
   const uint32_t* cur = cursor + (uint64_t)kk * L;
@@ -985,9 +1177,11 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_slots(uint32_t* slots, const
     return;
   }
   if (h >= HN) return;
-  const uint64_t beg = bin_start[v], end = bin_start[v + 1];
+  const uint64_t beg = pl.beg, end = pl.end;
   if (beg == end) return;
-  for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) g_cur[bk] = cur[((uint64_t)h << fb) + bk];
+  // (a part of a multi-part bin writes behind the entries the parts before it hold of every bucket)
+  const uint32_t* sub_row = pl.np > 1 ? sub + (uint64_t)pl.row * nbmax : nullptr;
+  for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) g_cur[bk] = cur[((uint64_t)h << fb) + bk] + (sub_row ? sub_row[bk] : 0u);
   for (uint64_t t0 = beg; t0 < end; t0 += BP_TILE) {
     for (uint32_t bk = tid; bk < NB; bk += BP_THREADS) t_cnt[bk] = 0;
     lds_barrier();

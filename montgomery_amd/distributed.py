@@ -57,21 +57,30 @@ def point_shards(n: int, world: int) -> List[Tuple[int, int]]:
 
 
 def choose_window(plan: Callable[[int, Optional[int]], Tuple[int, int]], n: int, world: int, split: str) -> Tuple[int, int]:
-    """(c, K) for one MSM of n points sharded over `world` ranks; plan(n, c) -> (c, K) is the library's `msm_plan`.
+    """(c, K) for one MSM of n points sharded over `world` ranks; plan(n, c[, no_tables]) -> (c, K) is the library's `msm_plan`
+    (`MsmContext.plan`: asked with no_tables=True, because shards run the plain path whatever tables the context holds).
     All ranks must use the same window: their window sums meet slot by slot.
     by points: every rank runs a whole MSM over n / world points -- the window the library picks for THAT size;
     by windows: a rank runs K / world windows over all points.  The big windows a single GPU takes from 2^24 points (K = 6)
       neither divide among 4 or 8 ranks nor pay for a shard of three windows, which has no second window group of its own
       size beside it (tools/shard_time.py at 2^26, 2 ranks: 84.1 ms with three 22-bit windows against 81 with four 16-bit
       ones): c = 16 (K = 8) whenever the ranks divide its windows, else the pick for a rank's share of the points."""
+    def plain(m, c):
+        # shards always run the plain path (msm_window_sums): a `plan` that knows window tables (MsmContext.plan) is asked for
+        # the plain plan, one that takes (n, c) only -- the CPU tests' -- is the plain plan already
+        try:
+            return plan(m, c, no_tables=True)
+        except TypeError:
+            return plan(m, c)
+
     if world <= 1 or split == "buckets":   # a bucket-range shard keeps the single-GPU plan: every rank runs all of its windows
-        return plan(n, None)
+        return plain(n, None)
     if split != "points":
-        c16, K16 = plan(n, 16)
+        c16, K16 = plain(n, 16)
         if K16 % world == 0:
             return c16, K16
-    c, _ = plan(max(n // world, 1), None)
-    return plan(n, c)   # (K for the call the ranks actually make)
+    c, _ = plain(max(n // world, 1), None)
+    return plain(n, c)   # (K for the call the ranks actually make)
 
 
 def choose_split(n: int, world: int, K: int) -> str:

@@ -223,6 +223,30 @@ def test_batch_add_gather_mode_every_kind_of_pair(gpu_ctx):
         assert out[96 * i : 96 * i + 96] == (b"\0" * 96 if exp is None else exp[0].to_bytes(48, "little") + exp[1].to_bytes(48, "little")), i
 
 
+@pytest.mark.parametrize("kind", ["double", "cancel", "no_a", "no_b", "none"])
+def test_one_degenerate_pair_in_one_wave_of_a_workgroup(gpu_ctx, kind):
+    """k_batch_add shares ONE inversion among the four waves of a workgroup (batch_add.h): the running products of a lane column
+    are multiplied together, so a zero or a wrong denominator in one wave would poison the other three.  768 generic pairs =
+    one workgroup x 3 steps in gather mode (msm_test_batch_add walks three pairs per lane); exactly one of them -- wave 2,
+    lane 2, the middle step -- is a doubling, a cancellation, or has an identity operand.  Every sum must match, the other
+    waves' included.  The second call has two workgroups and the special pair in the last step."""
+    p = C377.p
+    base, _ = O.random_points_bls377("gpu/one-wave", 64)
+    enc = lambda P: b"\0" * 96 if P is None else P[0].to_bytes(48, "little") + P[1].to_bytes(48, "little")
+    for n, at in ((768, 256 + 130), (1536, 2 * 512 + 256 + 3 * 64 + 63)):
+        g = [base[i % 64] for i in range(n)]
+        h = [base[(i * 5 + 1) % 64] for i in range(n)]
+        P = g[at]
+        g[at], h[at] = {"double": (P, P), "cancel": (P, O.aff_neg(P, p)), "no_a": (None, P), "no_b": (P, None), "none": (None, None)}[kind]
+        out = gpu_ctx.test_batch_add(b"".join(map(enc, g)), b"".join(map(enc, h)))
+        memo = {}
+        for i in range(n):
+            key = (g[i], h[i])
+            if key not in memo:
+                memo[key] = O.aff_add(g[i], h[i], p)
+            assert out[96 * i : 96 * i + 96] == enc(memo[key]), (kind, n, i)
+
+
 def test_bucket_reduction_projective_and_all_affine(gpu_ctx):
     """P_k = sum_l l B_(k,l) by the projective reduction the MSM uses (mode 0) and by the reference's
     all-affine reduction (reduceBucketsAffine, src/msm-batched-affine-single-thread.ts:522-667: in-place batched-affine

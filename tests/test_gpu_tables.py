@@ -119,3 +119,39 @@ def test_edwards_and_other_curves_on_tables():
             got, it = ctx.run_device(dev, n)
             assert it["tables"] and not ip["tables"] and key(got) == key(plain), (curve, n)
         ctx.close()
+
+
+def test_a_call_split_by_points_leaves_the_tables(gpu_ctx):
+    """A run on window tables addresses row k * n_points + i from the entry index alone; a call that has to run over ranges of
+    the points (a tight msm_set_workspace_limit here, host scalars arriving range by range below) would read other points'
+    rows.  Such a call takes the plain path under the same window and says so (msm_result.tables = 0)."""
+    n = 1 << 18
+    gpu_ctx.generate_points(n, seed=91)
+    dev, _ = gpu_ctx.generate_scalars(n, seed=92)
+    want, iw = gpu_ctx.run_device(dev, n, no_tables=True)
+    on_tab, it = gpu_ctx.run_device(dev, n)
+    assert it["tables"] and on_tab.as_tuple() == want.as_tuple()
+    gpu_ctx.set_workspace_limit(60 << 20)
+    try:
+        got, ig = gpu_ctx.run_device(dev, n)
+        assert not ig["tables"] and (ig["c"], ig["K"]) == (it["c"], it["K"]), ig
+        assert got.as_tuple() == want.as_tuple()
+    finally:
+        gpu_ctx.set_workspace_limit(0)
+    again, ia = gpu_ctx.run_device(dev, n)
+    assert ia["tables"] and again.as_tuple() == want.as_tuple()
+
+
+def test_host_scalars_with_the_tables_window_at_2p24(gpu_ctx):
+    """msm_run over HOST scalars of 2^24 points with the explicit window the tables were built for: the scalars cross PCIe range
+    by range of the points, so the call must leave the tables (it read the wrong rows and returned MSM_OK)."""
+    n = 1 << 24
+    gpu_ctx.generate_points(n, seed=93)
+    dev, sb = gpu_ctx.generate_scalars(n, seed=94, to_host=True)
+    want, _ = gpu_ctx.run_device(dev, n, no_tables=True)
+    c, K = gpu_ctx.plan(n)
+    on_tab, it = gpu_ctx.run_device(dev, n)
+    assert it["tables"] and (it["c"], it["K"]) == (c, K) and on_tab.as_tuple() == want.as_tuple()
+    got, ig = gpu_ctx.run(sb, c=c)
+    assert not ig["tables"] and ig["c"] == c and got.as_tuple() == want.as_tuple(), ig
+    gpu_ctx.set_points(O.points_to_bytes([(C.gx, C.gy)], 48))   # give the 4 GB of rows and 24 GB of tables back
