@@ -88,6 +88,14 @@ def expected_from_logs(curve_name, a_host, s_host, n):
     return O.aff_scale(k, (C.gx, C.gy), C.p)
 
 
+def C_uint8_view(arr):
+    """a C-contiguous numpy uint8 array as a ctypes array over the same memory (no copy: 2 GB at 2^26)"""
+    import ctypes
+
+    flat = arr.reshape(-1)
+    return (ctypes.c_uint8 * flat.size).from_buffer(flat)
+
+
 def cpu_baseline(ctx, log2n_sample, seed):
     """Times oracle/msm_oracle.c (kind "port") on the host cores over the first 2^k resident points, k = 20 and
     log2n_sample: one untimed warm-up call (thread pool, page faults), then repeated timed calls per size -- median and
@@ -308,6 +316,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the known-discrete-log check of the last timed result")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-scalar (PCIe-inclusive) leg")
+    ap.add_argument("--no-skewed", action="store_true", help="skip the leg over skewed scalar distributions (prover-shaped, one scalar repeated)")
     ap.add_argument("--no-tables-leg", action="store_true", help="skip the leg that builds window tables for the headline size and times the MSM on them")
     ap.add_argument("--no-c16", action="store_true", help="skip the serialised step at c = 16 (same_kernel_at_c16): counter runs "
                                                           "then hold MSMs of one plan only")
@@ -388,7 +397,10 @@ def main():
         of the points, the window split wants K divisible by the rank count; --c overrides both"""
         if args.c or not sharded:
             return ctx.plan(n, args.c or None)
-        return choose_window(lambda m, cc: ctx.plan(m, cc, no_tables=True), n, world, how)
+        def plan(m, cc, no_tables=False, merged=False):
+            return ctx.plan(m, cc, no_tables=no_tables, merged=merged)
+
+        return choose_window(plan, n, world, how)
 
     if sharded:
         c, K = plan_for(split)
@@ -420,8 +432,10 @@ def main():
             return parts
 
         def my_point_sums(first, count):   # all K windows over this rank's share of the points: only its scalars are read
+            # (merged: only combined afterwards -- the call may run on the window tables of this rank's range of the points, which
+            # the library builds when the range comes back, i.e. during the warm-up steps)
             parts, box["info"] = ctx.window_sums(scal[i % n_sets].data_ptr() + 32 * first, count, 0, K, c=c, on_device=True,
-                                                 point_lo=first)
+                                                 point_lo=first, merged=True)
             return parts
 
         def my_bucket_sums(r, w):   # all K windows over all points, this rank's range of every window's buckets
@@ -611,6 +625,38 @@ def main():
                 if not tables_leg["equals_plain_path"]:
                     failed = "bench: the MSM on window tables differs from the plain path"
             ctx.set_tables_limit(0)
+        skewed = None
+        if not sharded and not is381 and not args.no_skewed:
+            # Skewed scalar distributions (montgomery_amd/workloads.py) over the same resident points, outside `value`: a prover's
+            # witness-shaped set (40 % zeros, 20 % ones, 10 % below 2^16, the rest uniform) and ONE scalar repeated (every entry of a
+            # window in one bucket).  The reference walks any bucket-size distribution through the same rounds
+            # (src/msm-batched-affine.ts:204,243-263); here the sort cuts heavy bins into parts (sort_kernels.h) and deep buckets
+            # run through the tail rounds.  Five timed calls after a warm-up each, median, result checked against the known logs.
+            from montgomery_amd import workloads
+
+            uniform_ms = statistics.median(step_ms)
+            skewed = []
+            for kind in ("prover", "one"):
+                s_np = workloads.scalars(kind, n, seed=4242)
+                scal[0].copy_(torch.from_numpy(s_np.reshape(-1)))
+                torch.cuda.synchronize()
+                plain = not infos[-1].get("tables")   # the path the headline ran on (the tables leg above may have left tables behind)
+                k_last, k_info = ctx.run_device(scal[0].data_ptr(), n, c=c_main, no_tables=plain)
+                k_ms = []
+                for _ in range(5):
+                    tk = time.perf_counter()
+                    k_last, k_info = ctx.run_device(scal[0].data_ptr(), n, c=c_main, no_tables=plain)
+                    k_ms.append((time.perf_counter() - tk) * 1e3)
+                k_ok = None
+                if verify:
+                    k_ok = bool(k_last.as_tuple() == expected_from_logs(args.curve, a_host, C_uint8_view(s_np), n))
+                    if not k_ok:
+                        failed = f"bench: the MSM over the '{kind}' scalar distribution failed the known-discrete-log check"
+                skewed.append({"scalars": kind, "median_ms": statistics.median(k_ms), "min_ms": min(k_ms), "max_ms": max(k_ms),
+                               "ratio_to_uniform": statistics.median(k_ms) / uniform_ms, "largest_bucket": k_info["max_bucket"],
+                               "tree_rounds": k_info["rounds"], "pair_adds": k_info["n_pairs_algo"], "verified": k_ok})
+                del s_np
+            ctx.generate_scalars(n, seed=1000, into=scal[0].data_ptr())   # set 0 as the other legs know it
         pmc = pmc_summary(args.curve, args.log2n, c)
         if excl and pmc and pmc.get("scatter_phase"):
             excl["scatter"]["hbm_bytes_per_entry_pmc"] = pmc["scatter_phase"]["hbm_bytes_per_entry"]
@@ -698,6 +744,7 @@ def main():
             "other_splits": other_splits,
             "pcie_inclusive": pcie,
             "window_tables_leg": tables_leg,
+            "skewed": skewed,
             "result_is_infinity": bool(last.isZero) if last is not None else None,
         }
         if not sharded and not args.no_cpu_baseline and not is381:

@@ -52,8 +52,9 @@ enum {
  * LIBRARY was built with, msm_abi_struct_bytes(0 / 1) its sizeof(msm_opts) / sizeof(msm_result).  The Python loader and the N-API
  * addon compare both at load time and refuse a mismatch.  History: 3 = round 3 (msm_generate_scalars writes to a caller-owned
  * buffer; msm_opts.point_lo / by_window); 4 = msm_result.n_pairs_algo; 5 = window tables (msm_opts.no_tables, msm_result.tables,
- * msm_precompute / msm_tables_info / msm_set_tables_limit), msm_reserve, msm_opts.bucket_shard / bucket_shards. */
-#define MSM_ABI_VERSION 5
+ * msm_precompute / msm_tables_info / msm_set_tables_limit), msm_reserve, msm_opts.bucket_shard / bucket_shards; 6 = window tables
+ * over a range of the points (msm_opts.merged_sums, msm_precompute with point_lo, msm_tables_range). */
+#define MSM_ABI_VERSION 6
 uint32_t msm_abi_version(void);
 uint32_t msm_abi_struct_bytes(int which);
 
@@ -95,6 +96,13 @@ typedef struct msm_opts {
                            single-GPU plan's (the reference splits every window's buckets across its threads the same way,
                            src/msm-common.ts:72-172).  The partial sums keep the buckets' true weights: the G results of
                            msm_window_sums add up per window (msm_combine_groups), those of msm_run as points */
+  int32_t merged_sums;  /* msm_window_sums, != 0: the caller only COMBINES the sums (msm_combine / msm_combine_groups), so the call may
+                           hand them back merged -- slot 0 of its window range then carries sum_k 2^(c (k - k_lo)) P_k and the
+                           other slots the identity, which the Horner step of either combine takes like one P_k per slot -- and
+                           with that run on window tables: those of the whole point set, or of the range of the points the call
+                           covers (the share of one rank of a points-split run; see msm_precompute).  Default 0: one P_k per
+                           slot, the plain path */
+  int32_t reserved_;
 } msm_opts;
 
 #define MSM_N_PHASES 8
@@ -150,12 +158,19 @@ int msm_set_points(msm_ctx* ctx, const void* points, uint64_t n, int on_device, 
  * msm_run builds them by itself on its first call over the WHOLE current point set with the default window (opts->c == 0)
  * when they fit the limit (default: 10 % of the device memory -- 28 GB: point sets of up to 2^24 BLS12-377 points; what they
  * buy shrinks from 6-10 % below 2^24 points to 1.5 % at 2^26, where they would take 96 GB), and uses them whenever the call's plan is the one they were built
- * for; any other call -- another window size, a prefix or a range of the points, msm_window_sums, a device-list context --
+ * for; any other call -- another window size, a prefix or another range of the points, msm_window_sums without merged_sums, a bucket-range shard, a device-list context --
  * takes the plain path over table 0, which is always the plain row table.  msm_precompute builds them ahead of the first call
  * (also for an explicit opts->c); it is not an error if they do not fit: the plain path stays.  msm_set_points drops them.
- * msm_tables_info: window size and number of tables present (0, 0: none) and their bytes. */
+ * Tables over a RANGE of the points (round 6): the rank of a points-split run works on its share [point_lo, point_lo + n) of
+ * the resident points in every step; msm_precompute with opts->point_lo builds the tables of exactly that range (2^23 points x 7
+ * tables = 15 GB, in a buffer of their own next to the plain rows), and msm_run / msm_window_sums (with msm_opts.merged_sums)
+ * over that range run on them.  Without msm_precompute they are built when a call comes back for the same range a second
+ * time in a row -- a caller that walks over several ranges on one GPU is spared a build per call.  A point set holds the tables
+ * of ONE range (or of the whole set, which a range never replaces by itself).
+ * msm_tables_info: window size and number of tables present (0, 0: none) and their bytes; msm_tables_range: the points they cover. */
 int msm_precompute(msm_ctx* ctx, uint64_t n, const msm_opts* opts);
 int msm_tables_info(const msm_ctx* ctx, int32_t* c_out, int32_t* K_out, uint64_t* bytes_out);
+int msm_tables_range(const msm_ctx* ctx, uint64_t* point_lo_out, uint64_t* n_out);
 int msm_set_tables_limit(msm_ctx* ctx, uint64_t bytes);   /* 0: never build tables */
 
 /* Everything a later msm_run(ctx, <device scalars>, n, opts) allocates or builds -- the per-call workspace (device memory costs

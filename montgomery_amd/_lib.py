@@ -17,7 +17,7 @@ CURVE_BLS12_377_G1 = 0
 CURVE_ED_ON_BLS12_377 = 1
 CURVE_BLS12_381_G1 = 2
 CURVE_PALLAS = 3
-ABI_VERSION = 5   # MSM_ABI_VERSION of the include/msm_hip.h this binding was written against
+ABI_VERSION = 6   # MSM_ABI_VERSION of the include/msm_hip.h this binding was written against
 N_PHASES = 8
 PHASE_NAMES = ("total", "upload", "digits", "sort", "accumulate", "reduce", "final", "accumulate_round1")
 
@@ -32,7 +32,7 @@ EXPORTS = (
     "msm_device_alloc", "msm_device_free", "msm_device_upload",
     "msm_test_fp_raw", "msm_test_curve_op", "msm_test_batch_add_mode",
     "msm_run_placed", "msm_combine_groups", "msm_test_bucket_reduce", "msm_set_workspace_limit",
-    "msm_precompute", "msm_tables_info", "msm_set_tables_limit", "msm_reserve",
+    "msm_precompute", "msm_tables_info", "msm_tables_range", "msm_set_tables_limit", "msm_reserve",
     "msm_abi_version", "msm_abi_struct_bytes",
 )
 
@@ -40,7 +40,7 @@ EXPORTS = (
 class MsmOpts(C.Structure):
     _fields_ = [("c", C.c_int32), ("unsafe", C.c_int32), ("k_lo", C.c_int32), ("k_hi", C.c_int32), ("serial", C.c_int32),
                 ("no_glv", C.c_int32), ("strict", C.c_int32), ("point_lo", C.c_uint32), ("by_window", C.c_int32), ("no_tables", C.c_int32),
-                ("bucket_shard", C.c_int32), ("bucket_shards", C.c_int32)]
+                ("bucket_shard", C.c_int32), ("bucket_shards", C.c_int32), ("merged_sums", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class MsmResult(C.Structure):
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
     lib.msm_set_workspace_limit.argtypes = [vp, u64]
     lib.msm_precompute.argtypes = [vp, u64, C.POINTER(MsmOpts)]
     lib.msm_tables_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u64)]
+    lib.msm_tables_range.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     lib.msm_set_tables_limit.argtypes = [vp, u64]
     lib.msm_reserve.argtypes = [vp, u64, C.POINTER(MsmOpts)]
     lib.msm_test_fp_raw.argtypes = [vp, C.c_int, vp, vp, vp, u64]

@@ -290,10 +290,12 @@ class MsmContext:
         return None if (x == 0 and y == 0) else (x, y)
 
     # -- msm ------------------------------------------------------------------------------
-    def plan(self, n: int, c: Optional[int] = None, no_tables: bool = False) -> Tuple[int, int]:
+    def plan(self, n: int, c: Optional[int] = None, no_tables: bool = False, merged: bool = False, point_lo: int = 0) -> Tuple[int, int]:
         """(c, K) of msm_run over n points; over the whole resident point set that is the plan on window tables where they
-        exist or would be built -- no_tables: the plain plan (what msm_window_sums and shards of the points run)."""
-        opts = MsmOpts(c=c or 0, no_tables=int(no_tables))
+        exist or would be built -- no_tables: the plain plan (what msm_window_sums without `merged` and bucket shards run);
+        merged: the plan of window_sums(..., merged=True) over the points [point_lo, point_lo + n), which may run on the window
+        tables of that range."""
+        opts = MsmOpts(c=c or 0, no_tables=int(no_tables), merged_sums=int(merged), point_lo=point_lo)
         cc, kk = C.c_int32(), C.c_int32()
         self._check(self._lib.msm_plan(self._h, n, C.byref(opts), C.byref(cc), C.byref(kk)))
         return cc.value, kk.value
@@ -340,10 +342,11 @@ class MsmContext:
         return out, _result_to_dict(res)
 
     # -- window tables (msm_precompute, include/msm_hip.h) ------------------------------------
-    def precompute(self, n: Optional[int] = None, c: Optional[int] = None, no_glv: bool = False) -> Tuple[int, int, int]:
-        """Builds the window tables of the current point set for the plan msm_run(n, c) would use (no-op if present or if they
-        do not fit the limit).  Returns tables_info()."""
-        opts = MsmOpts(c=c or 0, no_glv=int(no_glv))
+    def precompute(self, n: Optional[int] = None, c: Optional[int] = None, no_glv: bool = False, point_lo: int = 0) -> Tuple[int, int, int]:
+        """Builds the window tables of the current point set -- of its points [point_lo, point_lo + n): the share of one rank of a
+        points-split run -- for the plan msm_run(n, c) would use (no-op if present or if they do not fit the limit).
+        Returns tables_info()."""
+        opts = MsmOpts(c=c or 0, no_glv=int(no_glv), point_lo=point_lo)
         self._check(self._lib.msm_precompute(self._h, self.n_points if n is None else n, C.byref(opts)))
         return self.tables_info()
 
@@ -352,6 +355,12 @@ class MsmContext:
         c, k, b = C.c_int32(), C.c_int32(), C.c_uint64()
         self._check(self._lib.msm_tables_info(self._h, C.byref(c), C.byref(k), C.byref(b)))
         return c.value, k.value, b.value
+
+    def tables_range(self) -> Tuple[int, int]:
+        """(first point, number of points) the current point set's window tables cover; (0, 0): none."""
+        lo, n = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.msm_tables_range(self._h, C.byref(lo), C.byref(n)))
+        return lo.value, n.value
 
     def set_tables_limit(self, nbytes: int) -> None:
         self._check(self._lib.msm_set_tables_limit(self._h, nbytes))
@@ -363,14 +372,16 @@ class MsmContext:
 
     def window_sums(self, scalars: Union[BytesLike, int], n: int, k_lo: int, k_hi: int, c: Optional[int] = None,
                     on_device: bool = False, point_lo: int = 0, by_window: bool = False,
-                    bucket_shard: Tuple[int, int] = (0, 0)) -> Tuple[bytes, Dict]:
+                    bucket_shard: Tuple[int, int] = (0, 0), merged: bool = False) -> Tuple[bytes, Dict]:
         """Partition sums P_k, k in [k_lo, k_hi), over the resident points [point_lo, point_lo + n) (scalar i belongs to
-        point point_lo + i): (k_hi - k_lo) x 144 bytes (X, Y, Z)."""
+        point point_lo + i): (k_hi - k_lo) x 144 bytes (X, Y, Z).  merged (msm_opts.merged_sums): the caller only combines the
+        sums, so they may come back merged -- the first slot carries sum_k 2^(c (k - k_lo)) P_k, the others the identity -- and
+        the call may run on window tables (of the whole set, or of exactly this range of the points)."""
         if k_hi <= k_lo or k_lo < 0:   # (0, 0) would mean "all windows" to the C side and overrun the 144-byte buffer below
             raise MsmError(_lib.MSM_ERR_ARG, f"empty or negative window range [{k_lo}, {k_hi})")
         # bucket_shard = (g, G): only the buckets [L g / G, L (g + 1) / G) of every window (msm_opts.bucket_shard)
         opts = MsmOpts(c=c or 0, k_lo=k_lo, k_hi=k_hi, point_lo=point_lo, by_window=int(by_window),
-                       bucket_shard=bucket_shard[0], bucket_shards=bucket_shard[1])
+                       bucket_shard=bucket_shard[0], bucket_shards=bucket_shard[1], merged_sums=int(merged))
         res = MsmResult()
         out = (C.c_uint8 * (144 * max(k_hi - k_lo, 1)))()
         if on_device:

@@ -74,11 +74,11 @@ void msm_ctx_destroy(msm_ctx* ctx) {
   ctx->children.clear();
   (void)hipSetDevice(ctx->device);
   for (size_t i = 0; i < ctx->sets.size(); i++)
-    if ((int)i != ctx->cur_set) ctx->release(ctx->sets[i].rows);
+    if ((int)i != ctx->cur_set) { ctx->release(ctx->sets[i].rows); ctx->release(ctx->sets[i].tabs); }
   for (void* p : ctx->allocs) (void)hipFree(p);
   ctx->allocs.clear();
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  for (DevBuf* b : {&ctx->rows, &ctx->scal, &ctx->errflag, &ctx->misc}) ctx->release(*b);
+  for (DevBuf* b : {&ctx->rows, &ctx->tabs, &ctx->scal, &ctx->errflag, &ctx->misc}) ctx->release(*b);
   for (auto& w : ctx->ws) {
     if (w.stream) (void)hipStreamSynchronize(w.stream);
     for (DevBuf* b : w.all) ctx->release(*b);
@@ -110,7 +110,7 @@ static int set_points_one(msm_ctx* ctx, const void* points, uint64_t n, int on_d
   try {
     HIPCHK(hipSetDevice(ctx->device));
     ctx->n_points = 0;
-    ctx->tab_c = ctx->tab_K = 0;   // window tables belong to the points they were built from
+    ctx->drop_tables();   // window tables belong to the points they were built from
     ctx->ensure(ctx->rows, std::max<uint64_t>(n, 1) * row_words * 4);
     const uint32_t* d_wire = (const uint32_t*)points;
     if (!on_device && n) {
@@ -163,7 +163,9 @@ int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_ou
   bool tables_wanted = false;
   // (a context with resident points answers for msm_run over them, window tables included; msm_window_sums and shards of
   // the points always run the plain plan, which is also what a context without points reports)
-  int rc = ctx && n && n == ctx->n_points ? make_run_plan(const_cast<msm_ctx*>(ctx), n, opts, false, pl, tables_wanted) : make_plan(ctx, n, opts, pl);
+  // (msm_opts.merged_sums: the plan of msm_window_sums over a range of the points that may run on range tables)
+  const bool run_like = ctx && n && ((n == ctx->n_points && !(opts && opts->point_lo)) || (opts && opts->merged_sums));
+  int rc = run_like ? make_run_plan(const_cast<msm_ctx*>(ctx), n, opts, false, pl, tables_wanted) : make_plan(ctx, n, opts, pl);
   if (rc) return rc;
   if (c_out) *c_out = pl.c;
   if (K_out) *K_out = pl.K;
@@ -177,7 +179,13 @@ int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device
     return fail(ctx, MSM_ERR_NO_POINTS, "msm_window_sums: points [%llu, +%llu) but %llu resident points",
                 (unsigned long long)(opts ? opts->point_lo : 0), (unsigned long long)n, (unsigned long long)ctx->n_points);
   Plan pl;
-  if (make_plan(ctx, n, opts, pl)) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: bad window size");
+  // msm_opts.merged_sums: the caller only combines the sums (msm_combine / msm_combine_groups), so the call may hand them back
+  // merged -- and with that run on window tables, those of the whole set or of the range of the points it covers
+  const bool merged = opts && opts->merged_sums;
+  bool tables_wanted = false;
+  if (merged ? make_run_plan(ctx, n, opts, false, pl, tables_wanted, /*note_range=*/true) : make_plan(ctx, n, opts, pl))
+    return fail(ctx, MSM_ERR_ARG, "msm_window_sums: bad window size");
+  pl.merged = merged;
   int k_lo = opts ? opts->k_lo : 0, k_hi = opts ? opts->k_hi : 0;
   if (k_lo == 0 && k_hi == 0) k_hi = pl.K;
   if (k_lo < 0 || k_hi > pl.K || k_lo >= k_hi) return fail(ctx, MSM_ERR_ARG, "msm_window_sums: bad window shard [%d, %d) of %d", k_lo, k_hi, pl.K);
@@ -185,6 +193,7 @@ int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device
   try {
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<uint32_t> words;
+    pl.tables = n && tables_wanted && use_window_tables(ctx, n, opts, pl, /*may_build=*/true);
     if (ctx->is_te()) {
       // extended point (X : Y : Z : T) sent as X || Y || Z; the receiver rebuilds T (msm_combine: T Z = X Y)
       if (n) any_window_sums(ctx, scalars, n, on_device, opts, k_lo, k_hi, pl, words, stats);
@@ -361,7 +370,7 @@ static int run_impl(msm_ctx* ctx, const void* scalars, const void* const* placed
     return run_piped(ctx, scalars, n, opts, out, who);
   Plan pl;
   bool tables_wanted = false;   // window tables (msm_tables.hip): the plan is then the one tables want
-  if (make_run_plan(ctx, n, opts, placed != nullptr, pl, tables_wanted)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);
+  if (make_run_plan(ctx, n, opts, placed != nullptr, pl, tables_wanted, /*note_range=*/true)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);
   pl.merged = true;
   memset(out, 0, sizeof(*out));
   out->c = pl.c;
@@ -493,10 +502,17 @@ static int pointset_select_one(msm_ctx* ctx, int32_t id) {
   ctx->sets[ctx->cur_set].n = ctx->n_points;
   ctx->sets[ctx->cur_set].tab_c = ctx->tab_c;
   ctx->sets[ctx->cur_set].tab_K = ctx->tab_K;
+  ctx->sets[ctx->cur_set].tab_lo = ctx->tab_lo;
+  ctx->sets[ctx->cur_set].tab_n = ctx->tab_n;
+  ctx->sets[ctx->cur_set].tabs = ctx->tabs;
   ctx->rows = ctx->sets[id].rows;
   ctx->n_points = ctx->sets[id].n;
   ctx->tab_c = ctx->sets[id].tab_c;
   ctx->tab_K = ctx->sets[id].tab_K;
+  ctx->tab_lo = ctx->sets[id].tab_lo;
+  ctx->tab_n = ctx->sets[id].tab_n;
+  ctx->tabs = ctx->sets[id].tabs;
+  ctx->cand_n = 0;
   ctx->cur_set = id;
   return MSM_OK;
 }
@@ -533,6 +549,7 @@ int msm_pointset_destroy(msm_ctx* ctx, int32_t id) {
       if (c->cur_set == id) pointset_select_one(c, 0);
       (void)hipSetDevice(c->device);
       c->release(c->sets[id].rows);
+      c->release(c->sets[id].tabs);
       c->sets[id] = msm_ctx::PointSet();
       return (int)MSM_OK;
     });

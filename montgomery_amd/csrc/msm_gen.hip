@@ -166,7 +166,7 @@ int generate_points(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) {
   W_LAUNCH(ctx, msm::k_points_from_wire, dim3((N_BASIS * TBL + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t*)d_tbl.p,
                      (const uint32_t*)d_wire.p, (uint64_t)N_BASIS * TBL, 1, (uint32_t*)ctx->errflag.p);
   ctx->n_points = 0;
-  ctx->tab_c = ctx->tab_K = 0;   // window tables belong to the points they were built from
+  ctx->drop_tables();   // window tables belong to the points they were built from
   ctx->ensure(ctx->rows, std::max<uint64_t>(n, 1) * msm::ROW_WORDS * 4);
   if (n)
     W_LAUNCH(ctx, k_gen_points, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)ctx->rows.p,
@@ -254,7 +254,7 @@ int generate_points_te(msm_ctx* ctx, uint64_t n, uint64_t seed, uint8_t* a_out) 
   hipLaunchKernelGGL(msm::te::k_te_points_from_wire, dim3((N_BASIS * TBL + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t*)d_tbl.p,
                      (const uint32_t*)d_wire.p, (uint64_t)N_BASIS * TBL, 1, (uint32_t*)ctx->errflag.p);
   ctx->n_points = 0;
-  ctx->tab_c = ctx->tab_K = 0;   // window tables belong to the points they were built from
+  ctx->drop_tables();   // window tables belong to the points they were built from
   ctx->ensure(ctx->rows, std::max<uint64_t>(n, 1) * msm::te::TE_ROW_WORDS * 4);
   if (n) {
     const uint32_t grid = (uint32_t)((n + 255) / 256);

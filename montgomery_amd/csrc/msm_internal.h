@@ -189,10 +189,27 @@ struct msm_ctx {
     uint64_t n = 0;
     bool live = false;
     int tab_c = 0, tab_K = 0;
+    uint64_t tab_lo = 0, tab_n = 0;
+    msmi::DevBuf tabs;
   };
-  // Window tables of the CURRENT point set (msm_tables.hip): `rows` then holds tab_K tables of n_points rows each, table k =
-  // 2^(tab_c k) P (0: none, `rows` is the plain table).  Travel with the set through msm_pointset_select.
+  // Window tables of the CURRENT point set (msm_tables.hip): tab_K tables of tab_n rows each, table k = 2^(tab_c k) P over the
+  // points [tab_lo, tab_lo + tab_n) (tab_K = 0: none).  Tables of the WHOLE set live in `rows` (which grows to hold them: table 0
+  // is the plain row table); tables of a RANGE of the points -- the share of one rank of a points-split run -- in `tabs`, with
+  // a copy of the range's rows as table 0.  Travel with the set through msm_pointset_select.
   int tab_c = 0, tab_K = 0;
+  uint64_t tab_lo = 0, tab_n = 0;
+  msmi::DevBuf tabs;
+  // the range the last table-eligible call over a RANGE of the points asked for: range tables are built when a call comes back
+  // for the same range (a rank of a sharded run does; a caller walking over the shards of one GPU does not and is spared a build per call)
+  uint64_t cand_lo = 0, cand_n = 0;
+  int cand_c = 0;
+  const uint32_t* table_rows() const { return (const uint32_t*)(tabs.p ? tabs.p : rows.p); }
+  void drop_tables() {
+    tab_c = tab_K = 0;
+    tab_lo = tab_n = 0;
+    cand_n = 0;
+    release(tabs);
+  }
   uint64_t tables_limit = 0;   // bytes the tables of one point set may take (msm_set_tables_limit; default: 10 % of the device)
   std::vector<PointSet> sets = std::vector<PointSet>(1);   // slot 0 = the default set
   int cur_set = 0;
@@ -315,6 +332,8 @@ struct Plan {
   uint32_t bt_lo = 0, bt_n = 0xFFFFFFFFu; // the top window's range (its digits cover another span than the recoded windows')
   bool tables = false; // the call runs on window tables (msm_tables.hip): the windows of a group share one set of buckets, a
                        // group hands back ONE sum that already carries the windows' weights
+  const uint32_t* tab_rows = nullptr;   // tables: first row of table 0; its tables are tab_n rows each and cover the points
+  uint64_t tab_lo = 0, tab_n = 0;       //         [tab_lo, tab_lo + tab_n)
   bool merged = false; // a full MSM (msm_run): a window group may hand back sum_k 2^(c (k - k_first)) P_k in the slot of its
                        // first window instead of one P_k per slot (reduce_buckets); msm_window_sums never sets it
 };
@@ -323,7 +342,8 @@ struct Plan {
 int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl, bool for_tables = false);
 // the plan of msm_run(n, opts) -- on window tables where the call is eligible and they exist or would be built -- and whether
 // it is that plan (msm_tables.hip)
-int make_run_plan(msm_ctx* ctx, uint64_t n, const msm_opts* opts, bool placed, Plan& pl, bool& tables_wanted);
+// note_range: the call is real (not msm_plan): a range of the points it asks for is remembered as the candidate for range tables
+int make_run_plan(msm_ctx* ctx, uint64_t n, const msm_opts* opts, bool placed, Plan& pl, bool& tables_wanted, bool note_range = false);
 
 struct GroupStats {
   uint64_t n_pairs = 0;
@@ -405,8 +425,9 @@ void accumulate_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const Plan& pl
 void sort_kernel_attributes();   // dynamic-LDS limits of the sort kernels (once per process and device)
 
 // ---- msm_tables.hip ---------------------------------------------------------------------------------------------
-// true if the MSM over the first n resident points under plan `pl` can run on window tables; builds them when `may_build`
-bool use_window_tables(msm_ctx* ctx, uint64_t n, const msm_opts* opts, const Plan& pl, bool may_build);
+// true if the MSM over the resident points [opts->point_lo, + n) under plan `pl` can run on window tables -- `pl` then knows
+// where they are (tab_rows, tab_lo, tab_n); builds them when `may_build`
+bool use_window_tables(msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl, bool may_build);
 
 // ---- msm_upload.hip ---------------------------------------------------------------------------------------------
 void ensure_staging(msm_ctx* ctx);

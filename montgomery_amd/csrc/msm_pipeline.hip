@@ -42,8 +42,9 @@ class PairSync {
 // Partition sums P_k for windows [k_lo, k_hi) over the points [p_lo, p_lo + n) -> h_partials_out[(k - k_lo) * 36 ...]
 // scalars: device pointer, n x 8 words.
 // before_tree: called once with the group's stream when everything up to the scatter has been queued (see PairSync).
+// k_base: the first window of the CALL (window tables carry weights relative to it: table j = 2^(c j) P serves window k_base + j)
 void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars_all, uint64_t p_lo, uint64_t n, const Plan& pl,
-                      int k_lo, int k_hi, uint32_t* h_partials_out, GroupStats& st, uint64_t p_off = 0,
+                      int k_lo, int k_hi, int k_base, uint32_t* h_partials_out, GroupStats& st, uint64_t p_off = 0,
                       const std::function<void(hipStream_t)>* before_tree = nullptr, GroupDigits* share = nullptr) {
   hipStream_t s = w.stream;
   const uint32_t* d_scalars = d_scalars_all + p_lo * 8;   // scalar i of the call <-> resident point p_off + i
@@ -57,9 +58,9 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   HIPCHK(hipEventRecord(w.ev[5], s));   // the tree starts here (behind the partner group's sort, if there is one)
   TreeOut to;
   if (pl.tables) {
-    // one merged window over the tables k_lo .. k_hi - 1: its sum carries the windows' weights already.  It goes into the
-    // group's first slot, identities into the others.
-    accumulate_window_group(ctx, w, pl, 1, (uint64_t)k_lo * ctx->n_points, so, st, to);
+    // one merged window over the tables k_lo - k_base .. k_hi - k_base - 1: its sum carries the windows' weights (relative to the
+    // call's first window) already.  It goes into the group's first slot, identities into the others.
+    accumulate_window_group(ctx, w, pl, 1, (uint64_t)(k_lo - k_base) * pl.tab_n, so, st, to);
     reduce_buckets(ctx, w, to.fin, to.fin_cap, to.off_fin, to.bucket_proj, pl.L, 1, h_partials_out, pl.merged, pl.c);
     const int pw = ctx->is_te() ? 32 : 36;
     for (int kk = 1; kk < kc; kk++) {
@@ -197,12 +198,12 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   // does more than one group contribute to a window?  Then the sums of its ranges are added on the host below.
   bool split_points = false;
   for (const Group& g : groups) split_points |= g.p_n != n;
-  // Window tables address row k * n_points + i of the resident set from the entry index alone, which counts from the GROUP's
-  // first point and in units of the group's own n: a group over a range of the points (a tight workspace limit, the retry
+  // Window tables address row k * tab_n + i of the points they cover from the entry index alone, which counts from the GROUP's
+  // first point and in units of the group's own n: a group over another range of the points (a tight workspace limit, the retry
   // after an out-of-memory error, host scalars arriving range by range) would read other points' rows.  Such a call runs the
   // plain path under the same window -- table 0 is the plain row table -- and hands back one sum per window slot, which the
   // caller's Horner step takes like the one weighted sum of a run on tables.
-  if (pl.tables && (split_points || n != ctx->n_points || p_off != 0)) pl.tables = false;
+  if (pl.tables && (split_points || n != pl.tab_n || p_off != pl.tab_lo)) pl.tables = false;
   std::vector<std::vector<uint32_t>> split_part((split_points || pl.tables) ? groups.size() : 0);
   HIPCHK(hipMemsetAsync(ctx->errflag.p, 0, 4, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));   // staged scalars are in place before the group streams start
@@ -259,7 +260,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
         }
       };
       try {
-        run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, part.data(), sts[slot], p_off,
+        run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, k_lo, part.data(), sts[slot], p_off,
                          pair >= 0 ? &meet : nullptr, share.valid ? &share : nullptr);
       } catch (...) {
         psync.abort();   // the partner must not wait for a group that will not arrive

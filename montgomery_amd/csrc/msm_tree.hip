@@ -86,7 +86,8 @@ void accumulate_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const Plan& pl
       const uint64_t sstride = g.T + scratch_pad;
       if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * sstride * 4);
       BatchArgs a{};
-      a.points = (const uint32_t*)ctx->rows.p + row_off * (te ? (uint64_t)te::TE_ROW_WORDS : (uint64_t)ROW_WORDS);
+      // (on window tables the payloads count rows of the tables, which live in `rows` or, for a range of the points, in `tabs`)
+      a.points = (pl.tables ? pl.tab_rows : (const uint32_t*)ctx->rows.p) + row_off * (te ? (uint64_t)te::TE_ROW_WORDS : (uint64_t)ROW_WORDS);
       a.slots = r == 1 ? round1_slots : (const uint32_t*)w.slots.p;
       a.dest = r == 1 ? round1_dest : nullptr;
       a.in = buf[cur ^ 1];

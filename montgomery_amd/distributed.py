@@ -60,7 +60,8 @@ def choose_window(plan: Callable[[int, Optional[int]], Tuple[int, int]], n: int,
     """(c, K) for one MSM of n points sharded over `world` ranks; plan(n, c[, no_tables]) -> (c, K) is the library's `msm_plan`
     (`MsmContext.plan`: asked with no_tables=True, because shards run the plain path whatever tables the context holds).
     All ranks must use the same window: their window sums meet slot by slot.
-    by points: every rank runs a whole MSM over n / world points -- the window the library picks for THAT size;
+    by points: every rank runs a whole MSM over n / world points -- the window the library picks for THAT size (on the window
+      tables of the rank's range of the points where they fit: `window_sums(..., merged=True)`);
     by windows: a rank runs K / world windows over all points.  The big windows a single GPU takes from 2^24 points (K = 6)
       neither divide among 4 or 8 ranks nor pay for a shard of three windows, which has no second window group of its own
       size beside it (tools/shard_time.py at 2^26, 2 ranks: 84.1 ms with three 22-bit windows against 81 with four 16-bit
@@ -73,13 +74,20 @@ def choose_window(plan: Callable[[int, Optional[int]], Tuple[int, int]], n: int,
         except TypeError:
             return plan(m, c)
 
+    def shard(m):
+        # a points shard may run on the window tables of its range (window_sums(..., merged=True)): the plan of such a call
+        try:
+            return plan(m, None, merged=True)
+        except TypeError:
+            return plain(m, None)
+
     if world <= 1 or split == "buckets":   # a bucket-range shard keeps the single-GPU plan: every rank runs all of its windows
         return plain(n, None)
     if split != "points":
         c16, K16 = plain(n, 16)
         if K16 % world == 0:
             return c16, K16
-    c, _ = plain(max(n // world, 1), None)
+    c, _ = shard(max(n // world, 1)) if split == "points" else plain(max(n // world, 1), None)
     return plain(n, c)   # (K for the call the ranks actually make)
 
 
@@ -168,7 +176,9 @@ def sharded_msm_points(point_sums: Callable[[int, int], bytes], n: int, K: int, 
     """One points-split MSM on the current process group.
 
     point_sums(first, count) -> K * 144 bytes: the K window sums over this rank's share of the points
-    (product: `MsmContext.window_sums(..., point_lo=first)`; the CPU tests inject a checker).
+    (product: `MsmContext.window_sums(..., point_lo=first, merged=True)` -- the sums may come back merged, the first slot
+    carrying sum_k 2^(c k) P_k and the others the identity, as a run on the range's window tables leaves them; the CPU tests
+    inject a checker of either form).
     `exchange`: a ShardExchange of K * 144 bytes per rank kept by the caller across steps (default: one per call).
     Returns (True, affine-or-None) on rank 0 and None elsewhere."""
     ex = exchange or ShardExchange(PARTIAL_BYTES * K, device, group)

@@ -27,8 +27,8 @@ def test_library_exports_every_declared_symbol():
 def test_result_struct_layout_matches_header():
     from montgomery_amd._lib import MsmOpts, MsmResult
 
-    # msm_opts: 12 x 32-bit fields; msm_result: 96 B + 4 x int32 + 8 floats + 3 x u64 + 2 x int32
-    assert ctypes.sizeof(MsmOpts) == 48
+    # msm_opts: 14 x 32-bit fields (12 until ABI 5; merged_sums + one reserved word since 6); msm_result: 96 B + 4 x int32 + 8 floats + 3 x u64 + 2 x int32
+    assert ctypes.sizeof(MsmOpts) == 56
     text = open(os.path.join(ROOT, "include", "msm_hip.h")).read()
     body = re.sub(r"/\*.*?\*/", "", text[text.index("typedef struct msm_opts {"):text.index("} msm_opts;")], flags=re.S)
     fields = re.findall(r"u?int32_t\s+([a-z_0-9, ]+);", body)

@@ -75,6 +75,23 @@ def _worker(rank, world, port, q):
                 results.append((out[1], O.msm_batched_affine(sc, pts, c=c)))
             else:
                 assert out is None
+        # points split over the TABLES path: a rank's sums come back merged (msm_opts.merged_sums) -- its first slot carries
+        # sum_k 2^(c k) P_k, the others the identity (Z = 0) -- and combine exactly like one P_k per slot
+        for name, n, c in (("ta", 19, 7), ("tb", 2, 11)):
+            pts, _ = O.random_points_bls377("dist/" + name, n)
+            sc = O.prng_ints("dist/s/" + name, n, C.q)
+            K = -(-127 // c)
+
+            def merged_sums(first, count):
+                tot = O.msm_naive_affine(sc[first:first + count], pts[first:first + count], C) if count else None
+                X, Y, Z = (0, 1, 0) if tot is None else (tot[0] * 5 % C.p, tot[1] * 5 % C.p, 5)
+                return X.to_bytes(48, "little") + Y.to_bytes(48, "little") + Z.to_bytes(48, "little") + bytes(144 * (K - 1))
+
+            out = sharded_msm_points(merged_sums, n, K, c)
+            if rank == 0:
+                results.append((out[1], O.msm_batched_affine(sc, pts, c=c)))
+            else:
+                assert out is None
         for name, n, c in (("a", 24, 9), ("b", 5, 16), ("cancel", 2, 7)):
             pts, _ = O.random_points_bls377("dist/" + name, n)
             sc = O.prng_ints("dist/s/" + name, n, C.q)
@@ -180,7 +197,7 @@ def test_sharded_msm_gloo(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert len(results) == 7
+    assert len(results) == 9   # 2 bucket splits, 2 points splits, 2 points splits on merged sums (the tables path), 3 window splits
     for got, exp in results:
         assert got == exp
 
@@ -237,3 +254,17 @@ def test_choose_window_for_shards():
     assert choose_window(plan, 1 << 20, 8, "windows") == (16, 8)
     for world in (2, 3, 8):
         assert choose_window(plan, n, world, "buckets") == (21, 6)        # a bucket-range shard keeps the single-GPU plan
+
+    # a plan that knows window tables (MsmContext.plan): shards of the windows and of the buckets ask for the plain plan, a
+    # shard of the points for the plan of a call that may run on the tables of its range
+    asked = []
+
+    def plan2(m, c, no_tables=False, merged=False):
+        asked.append((m, no_tables, merged))
+        if c is None and not no_tables:
+            c = 18 if m >= 1 << 16 else 16       # tables: 18-bit windows from 2^16 points
+        return plan(m, c)
+
+    assert choose_window(plan2, 1 << 20, 8, "points") == (18, 7) and ((1 << 17), False, True) in asked
+    assert choose_window(plan2, 1 << 20, 8, "windows") == (16, 8)
+    assert choose_window(plan2, 1 << 20, 8, "buckets") == (16, 8)

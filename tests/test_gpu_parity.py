@@ -361,6 +361,17 @@ def test_msm_2p26_known_discrete_logs(gpu_ctx, c_oracle):
     assert (cs, Ks) == (18, 7)
     groups = b"".join(gpu_ctx.window_sums(dev + 32 * g * share, share, 0, Ks, on_device=True, point_lo=g * share)[0] for g in range(8))
     assert combine_groups_host(groups, 8, Ks, cs, _lib.CURVE_BLS12_377_G1) == res.as_tuple()
+    # the same eight shards each on the window tables of ITS range of the points (round 6: 7 tables x 2^23 rows = 15 GB per rank),
+    # as the ranks of `--split points` run them from their second step on
+    assert gpu_ctx.plan(share, merged=True, point_lo=share) == (cs, Ks)
+    groups = b""
+    for g in range(8):
+        assert gpu_ctx.precompute(share, c=cs, point_lo=g * share)[:2] == (cs, Ks) and gpu_ctx.tables_range() == (g * share, share)
+        part, pinfo = gpu_ctx.window_sums(dev + 32 * g * share, share, 0, Ks, c=cs, on_device=True, point_lo=g * share, merged=True)
+        assert pinfo["tables"], pinfo
+        groups += part
+    assert combine_groups_host(groups, 8, Ks, cs, _lib.CURVE_BLS12_377_G1) == res.as_tuple()
+    gpu_ctx.precompute(4096, point_lo=0)   # (give the 15 GB back: tables of a tiny range)
     # and eight bucket-range shards (`--split buckets`): the single-GPU plan, every rank an eighth of every window's buckets
     groups = b"".join(gpu_ctx.window_sums(dev, n, 0, 6, on_device=True, bucket_shard=(g, 8))[0] for g in range(8))
     assert combine_groups_host(groups, 8, 6, 21, _lib.CURVE_BLS12_377_G1) == res.as_tuple()

@@ -155,3 +155,99 @@ def test_host_scalars_with_the_tables_window_at_2p24(gpu_ctx):
     got, ig = gpu_ctx.run(sb, c=c)
     assert not ig["tables"] and ig["c"] == c and got.as_tuple() == want.as_tuple(), ig
     gpu_ctx.set_points(O.points_to_bytes([(C.gx, C.gy)], 48))   # give the 4 GB of rows and 24 GB of tables back
+
+
+def test_window_tables_over_a_range_of_the_points(gpu_ctx):
+    """Round 6: the share of one rank of a points-split run is a RANGE [point_lo, point_lo + n) of the resident points.  Its window
+    tables live in a buffer of their own; msm_run / msm_window_sums(merged_sums) over exactly that range run on them.  Built by
+    msm_precompute(point_lo), or by the library when a call comes back for the same range a second time in a row."""
+    from montgomery_amd import _lib
+    from montgomery_amd.distributed import combine_groups_host
+
+    n = 1 << 16
+    gpu_ctx.generate_points(n, seed=61)
+    dev, _ = gpu_ctx.generate_scalars(n, seed=62)
+    full, _ = gpu_ctx.run_device(dev, n, no_tables=True)
+    world = 4
+    share = n // world
+    c, K = gpu_ctx.plan(share, merged=True, point_lo=share)
+    assert (c, K) == gpu_ctx.plan(share, merged=True, point_lo=0)
+
+    def shard(g, merged=True):
+        return gpu_ctx.window_sums(dev + 32 * g * share, share, 0, K, c=c, on_device=True, point_lo=g * share, merged=merged)
+
+    # walking over the shards builds nothing (no range comes back twice in a row); every shard runs the plain path
+    parts = []
+    for g in range(world):
+        p, info = shard(g)
+        assert not info["tables"] and gpu_ctx.tables_info() == (0, 0, 0)
+        parts.append(p)
+    assert combine_groups_host(b"".join(parts), world, K, c, _lib.CURVE_BLS12_377_G1) == full.as_tuple()
+    # the same range again: the tables of the range are built and used; the sums come back merged (identities behind slot 0)
+    p1, i1 = shard(world - 1)
+    assert i1["tables"] and gpu_ctx.tables_info() == (c, K, K * share * 256) and gpu_ctx.tables_range() == ((world - 1) * share, share)
+    ident = lambda part, j: part[144 * j + 96 : 144 * j + 144] == bytes(48)       # Z = 0
+    assert not ident(p1, 0) and all(ident(p1, j) for j in range(1, K))
+    parts[world - 1] = p1
+    assert combine_groups_host(b"".join(parts), world, K, c, _lib.CURVE_BLS12_377_G1) == full.as_tuple()
+    # ... and msm_run over that range runs on them too, a prefix of the range or the whole set does not
+    r_tab, it = gpu_ctx.run_device(dev + 32 * (world - 1) * share, share, point_lo=(world - 1) * share)
+    r_pl, ip = gpu_ctx.run_device(dev + 32 * (world - 1) * share, share, point_lo=(world - 1) * share, no_tables=True)
+    assert it["tables"] and not ip["tables"] and r_tab.as_tuple() == r_pl.as_tuple()
+    r_sub, isub = gpu_ctx.run_device(dev + 32 * (world - 1) * share, share // 2, point_lo=(world - 1) * share, c=c)
+    assert not isub["tables"]
+    # without merged_sums msm_window_sums keeps one P_k per slot and the plain path
+    p_plain, i_plain = shard(world - 1, merged=False)
+    assert not i_plain["tables"] and not any(ident(p_plain, j) for j in range(K))
+    parts[world - 1] = p_plain
+    assert combine_groups_host(b"".join(parts), world, K, c, _lib.CURVE_BLS12_377_G1) == full.as_tuple()
+    # msm_precompute for another range replaces them; every shard on the tables of its own range
+    parts = []
+    for g in range(world):
+        assert gpu_ctx.precompute(share, c=c, point_lo=g * share) == (c, K, K * share * 256)
+        assert gpu_ctx.tables_range() == (g * share, share)
+        p, info = shard(g)
+        assert info["tables"]
+        parts.append(p)
+    assert combine_groups_host(b"".join(parts), world, K, c, _lib.CURVE_BLS12_377_G1) == full.as_tuple()
+    # a window shard on tables: windows [2, 5) through tables 0 .. 2, their sum in slot 2 of the full set of slots
+    lo, hi = 2, 5
+    pw, iw = gpu_ctx.window_sums(dev + 32 * (world - 1) * share, share, lo, hi, c=c, on_device=True, point_lo=(world - 1) * share, merged=True)
+    ref = b"".join(gpu_ctx.window_sums(dev + 32 * (world - 1) * share, share, k, k + 1, c=c, on_device=True, point_lo=(world - 1) * share)[0]
+                   for k in range(K))
+    mixed = ref[: 144 * lo] + pw + ref[144 * hi:]
+    from montgomery_amd.distributed import combine_host
+    assert iw["tables"] and combine_host(mixed, K, c, _lib.CURVE_BLS12_377_G1) == combine_host(ref, K, c, _lib.CURVE_BLS12_377_G1)
+    # the whole set: its tables go into the row buffer and replace the range's; a range then leaves them alone
+    whole, iwh = gpu_ctx.run_device(dev, n)
+    assert iwh["tables"] and gpu_ctx.tables_range() == (0, n) and whole.as_tuple() == full.as_tuple()
+    for _ in range(2):
+        p, info = shard(1)
+        assert not info["tables"] and gpu_ctx.tables_range() == (0, n)
+    # new points drop everything
+    gpu_ctx.generate_points(4096, seed=63)
+    assert gpu_ctx.tables_info() == (0, 0, 0) and gpu_ctx.tables_range() == (0, 0)
+
+
+def test_edwards_range_tables():
+    from montgomery_amd import _lib
+    from montgomery_amd.api import MsmContext
+    from montgomery_amd.distributed import combine_groups_host
+
+    ctx = MsmContext(_lib.CURVE_ED_ON_BLS12_377)
+    try:
+        n = 1 << 15
+        ctx.generate_points(n, seed=71)
+        dev, _ = ctx.generate_scalars(n, seed=72)
+        full, _ = ctx.run_device(dev, n, no_tables=True)
+        share = n // 2
+        c, K = ctx.plan(share, merged=True)
+        parts = []
+        for g in range(2):
+            ctx.precompute(share, c=c, point_lo=g * share)
+            p, info = ctx.window_sums(dev + 32 * g * share, share, 0, K, c=c, on_device=True, point_lo=g * share, merged=True)
+            assert info["tables"], info
+            parts.append(p)
+        assert combine_groups_host(b"".join(parts), 2, K, c, _lib.CURVE_ED_ON_BLS12_377) == (full.x, full.y)
+    finally:
+        ctx.close()

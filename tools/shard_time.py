@@ -22,7 +22,7 @@ def best_of(f, reps=3):
 
 full, _ = best_of(lambda: ctx.run_device(dev, n, no_tables=True))
 print(f"2^{lg}, c = {c}, K = {K}: full MSM {full:.1f} ms")
-plan = lambda m, cc: ctx.plan(m, cc, no_tables=True)
+plan = lambda m, cc, no_tables=False, merged=False: ctx.plan(m, cc, no_tables=no_tables, merged=merged)
 for G in (2, 4, 8):
     # the windows each sharding runs with (choose_window: K the ranks divide / the pick for a rank's share of the points)
     cw, Kw = choose_window(plan, n, G, "windows")
@@ -34,10 +34,16 @@ for G in (2, 4, 8):
     m = n // G
     first = (G - 1) * m
     tp, ip = best_of(lambda: ctx.window_sums(dev + 32 * first, m, 0, Kp, c=cp, on_device=True, point_lo=first))
+    # the same shard on the window tables of its range of the points (round 6), where they fit the limit (10 % of the device)
+    ctx.precompute(m, c=cp, point_lo=first)
+    tpt, ipt = best_of(lambda: ctx.window_sums(dev + 32 * first, m, 0, Kp, c=cp, on_device=True, point_lo=first, merged=True))
+    on_tab = bool(ipt["tables"])
+    ctx.precompute(4096, point_lo=0)   # (give the range's tables back)
     # bucket shard: the single-GPU plan, the slowest of the first and the last range of the buckets
     tb, ib = max((best_of(lambda g=g: ctx.window_sums(dev, n, 0, K, c=c, on_device=True, bucket_shard=(g, G))) for g in (0, G - 1)), key=lambda x: x[0])
     print(f"G = {G}: window shard (c = {cw}, {w} of {Kw} windows) {tw:.1f} ms (top windows {tt:.1f})  -> x{full / tw:.2f}   "
-          f"points shard (c = {cp}) {tp:.1f} ms -> x{full / tp:.2f}   bucket shard (c = {c}, K = {K}) {tb:.1f} ms -> x{full / tb:.2f}")
+          f"points shard (c = {cp}) {tp:.1f} ms -> x{full / tp:.2f}   " + (f"on range tables {tpt:.1f} ms -> x{full / tpt:.2f}   " if on_tab else
+          f"(range tables do not fit the limit; merged sums {tpt:.1f} ms)   ") + f"bucket shard (c = {c}, K = {K}) {tb:.1f} ms -> x{full / tb:.2f}")
     print("   bucket phases", {k: round(v, 1) for k, v in ib["phase_ms"].items()})
     print("   window phases", {k: round(v, 1) for k, v in (iw or {"phase_ms": {}})["phase_ms"].items()})
     print("   points phases", {k: round(v, 1) for k, v in ip["phase_ms"].items()})
