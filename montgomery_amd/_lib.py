@@ -69,6 +69,35 @@ class MsmError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process, whichever of torch and this package is imported first.
+
+    The ROCm wheels of torch bundle their own libamdhip64.so (SONAME libamdhip64.so.7, found through the RPATH of torch's
+    libraries under the name `libamdhip64.so`); libmsm_hip.so asks for `libamdhip64.so.7`.  With torch imported first the
+    dynamic loader hands this library the runtime torch has already mapped (same SONAME).  The other way round it would map
+    the system runtime for this library and then, for torch, the bundled file as a SECOND runtime -- and torch reports
+    "No HIP GPUs are available".  So if a torch installation with a bundled runtime exists and is not loaded yet, that runtime
+    is mapped here first: this library binds to it by SONAME, and a later `import torch` finds the very file already loaded.
+    torch itself is never imported by this package."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        try:
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass   # the library then binds to the system runtime, as a process without torch does
+
+
 def load() -> C.CDLL:
     """Load the HIP extension; raises if it has not been built (python __graft_entry__.py / make)."""
     global _lib
@@ -76,6 +105,7 @@ def load() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
     # a library built from another version of include/msm_hip.h keeps its symbol names but not its struct layouts

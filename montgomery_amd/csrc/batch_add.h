@@ -59,26 +59,10 @@ constexpr int BA_THREADS = 256;
 // the unpacking of the next operands with the running product), which doubles the live accumulators and costs a
 // resident wave.  Nothing crosses it.
 #define BA_FENCE() __builtin_amdgcn_sched_barrier(0)
-#ifdef BA_X_NOMUL   // experiment: memory traffic only (results are garbage)
-#define BA_MUL(r, x, y) fe_add<F>(r, x, y)
-#define BA_SQR(r, x) fe_add<F>(r, x, x)
-#define BA_INV(r, x) r = x
-#else
-#define BA_MUL(r, x, y) fe_mul<F>(r, x, y)
-#define BA_SQR(r, x) fe_sqr<F>(r, x)
-#ifdef BA_X_NOINV   // experiment: the shared inversion compiled out (wrong sums): what the inversions cost per round
-#define BA_INV(r, x) r = x
-#else
-#define BA_INV(r, x) fe_inv<F>(r, x)
-#endif
-#endif
-#ifndef MSM_BA_SHARED_INV
-#define MSM_BA_SHARED_INV 1  // one inversion per workgroup and lane column (k_batch_add); 0: one per lane, the form of rounds 1-4
-#endif
-static_assert(!MSM_BA_SHARED_INV || BA_THREADS == 256, "the shared inversion is written for four waves per workgroup");
-#ifndef MSM_BA_WAVES
-#define MSM_BA_WAVES 2      // resident waves per SIMD the register allocation is held to (2: 256 VGPRs, 3: 168 + LDS parking)
-#endif
+static_assert(BA_THREADS == 256, "the shared inversion is written for four waves per workgroup");
+// resident waves per SIMD the register allocation is held to: 256 VGPRs per lane, everything stays in registers (three waves --
+// 168 VGPRs and three coordinates parked in the LDS per step -- and more were measured slower: DESIGN.md section 5)
+constexpr int BA_WAVES = 2;
 
 // ---------------------------------------------------------------------------------------------------------------
 // packed-word helpers.  gfx9 allows ONE scalar or literal operand per VALU instruction and the carry-in of a chain is
@@ -192,9 +176,6 @@ __device__ __forceinline__ void ba_locate<MODE_GATHER>(PairLoc<MODE_GATHER>& L, 
   const uint32_t rs = a.slots ? 128u : 64u;   // uniform: bytes per operand (a row of the point table / one record)
   const bool aa = pp.x == 0xFFFFFFFFu, bb = pp.y == 0xFFFFFFFFu;
   // absent operands read row 0 (valid memory) and are then ignored: no divergent loads
-#ifdef BA_X_ROWMASK   // experiment: all gathers inside a 256 MB window of the table (wrong sums, timing of perfect locality)
-  pp.x &= (BA_X_ROWMASK << 2) | 3u; pp.y &= (BA_X_ROWMASK << 2) | 3u;
-#endif
   const uint64_t oa = aa ? 0 : (uint64_t)(pp.x >> 1) * rs;
   const uint64_t ob = bb ? 0 : (uint64_t)(pp.y >> 1) * rs;
   L.pa = reinterpret_cast<const char*>(a.points) + oa;
@@ -358,7 +339,7 @@ __device__ __forceinline__ uint32_t ba_denominator(Fe<F>& den, const PkW<F::NW>&
 // ---------------------------------------------------------------------------------------------------------------
 
 template <class CV, int MODE>
-__global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArgs a) {
+__global__ void __launch_bounds__(BA_THREADS, BA_WAVES) k_batch_add(BatchArgs a) {
   using F = typename CV::F;
   using Pk = PkW<F::NW>;
   constexpr int NW = F::NW, NP = F::NW / 4;   // packed words and 16-byte pieces per coordinate
@@ -368,11 +349,6 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
   // lane t owns the pairs e = t + i * T; all lanes walk all `steps` steps (a uniform loop: the step's bases stay in
   // SGPRs), lanes past the end of the round idle through it with den = 1 and no stores
   auto is_active = [&](uint32_t i) { return (uint64_t)i * T + t < a.n_out; };
-#ifdef BA_X_NOMEM   // experiment: every step uses the addresses of step 0 (cache hits; results are garbage): the ALU time alone
-#define BA_STEP(i) 0u
-#else
-#define BA_STEP(i) (i)
-#endif
 
   Fe<F> acc;
   fe_set_one<F>(acc);
@@ -388,18 +364,17 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
       Fe<F> den;
       ba_denominator<F, MODE, false>(den, x1, x2, nullptr, nullptr, L, a, t, is_active(i));
       if (i + 1 < steps) {   // the next pair's x: its registers are free now, the multiplication covers the latency
-        ba_locate<MODE>(L, a, BA_STEP(i + 1), T, t, is_active(i + 1));
+        ba_locate<MODE>(L, a, i + 1, T, t, is_active(i + 1));
         ba_load_x<F, MODE>(x1, x2, L, a, t);
       }
-      ba_store_pre(a, BA_STEP(i), T, t, acc.l);
+      ba_store_pre(a, i, T, t, acc.l);
       BA_FENCE();
-      BA_MUL(acc, acc, den);
+      fe_mul<F>(acc, acc, den);
       BA_FENCE();
     }
   }
 
   Fe<F> inv;
-#if MSM_BA_SHARED_INV && !defined(BA_X_NOMUL) && !defined(BA_X_NOINV)
   {
     // One inversion per WORKGROUP and lane column instead of one per wave.  An inversion costs ~13 pair additions' worth of
     // instructions and every lane paid one per launch: a quarter of the tree at 2^20, where a lane's chain is 28 - 56 pairs,
@@ -443,52 +418,30 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
       fe_mul<F>(inv, ti, e);
     }
   }
-#else
-  BA_INV(inv, acc);
-#endif
 
   // ---- backward sweep ------------------------------------------------------------------------
   // Order inside one step (what is live where decides the register allocation, hence the resident waves):
-  //   d = inv * pre | den, num (all rare cases here, while little else is live) | x1, x2, y1 parked in LDS |
-  //   inv *= den | m = num * d | m^2 | x1, x2 back: x3 = m^2 - x1 - x2 | next prefix product requested |
-  //   y1 back: y3 = m (x1 - x3) - y1 | loads of the next pair | stores
-  // The three coordinates that are only needed again after three multiplications wait in the LDS (each lane its own
-  // 144 bytes, no barrier): 36 registers that the allocator would otherwise spill to scratch memory to stay under the
-  // launch bound.
+  //   d = inv * pre | den, num (all rare cases here, while little else is live) |
+  //   inv *= den | next x and prefix product requested | m = num * d | m^2 | x3 = m^2 - x1 - x2 |
+  //   y3 = m (x1 - x3) - y1 | loads of the next pair's y | stores
+  // Everything stays in registers at two waves per SIMD (256 VGPRs per lane).
   {
-#if MSM_BA_WAVES >= 3
-    __shared__ uint4 park[3 * NP * BA_THREADS];
-    auto park_put = [&](int slot, const Pk& v) {
-#pragma unroll
-      for (int j = 0; j < NP; j++) park[(slot * NP + j) * BA_THREADS + threadIdx.x] = make_uint4(v.w[4 * j], v.w[4 * j + 1], v.w[4 * j + 2], v.w[4 * j + 3]);
-    };
-    auto park_get = [&](Pk& v, int slot) {
-#pragma unroll
-      for (int j = 0; j < NP; j++) {
-        const uint4 q = park[(slot * NP + j) * BA_THREADS + threadIdx.x];
-        v.w[4 * j] = q.x; v.w[4 * j + 1] = q.y; v.w[4 * j + 2] = q.z; v.w[4 * j + 3] = q.w;
-      }
-    };
-#else   // two waves per SIMD: 256 registers per lane, everything stays in registers
-    auto park_put = [&](int, const Pk&) {};
-    auto park_get = [&](Pk&, int) {};
-#endif
     PairLoc<MODE> L, Ln;
     Pk x1, x2, y1, y2, nx1, nx2;
     Fe<F> pre, npre;
-    ba_locate<MODE>(L, a, BA_STEP(steps - 1), T, t, is_active(steps - 1));
+    ba_locate<MODE>(L, a, steps - 1, T, t, is_active(steps - 1));
     ba_load_x<F, MODE>(x1, x2, L, a, t);
-    ba_load_pre(pre.l, a, BA_STEP(steps - 1), T, t);
+    ba_load_pre(pre.l, a, steps - 1, T, t);
     ba_load_y<F, MODE>(y1, y2, L, a, t);
     Ln = L;
 #pragma unroll 1
     for (int i = (int)steps - 1; i >= 0; i--) {
       const bool active = is_active((uint32_t)i);
-      const uint64_t e_cur = (uint64_t)BA_STEP(i) * T + t;
+      const uint64_t e_cur = (uint64_t)i * T + t;
       uint32_t o_local = 0;
       if (MODE == MODE_GATHER && a.dest && active) o_local = a.dest[e_cur];
       Fe<F> d, den, num;
-      BA_MUL(d, inv, pre);                         // 1 / den_i
+      fe_mul<F>(d, inv, pre);                         // 1 / den_i
       BA_FENCE();
       const uint32_t kind = ba_denominator<F, MODE, true>(den, x1, x2, &y1, &y2, L, a, t, active);
       {
@@ -505,33 +458,27 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
           fe_add<F>(num, num, sq);
         }
       }
-      park_put(0, x1);
-      park_put(1, x2);
-      park_put(2, y1);
-      asm volatile("" ::: "memory");                  // the parked values are re-read, not kept in registers
       BA_FENCE();
-      BA_MUL(inv, inv, den);                       // strip den_i from the running inverse
+      fe_mul<F>(inv, inv, den);                       // strip den_i from the running inverse
       BA_FENCE();
       // The next pair's x and prefix product are requested here, three multiplications before they are needed:
       // 37 registers that are free from now on (the widest point of the step, inv * den with d and num waiting, is behind)
       if (i > 0) {
-        ba_locate<MODE>(Ln, a, BA_STEP((uint32_t)i - 1), T, t, is_active((uint32_t)i - 1));
+        ba_locate<MODE>(Ln, a, (uint32_t)i - 1, T, t, is_active((uint32_t)i - 1));
         ba_load_x<F, MODE>(nx1, nx2, Ln, a, t);
-        ba_load_pre(npre.l, a, BA_STEP((uint32_t)i - 1), T, t);
+        ba_load_pre(npre.l, a, (uint32_t)i - 1, T, t);
       }
       BA_FENCE();
       Fe<F> m;
-      BA_MUL(m, num, d);
+      fe_mul<F>(m, num, d);
       BA_FENCE();
       Pk x3, y3;
       {
         Fe<F> mm;
-        BA_SQR(mm, m);
+        fe_sqr<F>(mm, m);
         pk_pack<F>(x3, mm);                           // < p (1 + 2^-11)
       }
       BA_FENCE();
-      park_get(x1, 0);
-      park_get(x2, 1);
       pk_sub_mod<F>(x3, x3, x1);                      // m^2 - x1 - x2, every step in [0, p (1 + 2^-11))
       pk_sub_mod<F>(x3, x3, x2);
       pk_reduce_product<F>(x3);
@@ -541,12 +488,11 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
         pk_sub_mod<F>(tw, x1, x3);
         pk_unpack<F>(tt, tw);
         BA_FENCE();
-        BA_MUL(y3l, m, tt);
+        fe_mul<F>(y3l, m, tt);
         pk_pack<F>(y3, y3l);
       }
       BA_FENCE();
       // y3 = m (x1 - x3) - y1; gather mode may hold y1 = p (a negated zero): reduce it first in that rare case
-      park_get(y1, 2);
       if (MODE == MODE_GATHER) pk_reduce_product<F>(y1);
       pk_sub_mod<F>(y3, y3, y1);
       pk_reduce_product<F>(y3);
@@ -555,7 +501,6 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
       // are still at hand.  Only "first operand is the identity" fetches the second operand again.
       if (__any(kind & ~BA_DOUBLE)) {
         const bool ca = kind & BA_COPY_A, cb = kind & BA_COPY_B, z = kind & BA_ZERO;
-        park_get(x1, 0);
 #pragma unroll
         for (int j = 0; j < NW; j++) {
           x3.w[j] = z ? INF_WORD : ca ? x1.w[j] : x3.w[j];
@@ -609,7 +554,7 @@ __global__ void __launch_bounds__(BA_THREADS, MSM_BA_WAVES) k_batch_add(BatchArg
           }
         } else
         {
-        char* ob = reinterpret_cast<char*>(a.out + (uint64_t)BA_STEP(i) * T);
+        char* ob = reinterpret_cast<char*>(a.out + (uint64_t)i * T);
         ba_store3(ob, 16u * t, a.out_cap * 16, x3);
         ba_store3(ob + NP * a.out_cap * 16, 16u * t, a.out_cap * 16, y3);
         }

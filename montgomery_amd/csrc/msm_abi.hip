@@ -274,19 +274,7 @@ static int run_piped(msm_ctx* ctx, const void* scalars, uint64_t n, const msm_op
     const int big = n >= (1ull << 25);
     std::vector<uint64_t> piece_end;
     std::vector<int> shifts = {big ? 4 : 3, big ? 2 : 1};
-#ifdef MSM_TUNING
-    if (const char* e = getenv("MSM_PIPE_SH")) {   // experiment: "5,3,1" = ranges ending at n/32, n/8, n/2, n
-      shifts.clear();
-      for (const char* q = e; *q;) { shifts.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; }
-    }
-#endif
     for (int sh : shifts) piece_end.push_back(((n >> sh) / gran) * gran);
-#ifdef MSM_TUNING
-    if (const char* e = getenv("MSM_PIPE_64")) {   // experiment: "4,13" = ranges ending at 4/64 and 13/64 of the points, and n
-      piece_end.clear();
-      for (const char* q = e; *q;) { piece_end.push_back(((n * (uint64_t)atoi(q) / 64) / gran) * gran); while (*q && *q != ',') q++; if (*q) q++; }
-    }
-#endif
     piece_end.push_back(n);
     ctx->ensure(ctx->scal, n * 32);   // before any workspace is sized from what the device has free
     std::vector<size_t> ends;
@@ -311,29 +299,14 @@ static int run_piped(msm_ctx* ctx, const void* scalars, uint64_t n, const msm_op
       if (R[q].cnt && make_plan(ctx, R[q].cnt, &R[q].o, R[q].pq)) return fail(ctx, MSM_ERR_ARG, "%s: bad window size", who);
       R[q].pq.merged = true;
     }
-#ifdef MSM_TUNING
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-    const bool pipe_log = getenv("MSM_PIPE_LOG") != nullptr;
-#endif
     // the ranges in order, each as soon as its scalars are in HBM (a second pipeline on the device running the middle range beside
     // its neighbours was tried and bought nothing -- work is conserved: profiles/r05_experiments.txt item 11)
     for (size_t q = 0; q < Q; q++) {
       Range& r = R[q];
       if (r.cnt == 0) continue;
-#ifdef MSM_TUNING
-      const double t_w0 = since();
-#endif
       pipe.wait_piece((int)q, ctx->stream);
       HIPCHK(hipStreamSynchronize(ctx->stream));       // the range's scalars are in HBM
-#ifdef MSM_TUNING
-      const double t_w1 = since();
-#endif
       window_sums_impl(ctx, (const uint32_t*)ctx->scal.p + r.lo * 8, r.cnt, 1, &r.o, 0, r.pq.K, r.pq, r.words, &r.st, r.o.point_lo);
-#ifdef MSM_TUNING
-      if (pipe_log) fprintf(stderr, "range %zu: %llu scalars, c = %d: waited %.2f .. %.2f, ran until %.2f ms (device total %.2f)\n", q,
-                            (unsigned long long)r.cnt, r.pq.c, t_w0, t_w1, since(), r.st.phase_ms[MSM_T_TOTAL]);
-#endif
     }
     msm_host::Proj6 acc = ctx->hc.zero();
     for (size_t q = 0; q < Q; q++) {

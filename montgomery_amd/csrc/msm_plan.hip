@@ -140,7 +140,7 @@ int make_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, Plan& pl, bo
 // backward sweep in step; four batches of 128 steps instead of one of 512 stagger the phases (2^26, one window:
 // 31.5 -> 29.2 ms).  With two groups on two streams the other stream already fills the gaps and 512 is better.
 RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather, bool lone) {
-  uint64_t target = (uint64_t)ctx->n_cu * 4 * MSM_BA_WAVES * 64;  // as many lanes as the kernel's launch bounds keep resident
+  uint64_t target = (uint64_t)ctx->n_cu * 4 * BA_WAVES * 64;  // as many lanes as the kernel's launch bounds keep resident
   // steps at full width below which a non-gather round runs on half as many lanes: every lane pays one inversion per
   // round (~13 pair additions' worth), and one wave per SIMD already gets 89 % of the multiplier's two-wave rate
   // (tools/ubench_mul2.hip).  Measured with the round-2 kernel: 2^20 4.05 -> 3.91 ms, 2^22 12.9 -> 12.4, neutral elsewhere.

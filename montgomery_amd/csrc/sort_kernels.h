@@ -359,13 +359,11 @@ __global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(uint32_t* slots, c
 // ---------------------------------------------------------------------------------------------
 
 constexpr int RX_THREADS = 1024;
-#ifndef RXA_WAVES
-#define RXA_WAVES 8   // pass A: two workgroups per CU (60 KB of LDS each) -- one loads its tile while the other ranks
-#endif
+constexpr int RXA_WAVES = 8;   // pass A: two workgroups per CU (60 KB of LDS each) -- one loads its tile while the other ranks
 constexpr int RXA_ITEMS = 7, RXA_TILE = RX_THREADS * RXA_ITEMS;    // pass A: 7168 records of 8 bytes staged per tile (56 KB)
-#ifndef RXB_THREADS
-#define RXB_THREADS 512   // pass B: 512-thread workgroups, two resident per CU (its ~108 VGPRs allow four waves per SIMD): one walks
-#endif                    // its virtual window's next tile in while the other ranks (1024 threads: one workgroup per CU, 2.46 ms)
+// pass B: 512-thread workgroups, two resident per CU (its ~108 VGPRs allow four waves per SIMD): one walks its virtual window's
+// next tile in while the other ranks (1024 threads: one workgroup per CU, 2.46 ms)
+constexpr int RXB_THREADS = 512;
 constexpr int RXB_ITEMS = 12, RXB_TILE = RXB_THREADS * RXB_ITEMS;   // payloads + bucket bytes staged per tile (30 KB)
 constexpr uint32_t RX_FINE_BITS = 7;
 
@@ -592,13 +590,7 @@ __device__ __forceinline__ uint32_t bucket_scan(uint32_t NB, uint32_t* lds_wave,
 //   ... with barriers that do not wait for the stores to drain                      2.35: nor the fences
 //   32 k tiles (256-byte runs), records staged in 4 bytes                           see item 10
 // 512 threads x 16 or x 24 with two workgroups per CU: 2.4 / 2.13; the next tile's digits requested early: no change.
-#ifndef MSM_BS_THREADS
-#define MSM_BS_THREADS 1024
-#endif
-#ifndef MSM_BS_ITEMS
-#define MSM_BS_ITEMS 32
-#endif
-constexpr int BS_THREADS = MSM_BS_THREADS, BS_ITEMS = MSM_BS_ITEMS, BS_TILE = BS_THREADS * BS_ITEMS;
+constexpr int BS_THREADS = 1024, BS_ITEMS = 32, BS_TILE = BS_THREADS * BS_ITEMS;
 // k_colscan for the bin split's slice histograms: few columns (the coarse bins of the group), many rows (one per slice -- on
 // window tables kc times as many).  k_colscan walks a column with one thread: B latencies in sequence (0.5 ms for 8 192 rows).
 // Here 32 row lanes share a column: each sums a contiguous range of the rows, the 32 sums are scanned in the LDS, and each lane
@@ -980,13 +972,7 @@ __global__ void __launch_bounds__(BC_THREADS) k_bin_count(uint32_t* counts, cons
 // pass B.  One block per bin v = kk * hb + h (heaviest -- a short top window's -- first: v = V - 1 - blockIdx.x).  `cursor` holds
 // the padded slot offset of every bucket of the group and, at [nb], the total; a bucket of n entries owns roundup(n, G) / 2
 // consecutive pairs of round 1, i.e. consecutive elements of its output.
-#ifndef MSM_BP_PREFETCH
-#define MSM_BP_PREFETCH 1
-#endif
-#ifndef MSM_BP_ITEMS
-#define MSM_BP_ITEMS 8
-#endif
-constexpr int BP_THREADS = 512, BP_ITEMS = MSM_BP_ITEMS, BP_TILE = BP_THREADS * BP_ITEMS;   // 4 096 records per tile
+constexpr int BP_THREADS = 512, BP_ITEMS = 8, BP_TILE = BP_THREADS * BP_ITEMS;   // 4 096 records per tile
 inline size_t bin_pairs_lds(uint32_t nbmax) { return (size_t)5 * nbmax * 4 + 64 * 4 + (size_t)((BP_TILE + nbmax) / 2 + 1) * 12; }
 inline size_t bin_slots_lds(uint32_t nbmax) { return (size_t)3 * nbmax * 4 + 64 * 4 + (size_t)BP_TILE * 6; }
 
@@ -1065,9 +1051,7 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_pairs(uint2* pairs, uint32_t
       const uint32_t l = r[i].x & 0xFFFFu;
       rk[i] = lds_rank_add(t_cnt, l ? l - 1 : 0u, l != 0);
     }
-#if MSM_BP_PREFETCH
     load_tile(nr, t0 + BP_TILE);   // the next tile's records are in flight while this one is paired and copied out
-#endif
     __syncthreads();
     // per bucket: m = pending + the tile's entries -> m / 2 pairs now, m & 1 entries pending
     const uint32_t n_pairs = bucket_scan<BP_THREADS>(
@@ -1105,12 +1089,8 @@ __global__ void __launch_bounds__(BP_THREADS) k_bin_pairs(uint2* pairs, uint32_t
     }
     out_pos += n_pairs;
     __syncthreads();
-#if MSM_BP_PREFETCH
 #pragma unroll
     for (int i = 0; i < BP_ITEMS; i++) r[i] = nr[i];
-#else
-    load_tile(r, t0 + BP_TILE);
-#endif
   }
   if (pl.j + 1 < pl.np) {
     // not the bin's last part: an odd one out is paired with nothing here (the bucket's entries pair up inside a part)

@@ -25,9 +25,6 @@ __global__ void __launch_bounds__(256) k_tail_desc(uint32_t* desc, const uint32_
   __shared__ uint32_t run[2];
   const uint32_t e0 = blockIdx.x * blockDim.x;
   const uint32_t e = e0 + threadIdx.x;
-#ifdef MSM_X_FLAT_TAIL_DESC   // experiment: every lane searches the whole table (the kernel of rounds 1-3)
-  if (threadIdx.x == 0) { run[0] = 0; run[1] = nb - 1; }
-#else
   if (threadIdx.x == 0 || threadIdx.x == blockDim.x - 1) {
     const uint32_t ee = min(threadIdx.x == 0 ? e0 : e0 + blockDim.x - 1, n_out - 1);
     uint32_t lo = 0, hi = nb;
@@ -37,7 +34,6 @@ __global__ void __launch_bounds__(256) k_tail_desc(uint32_t* desc, const uint32_
     }
     run[threadIdx.x == 0 ? 0 : 1] = lo;
   }
-#endif
   __syncthreads();
   if (e >= n_out) return;
   uint32_t lo = run[0], hi = run[1] + 1;   // the bucket of e lies in [run[0], run[1]]: off_out[lo] <= e < off_out[hi]

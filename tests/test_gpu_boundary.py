@@ -455,3 +455,39 @@ def test_bench_sharded_path_over_rccl_with_one_rank():
     assert d["n_gpus"] == 1 and d["verified"] is True and d["split"] == "windows", d
     assert "window-shard x1" in d["config"]["parallelism"] and len(d["ranks"]) == 1 and d["ranks"][0]["all_gather_ms"] is not None
     assert d["other_splits"][0]["split"] == "points" and d["other_splits"][0]["verified"] is True
+
+
+def test_package_imported_before_torch_shares_one_hip_runtime():
+    """The ROCm wheels of torch bundle their own libamdhip64; a process that loaded libmsm_hip.so first used to map the system
+    runtime, torch then a second one, and torch saw no GPU.  The loader
+    now maps the runtime torch would use before the library (montgomery_amd/_lib.py): either import order leaves ONE runtime.
+    A child process imports the package and runs an MSM BEFORE it imports torch, then uses a torch tensor as the scalar buffer."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+from montgomery_amd.api import MsmContext
+assert "torch" not in sys.modules
+ctx = MsmContext()
+n = 1 << 12
+ctx.generate_points(n, seed=3)
+dev, sb = ctx.generate_scalars(n, seed=4, to_host=True)
+first, _ = ctx.run_device(dev, n)
+import torch
+assert torch.cuda.is_available(), "torch sees no GPU after montgomery_amd was imported first"
+t = torch.frombuffer(bytearray(sb), dtype=torch.uint8).to("cuda:0")
+torch.cuda.synchronize()
+second, _ = ctx.run_device(t.data_ptr(), n)
+assert second.as_tuple() == first.as_tuple()
+maps = open("/proc/self/maps").read()
+libs = sorted({l.split()[-1] for l in maps.splitlines() if "libamdhip64" in l})
+assert len(libs) == 1, libs
+ctx.close()
+print("ok", libs[0])
+''' % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and out.stdout.strip().startswith("ok"), out.stdout[-1500:] + out.stderr[-3000:]
