@@ -136,6 +136,7 @@ def cpu_baseline(ctx, log2n_sample, seed, log2n_headline=None):
                        "std_s": statistics.stdev(times) if len(times) > 1 else None, "points_per_s": n / statistics.median(times),
                        "threads": threads, "window_bits": e["window_bits"]})
     top = [e for e in series if e["log2_n"] == sizes[-1]][0]   # `value`: the repeated sample (median of 3); the one call at the headline size is series[-1]
+    threads = top["threads"]
     quota = rep.get("quota") or 0
     return {
         "value": top["points_per_s"],
