@@ -668,6 +668,77 @@ MSM_DEV void bit_tree_body(uint32_t* out, const uint32_t* rows, const uint32_t* 
   // the same number of additions in sequence.  Second stage (masked == 2): grid (1, nbits + 1, kc).
   uint32_t blk = blockIdx.x, y = blockIdx.y, nblk = gridDim.x;
   const uint32_t kk = blockIdx.z, tid = threadIdx.x;
+  if (masked >= 3) {
+    // Two-dimensional form (round 6).  The masked sums above add every row to half of the nbits sums: nchunks * nbits / 2
+    // additions.  With the chunk index cut as ch = hi * M_lo + lo,  sum_ch ch * row_ch = M_lo * sum_hi hi * A_hi + sum_lo lo * B_lo
+    // with A_hi = sum_lo row (a run of M_lo rows) and B_lo = sum_hi row (a column of M_hi rows): 2 * nchunks additions, and the
+    // bit-sliced weighting then runs over the M_hi + M_lo sums only -- S_b = masked sum over B for the low bits, over A for the
+    // high ones: the same nbits + 1 results, so the host tail is unchanged.
+    //   masked == 3: grid (M_hi + M_lo + nblk_out, 1, kc): block -> A_hi | B_lo | a share of the local triangles; raw points to
+    //                out[kk][M_hi + M_lo + nblk_out]
+    //   masked == 4: grid (1, nbits + 1, kc) over those (`rows` = the first stage's output): y < h0: bit y of lo over B;
+    //                y < nbits: bit y - h0 of hi over A; y == nbits: the nblk_out triangle shares
+    const uint32_t h1 = nbits / 2, h0 = nbits - h1, M_lo = 1u << h0, M_hi = 1u << h1, per_kk = M_hi + M_lo + nblk_out;
+    uint32_t count, kind;   // kind 0: A run, 1: B column, 2: triangle share (first stage); 3: masked over stage-1 slots, 4: plain over slots
+    uint32_t a0 = 0, a1 = 0;
+    if (masked == 3) {
+      if (blk < M_hi) { kind = 0; count = M_lo; a0 = blk * M_lo; }
+      else if (blk < M_hi + M_lo) { kind = 1; count = M_hi; a0 = blk - M_hi; }
+      else {
+        kind = 2;
+        const uint32_t t = blk - M_hi - M_lo, span = (n_in + nblk_out - 1) / nblk_out;
+        a0 = min(t * span, n_in);
+        count = min(a0 + span, n_in) - a0;
+      }
+    } else {
+      if (y < h0) { kind = 3; count = M_lo >> 1; a0 = M_hi; a1 = y; }
+      else if (y < nbits) { kind = 3; count = M_hi >> 1; a0 = 0; a1 = y - h0; }
+      else { kind = 4; count = nblk_out; a0 = M_hi + M_lo; }
+    }
+    uint32_t m = 1;
+    while (m < count && m < BT_THREADS) m <<= 1;
+    const uint32_t gl = tid & (m - 1);
+    P acc;
+    PT::zero(acc);
+#pragma unroll 1
+    for (uint32_t i = gl; i < count; i += m) {
+      P Q;
+      if (kind <= 2) {
+        const uint32_t j = kind == 1 ? i * M_lo + a0 : a0 + i;
+        const uint32_t* pl = (kind == 2 ? tris : rows) + (uint64_t)kk * W * n_in;
+#pragma unroll
+        for (int w = 0; w < W; w++) PT::word(Q, w) = pl[(uint64_t)w * n_in + j];
+      } else {
+        const uint32_t j = kind == 3 ? ((((i >> a1) << 1) | 1u) << a1) | (i & ((1u << a1) - 1u)) : i;
+        const uint32_t* pp = rows + ((uint64_t)kk * per_kk + a0 + j) * W;
+#pragma unroll
+        for (int w = 0; w < W; w++) PT::word(Q, w) = pp[w];
+      }
+      PT::add(acc, acc, Q);
+    }
+#pragma unroll 1
+    for (uint32_t s = m >> 1; s >= 1; s >>= 1) {
+#pragma unroll
+      for (int w = 0; w < W; w++) lds[w * BT_THREADS + tid] = PT::word(acc, w);
+      __syncthreads();
+      const uint32_t partner = (tid & ~(m - 1)) | ((gl + s) & (m - 1));
+      P Q;
+#pragma unroll
+      for (int w = 0; w < W; w++) PT::word(Q, w) = lds[w * BT_THREADS + partner];
+      __syncthreads();
+      PT::add(acc, acc, Q);
+    }
+    if (tid == 0) {
+      if (masked == 3) {
+        uint32_t* o = out + ((uint64_t)kk * per_kk + blk) * W;
+#pragma unroll
+        for (int w = 0; w < W; w++) o[w] = PT::word(acc, w);
+      } else {
+        PT::pack(out + ((uint64_t)kk * (nbits + 1) + y) * PT::PW, acc);
+      }
+    }
+    return;
+  }
   if (masked == 1) {
     const uint32_t half = nblk_out >> 1;
     if (blk < nbits * half) { y = blk / half; blk -= y * half; nblk = half; }

@@ -87,8 +87,28 @@ void reduce_buckets(msm_ctx* ctx, msm_ctx::Workspace& w, const uint4* fin, uint6
       // have half as many elements as the triangle sum and get half as many blocks; second stage: one wave per
       // (window, bit) over the block sums it finds (the slots a masked sum did not fill are never read)
       const uint32_t nblk = std::max<uint32_t>(2, nchunks / (8 * BT_THREADS));
-      ctx->ensure(w.columns2, (size_t)kc * (nbits + 1) * nblk * raw_words * 4);
       ctx->ensure(w.partials, (size_t)kc * (nbits + 1) * 36 * 4);
+      // Two-dimensional form (msm_kernels.h, bit_tree_body): row sums A_hi and column sums B_lo of the chunk matrix first --
+      // 2 additions per chunk instead of nbits / 2 -- then the nbits masked sums over those 2^(nbits / 2) + ... points.  Measured
+      // (profiles/r06_experiments.txt): 2^20 on tables 0.42 -> 0.2x ms for the two launches, 2^26 0.5 -> 0.3x per window group.
+      const bool two_d = nbits >= 6 && (1u << nbits) == nchunks;
+      if (two_d) {
+        const uint32_t M_hi = 1u << (nbits / 2), M_lo = 1u << (nbits - nbits / 2);
+        const uint32_t per_kk = M_hi + M_lo + nblk;
+        ctx->ensure(w.columns2, (size_t)kc * per_kk * raw_words * 4);
+        if (te) {
+          hipLaunchKernelGGL(te::k_te_bit_tree, dim3(per_kk, 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.columns2.p,
+                             (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, nbits, 3, 0, nblk);
+          hipLaunchKernelGGL(te::k_te_bit_tree, dim3(1, nbits + 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.partials.p,
+                             (const uint32_t*)w.columns2.p, (const uint32_t*)nullptr, nchunks, nbits, 4, 1, nblk);
+        } else {
+          W_LAUNCH(ctx, k_bit_tree, dim3(per_kk, 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.columns2.p,
+                             (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, nbits, 3, 0, nblk);
+          W_LAUNCH(ctx, k_bit_tree, dim3(1, nbits + 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.partials.p,
+                             (const uint32_t*)w.columns2.p, (const uint32_t*)nullptr, nchunks, nbits, 4, 1, nblk);
+        }
+      } else {
+      ctx->ensure(w.columns2, (size_t)kc * (nbits + 1) * nblk * raw_words * 4);
       if (te) {
         hipLaunchKernelGGL(te::k_te_bit_tree, dim3(nbits * (nblk / 2) + nblk, 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.columns2.p,
                            (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, nbits, 1, 0, nblk);
@@ -99,6 +119,7 @@ void reduce_buckets(msm_ctx* ctx, msm_ctx::Workspace& w, const uint4* fin, uint6
                            (const uint32_t*)w.rows_sum.p, (const uint32_t*)w.columns.p, nchunks, nbits, 1, 0, nblk);
         W_LAUNCH(ctx, k_bit_tree, dim3(1, nbits + 1, kc), dim3(BT_THREADS), 0, s, (uint32_t*)w.partials.p,
                            (const uint32_t*)w.columns2.p, (const uint32_t*)nullptr, nblk, nbits, 2, 1, 1u);
+      }
       }
     } else if (te) {
       hipLaunchKernelGGL(te::k_te_bucket_reduce, dim3((threads + 63) / 64), dim3(64), 0, s, (uint32_t*)w.columns.p, (uint32_t*)nullptr,
