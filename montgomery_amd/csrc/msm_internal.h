@@ -35,8 +35,9 @@
 #include <thread>
 #include <vector>
 
-// Experiment knobs (window-group count, round geometry, ...) are environment variables ONLY in builds made with
-// -DMSM_TUNING (tools/policy_sweep.sh, make ab EXTRA=-DMSM_TUNING); the product never reads the environment.
+// Policy knobs -- the six thresholds that are re-measured when a plan changes (MSM_GROUPS, MSM_MAX_STEPS, MSM_PBL, MSM_TC,
+// MSM_FINISH_MAX, MSM_TAIL_MIN) -- are environment variables ONLY in builds made with -DMSM_TUNING (make ab EXTRA=-DMSM_TUNING,
+// tools/knob_sweep.sh); the product never reads the environment.  The knobs of closed experiments left in round 6.
 #ifdef MSM_TUNING
 #define MSM_KNOB(var, name, lo) do { if (const char* _e = getenv(name)) var = std::max<long long>((lo), atoll(_e)); } while (0)
 #define MSM_KNOB_SET(name) (getenv(name) != nullptr)
@@ -448,7 +449,6 @@ class PieceUpload {
   PieceUpload(msm_ctx* ctx, void* dst, const void* src, size_t bytes, const std::vector<size_t>& piece_end_bytes)
       : ctx_(ctx), dst_((char*)dst), src_((const char*)src), bytes_(bytes), ends_(piece_end_bytes), enq_(piece_end_bytes.size(), 0) {
     ensure_staging(ctx);
-    MSM_KNOB(n_streams_, "MSM_UPLOAD_STREAMS", 1);
     n_streams_ = std::max<long long>(1, std::min<long long>(n_streams_, T));
     HIPCHK(hipStreamSynchronize(ctx->stream));   // dst may still be in use by what the stream holds
     for (int t = 0; t < T; t++) HIPCHK(hipStreamSynchronize(ctx->stage_stream[t]));
@@ -508,9 +508,6 @@ class PieceUpload {
         cv_.notify_all();
       }
     };
-    double t_wait = 0, t_copy = 0, t_enq = 0;   // tuning builds: where the host side of the transfer spends its time
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(now() - a).count(); };
     for (size_t i = t; i < n_chunks && e == hipSuccess; i += T, turn++) {
       const size_t off = i * CH, len = std::min(CH, bytes_ - off);
       int upto = q;
@@ -518,21 +515,12 @@ class PieceUpload {
       mark(upto);
       const int slot = (int)(turn % S);
       char* pin = ctx_->stage_pin + ((size_t)t * S + slot) * CH;
-      auto a = now();
       if (turn >= (size_t)S) e = hipEventSynchronize(ctx_->stage_ev[t][slot]);
-      t_wait += since(a);
       if (e != hipSuccess) break;
-      a = now();
       memcpy(pin, src_ + off, len);
-      t_copy += since(a);
-      a = now();
       e = hipMemcpyAsync(dst_ + off, pin, len, hipMemcpyHostToDevice, ctx_->stage_stream[t % n_streams_]);
       if (e == hipSuccess) e = hipEventRecord(ctx_->stage_ev[t][slot], ctx_->stage_stream[t % n_streams_]);
-      t_enq += since(a);
     }
-    if (MSM_KNOB_SET("MSM_UPLOAD_TRACE"))
-      fprintf(stderr, "upload thread %d: slot wait %.1f ms, host copy %.1f ms, enqueue %.1f ms, total %.1f ms\n", t, t_wait, t_copy, t_enq,
-              since(t0_));
     mark((int)ends_.size());   // on an error too: nobody may wait for ever
     if (e == hipSuccess) e = hipStreamSynchronize(ctx_->stage_stream[t % n_streams_]);
     std::lock_guard<std::mutex> l(mu_);

@@ -8,44 +8,12 @@ using namespace msmi;
 
 namespace {
 
-// Two window groups that run side by side on the two streams meet here between their sorts and their trees: neither tree
-// starts before BOTH sorts are done.  A tree kernel holds 2 x 226 of a SIMD's 512 VGPRs for the 512 steps of a workgroup, so a
-// sort still running when the other group's tree arrives finds no room for its workgroups and takes three to four times as
-// long (profiles/r04_experiments.txt items 1 and 8).  Groups with equal work (c = 16: 4 + 4 windows) reach this point together
-// anyway; groups with unequal sorts (c = 22: the top window holds 17 bits) do not.
-// Host side: both workers arrive after queueing their sorts and recording their event, then each makes its stream wait for the
-// other's event.  A worker that fails releases its partner (abort).
-class PairSync {
- public:
-  // returns false if the partner will never arrive (it failed, or there is none)
-  bool arrive_and_wait(int pair, int n_pairs_expected) {
-    std::unique_lock<std::mutex> l(mu_);
-    if ((int)count_.size() < n_pairs_expected) count_.resize(n_pairs_expected, 0);
-    count_[pair]++;
-    cv_.notify_all();
-    cv_.wait(l, [&] { return count_[pair] >= 2 || aborted_; });
-    return count_[pair] >= 2;
-  }
-  void abort() {
-    std::lock_guard<std::mutex> l(mu_);
-    aborted_ = true;
-    cv_.notify_all();
-  }
-
- private:
-  std::mutex mu_;
-  std::condition_variable cv_;
-  std::vector<int> count_;
-  bool aborted_ = false;
-};
-
 // Partition sums P_k for windows [k_lo, k_hi) over the points [p_lo, p_lo + n) -> h_partials_out[(k - k_lo) * 36 ...]
 // scalars: device pointer, n x 8 words.
-// before_tree: called once with the group's stream when everything up to the scatter has been queued (see PairSync).
 // k_base: the first window of the CALL (window tables carry weights relative to it: table j = 2^(c j) P serves window k_base + j)
 void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_scalars_all, uint64_t p_lo, uint64_t n, const Plan& pl,
                       int k_lo, int k_hi, int k_base, uint32_t* h_partials_out, GroupStats& st, uint64_t p_off = 0,
-                      const std::function<void(hipStream_t)>* before_tree = nullptr, GroupDigits* share = nullptr) {
+                      GroupDigits* share = nullptr) {
   hipStream_t s = w.stream;
   const uint32_t* d_scalars = d_scalars_all + p_lo * 8;   // scalar i of the call <-> resident point p_off + i
   p_lo += p_off;
@@ -54,8 +22,7 @@ void run_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sca
   HIPCHK(hipEventRecord(w.ev[0], s));
   sort_window_group(ctx, w, d_scalars, n, pl, k_lo, k_hi, st, so, share);
   st.max_bucket = std::max<uint64_t>(st.max_bucket, so.max_bucket);
-  if (before_tree) (*before_tree)(s);
-  HIPCHK(hipEventRecord(w.ev[5], s));   // the tree starts here (behind the partner group's sort, if there is one)
+  HIPCHK(hipEventRecord(w.ev[5], s));   // the tree starts here
   TreeOut to;
   if (pl.tables) {
     // one merged window over the tables k_lo - k_base .. k_hi - k_base - 1: its sum carries the windows' weights (relative to the
@@ -147,7 +114,6 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     int ka, kb;
     uint64_t p_lo, p_n;
     int piece;   // pipelined upload: the piece whose arrival the group waits for (-1: the scalars are in place)
-    int pair;    // the two groups with the same pair id run side by side and start their trees together (PairSync); -1: none
   };
   std::vector<Group> groups;
   // A single window (the 8-GPU shard) has no second window group to hide its sort and tails under: split it by
@@ -158,8 +124,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   uint64_t pieces = 1;
   if (nwin == 1 && want_groups == 1 && !ctx->is_te() && n >= (1ull << 24) && !MSM_KNOB_SET("MSM_GROUPS")) pieces = 2;
   pieces = std::max(pieces, point_pieces(ctx, n, pl));
-  MSM_KNOB(pieces, "MSM_PIECES", 1);
-  if (!piece_end.empty() && (point_pieces(ctx, n, pl) > 1 || MSM_KNOB_SET("MSM_PIECES"))) {
+  if (!piece_end.empty() && point_pieces(ctx, n, pl) > 1) {
     // the workspace forces its own ranges: plain staged upload first (rare: 2^29 points, or a tight msm_set_workspace_limit)
     piece_end.clear();
     stage_scalars(ctx, scalars, n, on_device, &d_scal);
@@ -173,27 +138,17 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       const uint64_t cnt = piece_end[q] - lo;
       const int g = (nwin >= 2 && cnt >= (1ull << 22)) ? 2 : 1;
       const int per = std::max(1, std::min(wpg, (nwin + g - 1) / g));
-      const size_t first = groups.size();
-      for (int k = k_lo; k < k_hi; k += per) groups.push_back({k, std::min(k_hi, k + per), lo, cnt, (int)q, -1});
-      if (groups.size() - first == 2) groups[first].pair = groups[first + 1].pair = (int)q;
+      for (int k = k_lo; k < k_hi; k += per) groups.push_back({k, std::min(k_hi, k + per), lo, cnt, (int)q});
       lo = piece_end[q];
     }
   } else if (pieces > 1) {
     for (int k = k_lo; k < k_hi; k++)
       for (uint64_t q = 0; q < pieces; q++) {
         const uint64_t lo = n * q / pieces, hi = n * (q + 1) / pieces;
-        groups.push_back({k, k + 1, lo, hi - lo, -1, -1});
+        groups.push_back({k, k + 1, lo, hi - lo, -1});
       }
   } else {
-    long long first_group = 0;   // experiment: windows in the first of two uneven groups
-    MSM_KNOB(first_group, "MSM_WPG_A", 1);
-    if (first_group > 0 && first_group < nwin) {
-      groups.push_back({k_lo, k_lo + (int)first_group, 0, n, -1, -1});
-      groups.push_back({k_lo + (int)first_group, k_hi, 0, n, -1, -1});
-    } else {
-      for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg), 0, n, -1, -1});
-    }
-    if (groups.size() == 2) groups[0].pair = groups[1].pair = 0;
+    for (int k = k_lo; k < k_hi; k += wpg) groups.push_back({k, std::min(k_hi, k + wpg), 0, n, -1});
   }
   // does more than one group contribute to a window?  Then the sums of its ranges are added on the host below.
   bool split_points = false;
@@ -230,12 +185,6 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   std::atomic<int> next{0};
   GroupStats sts[msm_ctx::N_WS];
   const int nthreads = (opts && opts->serial) ? 1 : std::min<int>(msm_ctx::N_WS, (int)groups.size());
-  PairSync psync;
-  // Off: measured neutral where the groups' sorts differ (c = 22: 153.5 against 154.4 ms -- the stretched sort of one group
-  // was time the other group's tree had the chip to itself) and harmful where they are equal (c = 16: 159.9 against 157.3 --
-  // trees that start at the same instant walk their sweeps in step).  Kept as a knob of the tuning build.
-  long long want_pair_sync = 0;
-  MSM_KNOB(want_pair_sync, "MSM_PAIR_SYNC", 0);
   auto worker = [&](int slot) {
     HIPCHK(hipSetDevice(ctx->device));
     for (;;) {
@@ -248,24 +197,8 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
       // the exclusive timing of the roofline) -- walks its pairs in four short batches instead of one long one (round_geom)
       pg.lone = (groups.size() == 1 && (kb - ka == 1 || pl.tables)) || (opts && opts->serial);
       if (groups[gi].piece >= 0) pipe->wait_piece(groups[gi].piece, ctx->ws[slot].stream);
-      // the partner group runs on the other workspace; its ev[2] closes its sort
-      const int pair = (nthreads == 2 && want_pair_sync) ? groups[gi].pair : -1;
-      const std::function<void(hipStream_t)> meet = [&, slot, pair](hipStream_t s) {
-        if (psync.arrive_and_wait(pair, (int)groups.size())) HIPCHK(hipStreamWaitEvent(s, ctx->ws[1 - slot].ev[2], 0));
-        long long tree_delay_us = 0;   // experiment: the second group's tree starts this much after the first one's
-        MSM_KNOB(tree_delay_us, "MSM_TREE_DELAY_US", 0);
-        if (tree_delay_us && slot == 1) {
-          HIPCHK(hipStreamSynchronize(s));
-          std::this_thread::sleep_for(std::chrono::microseconds(tree_delay_us));
-        }
-      };
-      try {
-        run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, k_lo, part.data(), sts[slot], p_off,
-                         pair >= 0 ? &meet : nullptr, share.valid ? &share : nullptr);
-      } catch (...) {
-        psync.abort();   // the partner must not wait for a group that will not arrive
-        throw;
-      }
+      run_window_group(ctx, ctx->ws[slot], d_scal, groups[gi].p_lo, groups[gi].p_n, pg, ka, kb, k_lo, part.data(), sts[slot], p_off,
+                       share.valid ? &share : nullptr);
       if (split_points || pl.tables) split_part[gi] = part;
       else memcpy(&words[(size_t)(ka - k_lo) * pw], part.data(), part.size() * 4);
     }
@@ -274,12 +207,7 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
     // Whatever either worker throws (HIP failure, bad_alloc, ...) is re-raised here only after BOTH have stopped and both
     // group streams are idle: no queued kernel of a failed call may still run when the context is used again.
     std::exception_ptr err;
-    long long stagger_us = 0;
-    MSM_KNOB(stagger_us, "MSM_STAGGER_US", 0);
-    if (nthreads > 1) ctx->helper->run([&, stagger_us] {
-      if (stagger_us) std::this_thread::sleep_for(std::chrono::microseconds(stagger_us));
-      worker(1);
-    });
+    if (nthreads > 1) ctx->helper->run([&] { worker(1); });
     try { worker(0); } catch (...) { err = std::current_exception(); }
     if (nthreads > 1) {
       try { ctx->helper->wait(); } catch (...) { if (!err) err = std::current_exception(); }

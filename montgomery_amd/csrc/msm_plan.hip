@@ -144,16 +144,10 @@ RoundGeom round_geom(const msm_ctx* ctx, uint64_t n_out, bool gather, bool lone)
   // steps at full width below which a non-gather round runs on half as many lanes: every lane pays one inversion per
   // round (~13 pair additions' worth), and one wave per SIMD already gets 89 % of the multiplier's two-wave rate
   // (tools/ubench_mul2.hip).  Measured with the round-2 kernel: 2^20 4.05 -> 3.91 ms, 2^22 12.9 -> 12.4, neutral elsewhere.
-  uint64_t half_below = 128;
-  MSM_KNOB(half_below, "MSM_HALF_BELOW", 0);
+  const uint64_t half_below = 128;
   if (!gather && n_out < target * half_below) target /= 2;
   uint32_t max_steps = (lone && n_out >= target * 512) ? 128 : 512;
   MSM_KNOB(max_steps, "MSM_MAX_STEPS", 1);
-  {
-    long long tw = 0;
-    MSM_KNOB(tw, "MSM_TARGET_WAVES", 1);
-    if (tw) target = (uint64_t)ctx->n_cu * 4 * 64 * (uint64_t)tw;
-  }
   uint64_t steps = (n_out + target - 1) / target;
   steps = std::max<uint64_t>(1, std::min<uint64_t>(steps, max_steps));
   uint64_t threads = (n_out + steps - 1) / steps;

@@ -76,12 +76,10 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   const bool fits_lds = (size_t)L * 4 <= 128 * 1024;
   // measured (round 5, with one ds_add per key as the ranking: tools/sortpath_sweep.sh): the split wins from 2^21 entries per
   // window -- 2^20 points: sort 0.31 against 0.36 ms, 2^21: 0.51 / 0.85; 2^19: level, below: the one-level sort (2^16 0.11 / 0.14)
-  long long want_radix = (fits_lds && cbits > (int)RX_FINE_BITS && two_n >= (te ? 1ull << 22 : 1ull << 21)) ? 1 : 0;
-  MSM_KNOB(want_radix, "MSM_RADIX", 0);
+  const bool want_radix = fits_lds && cbits > (int)RX_FINE_BITS && two_n >= (te ? 1ull << 22 : 1ull << 21);
   // (the merged window of a run on window tables has kc = 1: the radix split would give its last pass one block per coarse bin,
   // 2^(c-8) of them for the whole chip -- the bin split cuts it into 2^10 bins whatever the window is)
-  long long want_bins = (!fits_lds || (pl.tables && two_n >= (1ull << 22))) ? 1 : 0;
-  MSM_KNOB(want_bins, "MSM_BINS", 0);
+  const bool want_bins = !fits_lds || (pl.tables && two_n >= (1ull << 22));
   const bool bin_split = !fits_lds || want_bins;
   const bool radix = !bin_split && want_radix && cbits > (int)RX_FINE_BITS && cbits - (int)RX_FINE_BITS <= 8;
   const bool one_level = !bin_split && !radix;
@@ -96,8 +94,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
       const int eff = pl.tables ? cbits : std::max(1, top ? std::min(cbits, pl.bits - (k_lo + kk) * pl.c) : std::min(cbits, pl.c - 1));
       // up to 10 bits: pass A sorts the window outright; else 2^10 coarse bins (16-entry runs of a 16 k tile), 2^11 if the
       // fine part would otherwise exceed 2^12 buckets per bin
-      long long ab_big = 10;
-      MSM_KNOB(ab_big, "MSM_BIN_AB", 1);
+      const int ab_big = 10;
       const int abk = eff <= (int)ab_big ? eff : std::max((int)ab_big, eff - (int)BS_MAX_FB);
       if (abk > (int)BS_MAX_AB) throw MsmFail{MSM_ERR_INTERNAL, "window too wide for the bin split"};
       ws.ab[kk] = (uint8_t)abk;
@@ -116,8 +113,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   uint64_t chunk = two_n, pps = n;   // entries per slice and window; points per slice
   if (bin_split) {
     // the digit kernel histograms ALL windows of the group over its slice of the points: four slices per CU
-    long long mult = 4;
-    MSM_KNOB(mult, "MSM_SORTB_MULT", 1);
+    const uint64_t mult = 4;
     // one slice per 4 096 points at least; the digit kernel wants a few blocks per CU whatever kc_d is, k_slice_scan walks
     // the kc_d * sortB rows of the merged window with 32 lanes per column
     sortB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)mult * ctx->n_cu, n / 4096));
@@ -137,8 +133,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   } else {
     // big inputs: finer slices also keep the round-1 gathers of neighbouring lanes inside one Infinity-Cache-sized
     // range of point rows (measured: 193 -> 183 ms at 2^26); small inputs: fewer, larger blocks (less fixed cost)
-    uint64_t mult = two_n >= (1ull << 27) ? 8 : two_n >= (1ull << 24) ? 4 : 2;   // measured 2^21 .. 2^26
-    MSM_KNOB(mult, "MSM_SORTB_MULT", 1);
+    const uint64_t mult = two_n >= (1ull << 27) ? 8 : two_n >= (1ull << 24) ? 4 : 2;   // measured 2^21 .. 2^26
     uint64_t want = std::max<uint64_t>(1, (mult * ctx->n_cu + kc - 1) / kc);
     uint64_t maxb = std::max<uint64_t>(1, two_n / 8192);
     sortB = (uint32_t)std::min<uint64_t>(want, maxb);
@@ -152,14 +147,12 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   // here because the count pass of the bin split prepares the parts of heavy bins for that pass.
   bool will_chunk = false;
   {
-    // from more than 2^23 rows of 256 bytes = 2 GB (measured, tools/chunk_plain.py and MSM_CHUNK_LOG of the tuning build: at
+    // from more than 2^23 rows of 256 bytes = 2 GB (measured, tools/chunk_plain.py on the round-5 tuning build: at
     // 2^23 rows -- 2^23 points, or 2^20 on seven window tables -- the plain slot form is 2.5 % ahead: 20.15 against 20.64 ms,
     // 3.23 / 3.32; at 2^23.8 rows level; at 2^24 rows the tile order wins by 10 %: 38.6 against 43.0)
-    long long chunk_rows_log = 23;
-    MSM_KNOB(chunk_rows_log, "MSM_CHUNK_LOG", 10);
+    const int chunk_rows_log = 23;
     const uint64_t table_rows = pl.tables ? (uint64_t)kc_d * n : n;
-    long long want_chunks = (bin_split && !te && pl.c >= 18 && table_rows > (1ull << chunk_rows_log)) ? 1 : 0;
-    MSM_KNOB(want_chunks, "MSM_CHUNKED", 0);
+    const bool want_chunks = bin_split && !te && pl.c >= 18 && table_rows > (1ull << chunk_rows_log);
     // (round 2 must be an index-free round to read the element records round 1 then writes: logG >= 2)
     will_chunk = bin_split && want_chunks && !te && logG >= 2;
   }

@@ -47,8 +47,6 @@ void accumulate_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const Plan& pl
       r_stop++;
   }
   // outputs alternate between two buffers: size each for the largest round it receives
-  long long scratch_pad = 0;   // lanes added to the scratch plane stride (experiment: power-of-two strides vs HBM channels)
-  MSM_KNOB(scratch_pad, "MSM_SCRATCH_PAD", 0);
   uint64_t capA = 1, capB = 1;
   {
     int which = 0;
@@ -83,7 +81,7 @@ void accumulate_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const Plan& pl
     for (uint32_t r = 1; r <= logG; r++) {
       uint64_t n_out = n_in / 2;
       RoundGeom g = round_geom(ctx, n_out, r == 1 || (r == 2 && chunked) || te, lone);   // no inversion on the Edwards path: always two waves
-      const uint64_t sstride = g.T + scratch_pad;
+      const uint64_t sstride = g.T;
       if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * sstride * 4);
       BatchArgs a{};
       // (on window tables the payloads count rows of the tables, which live in `rows` or, for a range of the points, in `tabs`)
@@ -123,7 +121,7 @@ void accumulate_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const Plan& pl
     for (int r = 1; r <= r_stop; r++) {
       uint64_t n_out = w.h_info[3 + r];
       RoundGeom g = round_geom(ctx, n_out, te);
-      const uint64_t sstride = g.T + scratch_pad;
+      const uint64_t sstride = g.T;
       if (!te) ctx->ensure(w.scratch, (size_t)g.steps * NL * sstride * 4);
       BatchArgs a{};
       a.in = buf[cur ^ 1];

@@ -16,7 +16,7 @@ for i in range(4):
 print(json.dumps({"ms": round(best * 1e3, 3), "phase": {k: round(v, 2) for k, v in info["phase_ms"].items()}}))
 '''
 for lg in (16, 18, 20, 22):
-    for v in ("", "MSM_PBL=4", "MSM_PBL=16", "MSM_FINISH_MAX=8", "MSM_FINISH_MAX=16", "MSM_FINISH_MAX=64", "MSM_TAIL_MIN=262144", "MSM_TC=2", "MSM_TC=8", "MSM_GROUPS=2", "MSM_SORTB_MULT=1", "MSM_SORTB_MULT=8"):
+    for v in ("", "MSM_PBL=4", "MSM_PBL=16", "MSM_FINISH_MAX=8", "MSM_FINISH_MAX=16", "MSM_FINISH_MAX=64", "MSM_TAIL_MIN=262144", "MSM_TC=2", "MSM_TC=8", "MSM_GROUPS=2"):
         env = dict(os.environ)
         if v:
             k, val = v.split("="); env[k] = val
