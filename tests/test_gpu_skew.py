@@ -75,3 +75,27 @@ def test_one_scalar_repeated_over_degenerate_points(gpu_ctx):
             res, info = gpu_ctx.run(sb, c=c, no_tables=True)
             assert res.as_tuple() == exp, (c, info)
     gpu_ctx.set_points(O.points_to_bytes([P], 48))
+
+
+@pytest.mark.parametrize("kind", ["one", "prover"])
+def test_skewed_scalars_on_the_edwards_path(c_oracle, kind):
+    """Ed-on-BLS12-377 at 2^22: the 18-bit windows of the plain path take the bin split (padded slots), whose heavy bins are cut
+    into parts like the Weierstrass ones; and the same input on window tables (one merged window).  Scalars above the 251-bit
+    group order are reduced by the library (msm_opts.strict = 0), the expected value is taken mod q as well."""
+    from montgomery_amd import _lib
+    from montgomery_amd.api import MsmContext
+
+    E = O.ED_ON_BLS12_377
+    n = 1 << 22
+    ctx = MsmContext(_lib.CURVE_ED_ON_BLS12_377)
+    try:
+        a = ctx.generate_points(n, seed=977, want_scalars=True, raw=True)
+        s = workloads.scalars(kind, n, seed=22)
+        k = c_oracle.dot_mod(a, s.tobytes(), n, E.q)
+        exp = O.te_to_affine(O.te_scale(k, O.te_from_affine((E.gx, E.gy), E), E), E)
+        plain, ip = ctx.run(s.tobytes(), no_tables=True)
+        assert ip["c"] == 18 and (plain.x, plain.y) == exp, ip
+        tab, it = ctx.run(s.tobytes())
+        assert it["tables"] and (tab.x, tab.y) == exp, it
+    finally:
+        ctx.close()
