@@ -54,7 +54,7 @@ PAIR_MADS_SURVEY = 1800
 # (tools/pmc_headline.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled: gfx950 halves wide coalesced
 # reads); the round-3 constant (2^24, regular rounds only) if that file is missing
 PAIR_TRAFFIC_BYTES_PMC = 488
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_2p26.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_2p26.json")
 
 
 def pmc_summary(curve, log2n, window_bits):
@@ -721,7 +721,7 @@ def main():
                 "traffic_note": ("HBM bytes per launch = algorithmic pair additions per launch x the measured bytes per pair addition of "
                                  + os.path.relpath(PMC_FILE, ROOT) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
                                  "command at this size, curve and window; not collected inside this run)") if pmc else
-                                "null: the committed PMC summary was taken at another size, curve or window (profiles/r05_pmc_2p26.json: "
+                                "null: the committed PMC summary was taken at another size, curve or window (profiles/r06_pmc_2p26.json: "
                                 "BLS12-377, 2^26, 21-bit windows)",
                 "traffic_bytes_per_pair_add": pmc["per_pair_addition"]["all_rounds"]["hbm_bytes_per_pair_add"] if pmc else None,
                 "pair_adds_per_step": pairs / max(len(infos), 1),

@@ -1,7 +1,7 @@
 """Copies the judged summaries of one profiling run (gpurun_out/prof_<tag>/) into profiles/ (tracked)."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 for name, dst in (("trace26", f"{tag}_kernel_stats_2p26.csv"), ("trace20", f"{tag}_kernel_stats_2p20.csv"), ("trace_ed20", f"{tag}_kernel_stats_ed377_2p20.csv")):
@@ -10,7 +10,8 @@ for name, dst in (("trace26", f"{tag}_kernel_stats_2p26.csv"), ("trace20", f"{ta
         shutil.copy(f[-1], f"profiles/{dst}")
 for name in ("bench_2p26.json", "bench_2p20.json", "bench_ed377_2p20.json", "bench_bls381_2p26.json", "bench_bls381_2p20.json",
              "ubench_exec.txt", "ubench_occ.txt", "ubench_bt.txt", "ubench_inv.txt", "ubench_int2.txt", "ubench_mul2.txt", "ubench_mad3.txt",
-             "ubench_gather.txt", "ubench_carry.txt", "cpu_baseline.json", "bench_2rank_gloo_2p22.json", "js_bench_2p20.txt"):
+             "ubench_gather.txt", "ubench_carry.txt", "cpu_baseline.json", "bench_2rank_gloo_2p22.json", "js_bench_2p20.txt", "shard_proxy.txt",
+             "skew_time.txt"):
     if os.path.exists(f"{src}/{name}"):
         shutil.copy(f"{src}/{name}", f"profiles/{tag}_{name}")
 out = {}

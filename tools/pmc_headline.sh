@@ -3,7 +3,7 @@
 # trace domains), as MI355X_MICROARCH.md prescribes.  usage: tools/pmc_headline.sh TAG [LOG2N] [extra bench.py arguments, e.g. --c 16]
 # Every run holds two MSMs (the timed step and the serialised "exclusive" one); tools/collect_pmc.py TAG LOG2N turns the
 # counter files into profiles/<TAG>_pmc_2p<LOG2N>.json with per-pair-addition figures.
-TAG=${1:-r05}; LG=${2:-26}; EXTRA="${@:3}"
+TAG=${1:-r06}; LG=${2:-26}; EXTRA="${@:3}"
 CURVE=bls12-377; SFX=""
 case "$EXTRA" in *"--curve ed377"*) CURVE=ed377; SFX=_ed377;; esac
 cd "$(dirname "$0")/.."
@@ -11,7 +11,7 @@ REPO=$PWD
 export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/pmc_${TAG}${SFX}_2p$LG
 rm -rf $OUT; mkdir -p $OUT
-PM="python3 $REPO/bench.py --steps 1 --warmup 0 --log2n $LG --no-cpu-baseline --no-verify --no-other-configs --no-pcie --no-c16 --no-tables-leg $EXTRA"
+PM="python3 $REPO/bench.py --steps 1 --warmup 0 --log2n $LG --no-cpu-baseline --no-verify --no-other-configs --no-pcie --no-c16 --no-tables-leg --no-skewed $EXTRA"
 cd /tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PM > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PM > $OUT/pmc_write.log 2>&1
