@@ -63,9 +63,9 @@ def choose_window(plan: Callable[[int, Optional[int]], Tuple[int, int]], n: int,
     by points: every rank runs a whole MSM over n / world points -- the window the library picks for THAT size (on the window
       tables of the rank's range of the points where they fit: `window_sums(..., merged=True)`);
     by windows: a rank runs K / world windows over all points.  The big windows a single GPU takes from 2^24 points (K = 6)
-      neither divide among 4 or 8 ranks nor pay for a shard of three windows, which has no second window group of its own
-      size beside it (tools/shard_time.py at 2^26, 2 ranks: 84.1 ms with three 22-bit windows against 81 with four 16-bit
-      ones): c = 16 (K = 8) whenever the ranks divide its windows, else the pick for a rank's share of the points."""
+      do not divide among 4 or 8 ranks: the single-GPU plan where the ranks divide its K (2 ranks at 2^26: three 21-bit windows
+      each -- since the round-5 sort 72.4 ms against 78.9 for four 16-bit ones, tools/window_shard_time.py), else c = 16
+      (K = 8) where they divide that, else the pick for a rank's share of the points."""
     def plain(m, c):
         # shards always run the plain path (msm_window_sums): a `plan` that knows window tables (MsmContext.plan) is asked for
         # the plain plan, one that takes (n, c) only -- the CPU tests' -- is the plain plan already
@@ -84,6 +84,11 @@ def choose_window(plan: Callable[[int, Optional[int]], Tuple[int, int]], n: int,
     if world <= 1 or split == "buckets":   # a bucket-range shard keeps the single-GPU plan: every rank runs all of its windows
         return plain(n, None)
     if split != "points":
+        # the single-GPU plan where the ranks divide its windows (2^26 on 2 ranks: three 21-bit windows each, 72.4 ms against
+        # 78.9 for four 16-bit ones -- profiles/r06_experiments.txt item 9), else K = 8
+        c1, K1 = plain(n, None)
+        if K1 % world == 0:
+            return c1, K1
         c16, K16 = plain(n, 16)
         if K16 % world == 0:
             return c16, K16

@@ -245,12 +245,14 @@ def test_choose_window_for_shards():
 
     n = 1 << 26
     assert choose_window(plan, n, 1, "windows") == (21, 6)
-    for world in (2, 4, 8):
+    assert choose_window(plan, n, 2, "windows") == (21, 6)              # the single-GPU plan divides: three windows per rank
+    assert choose_window(plan, n, 6, "windows") == (21, 6)
+    for world in (4, 8):
         assert choose_window(plan, n, world, "windows") == (16, 8)      # K = 8 divides: every rank the same number of windows
     assert choose_window(plan, n, 2, "points") == (21, 6)               # a share of 2^25 points: the library's pick for it
     assert choose_window(plan, n, 4, "points") == (21, 6)
     assert choose_window(plan, n, 8, "points") == (18, 7)               # 2^23 points per rank
-    assert choose_window(plan, n, 3, "windows") == (21, 6)              # 8 does not divide by 3: the pick for a rank's share
+    assert choose_window(plan, n, 3, "windows") == (21, 6)              # K = 6 divides by 3
     assert choose_window(plan, 1 << 20, 8, "windows") == (16, 8)
     for world in (2, 3, 8):
         assert choose_window(plan, n, world, "buckets") == (21, 6)        # a bucket-range shard keeps the single-GPU plan
