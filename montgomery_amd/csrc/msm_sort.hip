@@ -323,7 +323,13 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     ctx->ensure(w.slots, std::max<uint64_t>(total_slots, 2) * 4);
     HIPCHK(hipMemsetAsync(w.slots.p, 0xFF, std::max<uint64_t>(total_slots, 2) * 4, s));
     round1_slots = (const uint32_t*)w.slots.p;
-    if (radix) {
+    // The last pass of the radix split gives one block to a coarse bin: a bucket that holds far more than a bin's share of the
+    // entries (one scalar repeated: a whole window in one bucket) would make one block walk them all.  The histogram is the
+    // one-level sort's, so such an input -- the host has the largest bucket by now -- takes the one-level scatter instead, which
+    // splits the ENTRIES across the blocks (its partial-line writes do not matter when most payloads go to a few long runs):
+    // one scalar repeated at 2^20 points, sort phase 1.39 -> 0.4x ms.
+    const bool heavy = radix && max_bucket >= (1u << 16) && (uint64_t)max_bucket * Hn >= 16 * two_n;
+    if (radix && !heavy) {
       // pass A: coarse split into dig2 / idx2; pass B: one block per coarse bin, payloads to their padded slots
       ctx->ensure(w.part, ((size_t)kc * sortB * Hn + 2 * (size_t)V + 2) * 4);
       uint32_t* d_blk_off = (uint32_t*)w.part.p;
@@ -339,7 +345,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
                          (const uint32_t*)d_vstart, (const uint32_t*)d_blk_off, (const uint32_t*)w.dig.p, two_n, chunk, Hn, ws);
       hipLaunchKernelGGL(k_radix_fine, dim3(V), dim3(RXB_THREADS), 0, s, (uint32_t*)w.slots.p, (const uint32_t*)w.cursor.p,
                          (const uint32_t*)d_vstart, (const uint32_t*)w.dig2.p, (const uint32_t*)w.idx2.p, Hn, L, ws);
-    } else if (one_level) {
+    } else {
       hipLaunchKernelGGL(k_scatter_lds, dim3(sortB, kc), dim3(SORT_THREADS), (size_t)L * 4, s, (uint32_t*)w.slots.p,
                          (const uint32_t*)w.cursor.p, (const uint32_t*)w.block_hist.p, (const uint32_t*)w.dig.p, two_n,
                          chunk, L);
