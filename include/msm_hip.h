@@ -207,7 +207,9 @@ int msm_run(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const 
  * only (src/msm-batched-affine.ts:42 "P_k = sum_l l * B_(k,l)") and writes them as
  * (k_hi - k_lo) x 144 bytes: X || Y || Z homogeneous projective, 48-byte little-endian canonical
  * integers (twisted Edwards: the extended point without T, which msm_combine rebuilds from T Z = X Y).
- * Ranks exchange these with one all-gather; msm_combine finishes. */
+ * Ranks exchange these with one all-gather; msm_combine finishes.  With msm_opts.merged_sums the slots may come back merged
+ * (first slot: sum_k 2^(c (k - k_lo)) P_k, the others the identity), which either combine takes unchanged, and the call may run
+ * on window tables (msm_result.tables says whether it did). */
 int msm_window_sums(msm_ctx* ctx, const void* scalars, uint64_t n, int on_device, const msm_opts* opts,
                     uint8_t* partials_out, msm_result* stats);
 
@@ -227,7 +229,8 @@ int msm_combine_groups(int curve, const uint8_t* partials, int32_t G, int32_t K,
 
 /* Window plan for n points: the c the library would pick (opts->c forces one) and the resulting K (see msm_opts.c).  It is the
  * plan of msm_run over DEVICE-RESIDENT scalars: over the whole current point set that is the plan on window tables where they
- * exist or would be built (opts->no_tables: the plain plan, which msm_window_sums and every shard of the points always run).
+ * exist or would be built (opts->no_tables: the plain plan, which msm_window_sums without merged_sums and bucket-range shards run;
+ * opts->merged_sums: the plan of msm_window_sums(merged_sums) over the range [point_lo, point_lo + n), on its tables where they fit).
  * Host scalars of 2^24 points and more cross PCIe behind the computation: msm_run then runs whole MSMs over growing ranges of
  * the points, each under the plan of ITS size, and msm_result reports the plan of the last, biggest range. */
 int msm_plan(const msm_ctx* ctx, uint64_t n, const msm_opts* opts, int32_t* c_out, int32_t* K_out);
