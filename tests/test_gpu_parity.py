@@ -371,7 +371,7 @@ def test_msm_2p26_known_discrete_logs(gpu_ctx, c_oracle):
         assert pinfo["tables"], pinfo
         groups += part
     assert combine_groups_host(groups, 8, Ks, cs, _lib.CURVE_BLS12_377_G1) == res.as_tuple()
-    gpu_ctx.precompute(4096, point_lo=0)   # (give the 15 GB back: tables of a tiny range)
+    gpu_ctx.precompute(4096, point_lo=0)   # (tables of a tiny range from here on; the 15 GB buffer goes back with the next point set)
     # and eight bucket-range shards (`--split buckets`): the single-GPU plan, every rank an eighth of every window's buckets
     groups = b"".join(gpu_ctx.window_sums(dev, n, 0, 6, on_device=True, bucket_shard=(g, 8))[0] for g in range(8))
     assert combine_groups_host(groups, 8, 6, 21, _lib.CURVE_BLS12_377_G1) == res.as_tuple()

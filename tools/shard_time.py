@@ -38,7 +38,7 @@ for G in (2, 4, 8):
     ctx.precompute(m, c=cp, point_lo=first)
     tpt, ipt = best_of(lambda: ctx.window_sums(dev + 32 * first, m, 0, Kp, c=cp, on_device=True, point_lo=first, merged=True))
     on_tab = bool(ipt["tables"])
-    ctx.precompute(4096, point_lo=0)   # (give the range's tables back)
+    ctx.precompute(4096, point_lo=0)   # (tables of a tiny range from here on: the other shards run the plain path)
     # bucket shard: the single-GPU plan, the slowest of the first and the last range of the buckets
     tb, ib = max((best_of(lambda g=g: ctx.window_sums(dev, n, 0, K, c=c, on_device=True, bucket_shard=(g, G))) for g in (0, G - 1)), key=lambda x: x[0])
     print(f"G = {G}: window shard (c = {cw}, {w} of {Kw} windows) {tw:.1f} ms (top windows {tt:.1f})  -> x{full / tw:.2f}   "
