@@ -107,7 +107,9 @@ int window_sums_once(msm_ctx* ctx, const void* scalars, uint64_t n, int on_devic
   // per-group latencies (read-backs, bucket reduction depth) cost more than the overlap returns
   // (on window tables from 2^21: 5.87 -> 5.73 ms, Edwards 3.96 -> 3.72; the plain path at 2^21 prefers one group, 6.71 / 6.88; at
   // 2^20 one group wins on tables too, 3.24 / 3.33 -- round 5, tools/knob_sweep.sh MSM_GROUPS)
-  int want_groups = (nwin >= 2 && (n >= (1ull << 22) || (pl.tables && n >= (1ull << 21)))) ? 2 : 1;
+  // (round 6: the Edwards path on tables from 2^20 -- fifteen digit windows in one group leave the chip to one stream's ramps:
+  // 2.19 - 2.24 -> 2.13 - 2.18 ms; BLS12-377 at 2^20 is level, 3.44 / 3.41, and stays on one group)
+  int want_groups = (nwin >= 2 && (n >= (1ull << 22) || (pl.tables && n >= (ctx->is_te() ? 1ull << 20 : 1ull << 21)))) ? 2 : 1;
   MSM_KNOB(want_groups, "MSM_GROUPS", 1);
   wpg = std::max(1, std::min(wpg, (nwin + want_groups - 1) / want_groups));
   struct Group {
