@@ -209,7 +209,17 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     // (on tables the slices of all kc_d digit windows are the slices of the one merged window, in the same row order)
     hipLaunchKernelGGL(k_slice_scan, dim3((hb + 31) / 32, kc), dim3(1024), 0, s, hist_p, d_bin_tot,
                        pl.tables ? sortB * (uint32_t)kc_d : sortB, hb, (uint32_t)kc);
-    hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_bin_start, (const uint32_t*)d_bin_tot, V, (uint32_t*)w.info.p);
+    // heavy bins are cut into parts of part_len records, one block each (sort_kernels.h, "Parts of heavy bins"): twice the mean
+    // bin, so that uniform digits never see one; a multiple of the tile of pass B.  The table comes out of k_vscan.
+    part_len = (uint32_t)std::max<uint64_t>(1u << 16, ((2 * n_entries / V + BP_TILE - 1) / BP_TILE) * BP_TILE);
+    part_grid = V + V / 2 + 1;
+    ctx->ensure(w.parts, ((size_t)2 * (V + 1) + (V + 2)) * 4);
+    d_extra_first = (uint32_t*)w.parts.p;
+    d_mp_first = d_extra_first + (V + 1);
+    d_part_pair_off = d_mp_first + (V + 1);
+    PartTables ptab{d_extra_first, d_mp_first, d_part_pair_off, hb, part_len, {}};
+    for (int kk = 0; kk < 16; kk++) ptab.fb[kk] = ws.fb[kk];
+    hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_bin_start, (const uint32_t*)d_bin_tot, V, (uint32_t*)w.info.p, ptab);
     // a block of pass A takes as many consecutive slices of the digit kernel as make two tiles
     const uint32_t per_block = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(sortB, std::max<uint64_t>(1, (1ull << BS_SPAN_LOG) / chunk)),
                                                             std::max<uint64_t>(1, (2 * (uint64_t)BS_TILE + chunk - 1) / chunk));
@@ -221,17 +231,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
     bool spans_all = true;
     for (int kk = 0; kk < kc; kk++) spans_all &= (1u << ws.ab[kk]) == hb && (int)ws.ab[kk] + (int)ws.fb[kk] == cbits;
     if (!spans_all) HIPCHK(hipMemsetAsync(w.counts.p, 0, nb * 4, s));   // (`info` was cleared by k_vscan)
-    // heavy bins are cut into parts of part_len records, one block each (sort_kernels.h, "Parts of heavy bins"): twice the mean
-    // bin, so that uniform digits never see one; a multiple of the tile of pass B
-    part_len = (uint32_t)std::max<uint64_t>(1u << 16, ((2 * n_entries / V + BP_TILE - 1) / BP_TILE) * BP_TILE);
-    part_grid = V + V / 2 + 1;
-    ctx->ensure(w.parts, ((size_t)2 * (V + 1) + (V + 2)) * 4);
-    d_extra_first = (uint32_t*)w.parts.p;
-    d_mp_first = d_extra_first + (V + 1);
-    d_part_pair_off = d_mp_first + (V + 1);
     ctx->ensure(w.sub, (size_t)(V + 2) * nbmax * 4);   // rows: the parts of multi-part bins, at most V of them
-    hipLaunchKernelGGL(k_bin_parts, dim3(1), dim3(SCAN_THREADS), 0, s, d_extra_first, d_mp_first, (const uint32_t*)d_bin_start, V, hb, part_len, ws);
-    HIPCHK(hipMemsetAsync(d_part_pair_off, 0, (size_t)(V + 2) * 4, s));
     hipLaunchKernelGGL(k_bin_count, dim3(part_grid), dim3(BC_THREADS), (size_t)nbmax * 4, s, (uint32_t*)w.counts.p, (const uint32_t*)d_bin_start,
                        (const uint2*)w.rec.p, hb, L, ws, (uint32_t*)w.info.p, V, (const uint32_t*)d_extra_first, (const uint32_t*)d_mp_first,
                        part_len, (uint32_t*)w.sub.p, nbmax);
@@ -340,7 +340,7 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
       const uint64_t co = (uint64_t)kc * (sortB + 1) * Hn;
       hipLaunchKernelGGL(k_coarse_offsets, dim3((uint32_t)((co + 255) / 256)), dim3(256), 0, s, d_blk_off, d_vtot,
                          (const uint32_t*)w.block_hist.p, (const uint32_t*)w.counts.p, sortB, L, Hn, (uint32_t)kc);
-      hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_vstart, (const uint32_t*)d_vtot, V, (uint32_t*)nullptr);
+      hipLaunchKernelGGL(k_vscan, dim3(1), dim3(SCAN_THREADS), 0, s, d_vstart, (const uint32_t*)d_vtot, V, (uint32_t*)nullptr, PartTables{});
       hipLaunchKernelGGL(k_radix_coarse, dim3(sortB, kc), dim3(RX_THREADS), 0, s, (uint32_t*)w.dig2.p, (uint32_t*)w.idx2.p,
                          (const uint32_t*)d_vstart, (const uint32_t*)d_blk_off, (const uint32_t*)w.dig.p, two_n, chunk, Hn, ws);
       hipLaunchKernelGGL(k_radix_fine, dim3(V), dim3(RXB_THREADS), 0, s, (uint32_t*)w.slots.p, (const uint32_t*)w.cursor.p,

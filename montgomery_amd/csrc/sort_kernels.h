@@ -402,14 +402,24 @@ __global__ void __launch_bounds__(256) k_coarse_offsets(uint32_t* blk_off, uint3
 #endif
 
 // (zero64: 64 words this launch clears on the way -- the `info` block of the bucket scans -- or null: one fill fewer in the stream)
-__global__ void __launch_bounds__(SCAN_THREADS) k_vscan(uint32_t* v_start, const uint32_t* v_tot, uint32_t V, uint32_t* zero64)
+// The bin split also takes its part table from here (see "Parts of heavy bins" below; v_tot[v] is the size of bin v): extra_first[v]
+// = parts beyond the first of the bins before v, mp_first[v] = rows of `sub` of the bins before v (V + 1 entries each), and
+// part_pair_off (V + 2 words) is cleared for k_part_scan -- one launch instead of three in front of the count pass.
+struct PartTables {
+  uint32_t* extra_first;   // nullptr: no part table (radix split)
+  uint32_t* mp_first;
+  uint32_t* part_pair_off;
+  uint32_t hb, part_len;
+  uint8_t fb[16];
+};
+__global__ void __launch_bounds__(SCAN_THREADS) k_vscan(uint32_t* v_start, const uint32_t* v_tot, uint32_t V, uint32_t* zero64, PartTables pt)
 #ifndef MSM_SORT_TU
     ;
 #else
 {
   __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
   if (zero64 && threadIdx.x < 64) zero64[threadIdx.x] = 0;
-  uint32_t carry = 0;
+  uint32_t carry = 0, carry_e = 0, carry_m = 0;
   for (uint32_t base = 0; base < V; base += SCAN_THREADS) {
     const uint32_t i = base + threadIdx.x;
     const uint32_t v = i < V ? v_tot[i] : 0u;
@@ -418,8 +428,24 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_vscan(uint32_t* v_start, const
     if (i < V) v_start[i] = ex;
     carry += tot;
     __syncthreads();
+    if (pt.extra_first) {   // uniform
+      uint32_t np = 1;
+      if (i < V && pt.fb[i / pt.hb] != 0 && v > pt.part_len) np = (v + pt.part_len - 1) / pt.part_len;   // (a window pass A sorted outright has no parts)
+      uint32_t tot_e, tot_m;
+      const uint32_t ex_e = block_excl_scan(np - 1, lds_wave, tot_e) + carry_e;
+      __syncthreads();
+      const uint32_t ex_m = block_excl_scan(np > 1 ? np : 0u, lds_wave, tot_m) + carry_m;
+      __syncthreads();
+      if (i < V) { pt.extra_first[i] = ex_e; pt.mp_first[i] = ex_m; }
+      carry_e += tot_e;
+      carry_m += tot_m;
+    }
   }
   if (threadIdx.x == 0) v_start[V] = carry;
+  if (pt.extra_first) {
+    if (threadIdx.x == 0) { pt.extra_first[V] = carry_e; pt.mp_first[V] = carry_m; }
+    for (uint32_t j = threadIdx.x; j < V + 2; j += SCAN_THREADS) pt.part_pair_off[j] = 0;
+  }
 }
 #endif
 
@@ -752,8 +778,8 @@ __global__ void __launch_bounds__(BS_THREADS) k_bin_split(uint2* rec, const uint
 //     so a bucket's round-1 elements are the concatenation of ceil(n_part / 2) per part: `counts` gets 2 * that sum (the slots a
 //     bucket is padded from), the prefix is in elements, and part_pair_off[row] says where in the bin's run of the pair list the
 //     part starts;  slots (k_bin_slots): the prefix is in entries and `counts` is the true size.
-// Uniform digits never have a multi-part bin: one extra launch (k_part_scan, every block returns at once) and V / 2 blocks of
-// the two passes that return at once.
+// The part table comes out of k_vscan (it has the bin sizes in hand).  Uniform digits never have a multi-part bin: one extra
+// launch (k_part_scan, every block returns at once) and V / 2 blocks of the two passes that return at once.
 // ---------------------------------------------------------------------------------------------
 struct PartLoc {
   uint32_t v, j, np, row;   // bin, part of the bin, parts of the bin, row of `sub` (np > 1)
@@ -786,35 +812,6 @@ __device__ __forceinline__ PartLoc locate_part(uint32_t p, uint32_t V, const uin
   L.end = L.np == 1 ? b1 : min(b1, L.beg + (uint64_t)part_len);
   return L;
 }
-
-// extra_first[v] = parts beyond the first of the bins before v, mp_first[v] = rows of `sub` of the bins before v (V + 1 entries each)
-__global__ void __launch_bounds__(SCAN_THREADS) k_bin_parts(uint32_t* extra_first, uint32_t* mp_first, const uint32_t* bin_start, uint32_t V,
-                                                            uint32_t hb, uint32_t part_len, WinSplit ws)
-#ifndef MSM_SORT_TU
-    ;
-#else
-{
-  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
-  uint32_t carry_e = 0, carry_m = 0;
-  for (uint32_t base = 0; base < V; base += SCAN_THREADS) {
-    const uint32_t v = base + threadIdx.x;
-    uint32_t np = 1;
-    if (v < V) {
-      const uint32_t kk = v / hb, size = bin_start[v + 1] - bin_start[v];
-      if (ws.fb[kk] != 0 && size > part_len) np = (size + part_len - 1) / part_len;   // (a window pass A sorted outright has no parts)
-    }
-    uint32_t tot_e, tot_m;
-    const uint32_t ex_e = block_excl_scan(np - 1, lds_wave, tot_e) + carry_e;
-    __syncthreads();
-    const uint32_t ex_m = block_excl_scan(np > 1 ? np : 0u, lds_wave, tot_m) + carry_m;
-    __syncthreads();
-    if (v < V) { extra_first[v] = ex_e; mp_first[v] = ex_m; }
-    carry_e += tot_e;
-    carry_m += tot_m;
-  }
-  if (threadIdx.x == 0) { extra_first[V] = carry_e; mp_first[V] = carry_m; }
-}
-#endif
 
 // Bins of several parts: sub[row of part j][bucket] = the part's entries of the bucket (k_bin_count) -> the exclusive prefix over
 // the parts, in round-1 elements (pairs_mode: ceil(n / 2) per part) or in entries; counts[bucket] = 2 * the sum of the parts'
