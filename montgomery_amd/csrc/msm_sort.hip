@@ -82,7 +82,6 @@ void sort_window_group(msm_ctx* ctx, msm_ctx::Workspace& w, const uint32_t* d_sc
   const bool want_bins = !fits_lds || (pl.tables && two_n >= (1ull << 22));
   const bool bin_split = !fits_lds || want_bins;
   const bool radix = !bin_split && want_radix && cbits > (int)RX_FINE_BITS && cbits - (int)RX_FINE_BITS <= 8;
-  const bool one_level = !bin_split && !radix;
   WinSplit ws{};
   uint32_t hb = 1, nbmax = 1;   // bin split: coarse bins per window (stride of the bin tables), most buckets of one bin
   if (bin_split) {

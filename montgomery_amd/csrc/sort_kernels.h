@@ -1,6 +1,6 @@
-// Curve-independent kernels of the MSM pipeline: bucket-size scans, the LDS-privatised counting sort (one level for small
-// inputs, LDS-staged two-pass split for c <= 16, three-pass split up to the largest accepted window c = 24) and the operand
-// descriptors of the tail rounds (tree_kernels.h).
+// Curve-independent kernels of the MSM pipeline: bucket-size scans and the LDS-privatised counting sort -- one level for small
+// inputs, the LDS-staged two-pass radix split for c <= 16, the two-pass bin split (8-byte records, pairs of round 1 out of its
+// second pass, heavy bins cut into parts) up to the largest accepted window c = 24.
 // (reference phases: integrateBucketCounts src/msm-batched-affine.ts:423-447, sortPoints :456-502)
 // Defined in sort_kernels.hip (MSM_SORT_TU); the host translation units see declarations.  The curve-templated kernels live in
 // msm_kernels.h, the kernels around the tree rounds in tree_kernels.h.
